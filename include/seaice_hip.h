@@ -1,0 +1,188 @@
+/*
+ * seaice_hip.h -- C ABI of the MI355X-native sea-ice dynamics library (libseaice_hip.so).
+ *
+ * This is the boundary a host model binds to (Fortran ISO_C_BINDING, ctypes, ...).  It replaces,
+ * for one MPAS block per context, the reference's velocity-solver entry points:
+ *
+ *   seaice_mesh_pool_create / _destroy   src/shared/mpas_seaice_mesh_pool.F:76, 188
+ *   seaice_init_velocity_solver          src/shared/mpas_seaice_velocity_solver.F:85
+ *   seaice_run_velocity_solver           src/shared/mpas_seaice_velocity_solver.F:562
+ *     velocity_solver_pre_subcycle       :613     subcycle_velocity_solver  :2404
+ *     velocity_solver_post_subcycle      :3360
+ *   mpas_dmpar_field_halo_exch (pack / unpack halves only; the transport stays with the host)
+ *
+ * Conventions
+ *   - Plain pointers and sizes only.  Host arrays use the reference's layout: Fortran order, float64
+ *     (RKIND) / int32, connectivity 1-based with "nX+1" meaning "no neighbour".  Arrays may be
+ *     longer than the logical extent (MPAS allocates nCells+1); only the logical part is touched.
+ *   - Fields live on the device under their Registry.xml names (src/Registry.xml:3691-3765 and
+ *     the pools listed in sih_field_put).  The library keeps its own renumbered, structure-of-arrays
+ *     copies; every put/get converts from/to the reference layout and numbering.
+ *   - Every function returns SIH_OK (0) or a positive error code; sih_last_error() gives the text.
+ *     An error corresponds to the reference's MPAS_LOG_CRIT abort: the caller must not continue.
+ *   - One host thread drives a context at a time (the reference solver is not re-entrant either:
+ *     module-level save variables, src/shared/mpas_seaice_velocity_solver.F:26-58).
+ */
+#ifndef SEAICE_HIP_H
+#define SEAICE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sih_ctx sih_ctx;
+
+enum {
+    SIH_OK = 0,
+    SIH_ERR_ARG = 1,        /* bad argument / unknown option (reference: "... unknown", MPAS_LOG_CRIT) */
+    SIH_ERR_HIP = 2,        /* HIP runtime failure */
+    SIH_ERR_STATE = 3,      /* call out of order (e.g. run before init) */
+    SIH_ERR_UNSUPPORTED = 4 /* option of the reference that is outside this library's scope */
+};
+
+/* Mesh description of one block: the `mesh` pool fields the dynamics read
+ * (src/Registry.xml:2251-2367).  All pointers are borrowed for the duration of the call. */
+typedef struct sih_mesh_desc {
+    int32_t nCells, nCellsSolve;
+    int32_t nVertices, nVerticesSolve;
+    int32_t nEdges, nEdgesSolve;
+    int32_t maxEdges, vertexDegree;
+    int32_t onASphere;          /* mesh attribute on_a_sphere */
+    double sphereRadius;        /* mesh attribute sphere_radius (after rescale_mesh) */
+    const int32_t *nEdgesOnCell;   /* (nCells) */
+    const int32_t *verticesOnCell; /* (maxEdges, nCells) */
+    const int32_t *cellsOnCell;    /* (maxEdges, nCells) */
+    const int32_t *edgesOnCell;    /* (maxEdges, nCells), may be NULL if advection is not used */
+    const int32_t *cellsOnVertex;  /* (vertexDegree, nVertices) */
+    const int32_t *cellsOnEdge;    /* (2, nEdges), may be NULL */
+    const int32_t *verticesOnEdge; /* (2, nEdges), may be NULL */
+    const double *xCell, *yCell, *zCell;       /* (nCells) */
+    const double *xVertex, *yVertex, *zVertex; /* (nVertices) */
+    const double *areaCell;                    /* (nCells) */
+    const double *areaTriangle;                /* (nVertices) */
+    const double *fVertex;                     /* (nVertices) */
+    const double *dvEdge, *dcEdge;             /* (nEdges), may be NULL */
+    int32_t renumber; /* 1: library renumbers cells/vertices internally for locality; 0: keep order */
+} sih_mesh_desc;
+
+/* Options read by the velocity solver (src/shared/mpas_seaice_velocity_solver.F:103-135, 792-798,
+ * 1378-1383; defaults in src/Registry.xml:566-647). */
+typedef struct sih_evp_config {
+    double dt;                        /* config_dt */
+    int32_t dynamicsSubcycleNumber;   /* config_dynamics_subcycle_number */
+    int32_t elasticSubcycleNumber;    /* config_elastic_subcycle_number */
+    int32_t constitutiveRelation;     /* 1 evp, 2 evp_revised, 3 linear */
+    int32_t variationalBasis;         /* 1 wachspress (computed on device), 0 none (host supplies it) */
+    int32_t variationalDenominator;   /* 0 original, 1 alternate */
+    int32_t wachspressIntegrationOrder; /* dunavant rule order; 8 is the reference default */
+    int32_t rotateCartesianGrid;
+    int32_t includeMetricTerms;
+    int32_t useAirStress;
+    int32_t useOceanStress;
+    int32_t oceanStressType;          /* 1 quadratic, 2 linear */
+    int32_t surfaceTilt;              /* 0 none, 1 geostrophic, 2 ssh gradient */
+    int32_t calcVelocityMasks;
+    int32_t useColumnPackage;         /* only selects ridgeConvergence/ridgeShear output; strength is Hibler */
+    int32_t nCategories;
+    double minEdgeLengthGlobal;       /* global min of dvEdge (mpas_dmpar_min_real in seaice_init_evp);
+                                         <= 0: use this block's own minimum */
+} sih_evp_config;
+
+/* ---- life cycle ----------------------------------------------------------------------------- */
+/* replaces seaice_mesh_pool_create (mesh_pool.F:76): uploads connectivity/geometry, builds the
+ * internal numbering.  `device` is the HIP device ordinal. */
+int sih_block_create(const sih_mesh_desc *mesh, int device, sih_ctx **ctx);
+/* replaces seaice_mesh_pool_destroy (mesh_pool.F:188) */
+int sih_block_destroy(sih_ctx *ctx);
+const char *sih_last_error(void);
+/* run on a caller-owned HIP stream (hipStream_t); NULL restores the context's own stream */
+int sih_set_stream(sih_ctx *ctx, void *hipStream);
+int sih_sync(sih_ctx *ctx);
+
+/* ---- initialisation ------------------------------------------------------------------------- */
+/* replaces the per-block part of seaice_init_velocity_solver (velocity_solver.F:85-252) and
+ * interior_vertices (mesh.F:423): time steps, EVP constants, metric terms, cellVerticesAtVertex,
+ * local coordinates, Wachspress basis gradients/integrals, variational denominator. */
+int sih_evp_init(sih_ctx *ctx, const sih_evp_config *cfg);
+/* re-pack the static basis after the host replaced basisGradient* / basisIntegrals* with its own
+ * (e.g. the piecewise-linear basis computed by the host model) */
+int sih_evp_static_changed(sih_ctx *ctx);
+
+/* ---- fields --------------------------------------------------------------------------------- */
+/* Copy a named field host -> device (put) or device -> host (get) in the reference layout.
+ * `count` is the logical element count and is checked.  Names (pool : fields):
+ *   velocity_solver : uVelocity vVelocity uVelocityInitial vVelocityInitial solveStress solveVelocity
+ *       solveVelocityPrevious icePressure stressDivergenceU stressDivergenceV airStressCellU
+ *       airStressCellV airStressVertexU airStressVertexV uOceanVelocityVertex vOceanVelocityVertex
+ *       oceanStressU oceanStressV oceanStressCoeff oceanStressCellU oceanStressCellV
+ *       seaSurfaceTiltVertexU seaSurfaceTiltVertexV surfaceTiltForceU surfaceTiltForceV
+ *       totalMassVertexfVertex divergence shear
+ *   velocity_variational : strain11 strain22 strain12 stress11 stress22 stress12 replacementPressure
+ *       principalStress1 principalStress2 (maxEdges,nCells); basisGradientU basisGradientV
+ *       basisIntegralsU basisIntegralsV basisIntegralsMetric (maxEdges,maxEdges,nCells);
+ *       tanLatVertexRotatedOverRadius variationalDenominator (nVertices);
+ *       cellVerticesAtVertex (vertexDegree,nVertices)
+ *   icestate : iceAreaVertex totalMassVertex iceAreaCellInitial totalMassCell
+ *   tracers_aggregate : iceAreaCell iceVolumeCell snowVolumeCell
+ *   tracers : iceAreaCategory iceVolumeCategory snowVolumeCategory (ONE,nCategories,nCells)
+ *   ocean_coupling : uOceanVelocity vOceanVelocity seaSurfaceTiltU seaSurfaceTiltV landIceMask
+ *       landIceMaskVertex
+ *   atmos_coupling : uAirVelocity vAirVelocity airDensity
+ *   boundary : interiorVertex          ridging : ridgeConvergence ridgeShear */
+int sih_field_put(sih_ctx *ctx, const char *name, const void *host, size_t count);
+int sih_field_get(sih_ctx *ctx, const char *name, void *host, size_t count);
+/* logical element count of a field, and 8 (float64) or 4 (int32) in *elemSize; 0 if unknown */
+size_t sih_field_count(sih_ctx *ctx, const char *name, int *elemSize);
+
+/* ---- time step ------------------------------------------------------------------------------ */
+/* velocity_solver_pre_subcycle (velocity_solver.F:613-671) split where the reference exchanges
+ * halos, so that a multi-block host can exchange between stages:
+ *   stage 0: aggregate_mass_and_area, iceAreaCellInitial          -> halo iceAreaCellInitial,totalMassCell
+ *   stage 1: cell->vertex area/mass, stress and velocity masks    -> halo solveVelocity
+ *   stage 2: ocean velocity to vertices, new_ice_velocities       -> halo uVelocity,vVelocity
+ *   stage 3: ice_strength (Hibler), constant_air_stress           -> halo icePressure, airStressCellU/V
+ *   stage 4: air stress to vertices, coriolis, ocean_stress, surface_tilt, init_subcycle_variables
+ * stage -1 runs all of them back to back (single block). */
+int sih_evp_pre_subcycle(sih_ctx *ctx, int stage);
+/* n iterations of single_subcycle_velocity_solver (velocity_solver.F:2478-2592) without the halo
+ * exchange: strain, EVP stress, stress divergence, ocean stress coefficient, velocity solve.
+ * `last` != 0 marks the final iteration of the dynamics step: strain, replacementPressure,
+ * stressDivergenceU/V and oceanStressCoeff are only materialised then (they are overwritten every
+ * iteration and read by nothing else in between). */
+int sih_evp_subcycle(sih_ctx *ctx, int n, int last);
+/* velocity_solver_post_subcycle (velocity_solver.F:3360-3380):
+ *   stage 0: final_divergence_shear, principal stresses, ocean stress on vertices -> halo oceanStressU/V
+ *   stage 1: ocean stress vertex->cell, rescale;  stage -1: both */
+int sih_evp_post_subcycle(sih_ctx *ctx, int stage);
+/* whole seaice_run_velocity_solver for a block that needs no halo exchange */
+int sih_evp_run(sih_ctx *ctx);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* Like sih_evp_subcycle(n, 0) but brackets the launches with HIP events on the context's stream:
+ * totalMs = whole loop; every `sampleEvery`-th iteration additionally times its two kernels
+ * (cellMs / vertexMs = mean duration of the sampled launches).  useGraph != 0 replays a captured
+ * HIP graph of the n iterations instead of launching them one by one (no per-kernel samples then). */
+int sih_evp_subcycle_timed(sih_ctx *ctx, int n, int useGraph, int sampleEvery, double *totalMs,
+                           double *cellMs, double *vertexMs);
+
+/* ---- halo exchange (pack / unpack only) -------------------------------------------------------
+ * location: 0 cells, 1 vertices.  sendIdx / recvIdx are 1-based local indices, all neighbours
+ * concatenated in the order the host will lay the message buffers out. */
+int sih_halo_set_lists(sih_ctx *ctx, int location, int nSend, const int32_t *sendIdx, int nRecv,
+                       const int32_t *recvIdx);
+/* gather the listed entries of `nFields` fields (all of one location and type) into a DEVICE buffer:
+ * buf[f * nSend + i] = field_f(sendIdx[i]);  unpack scatters buf[f * nRecv + i] -> field_f(recvIdx[i]).
+ * Both are asynchronous on the context's stream. */
+int sih_halo_pack(sih_ctx *ctx, int location, int nFields, const char *const *names, void *deviceBuf);
+int sih_halo_unpack(sih_ctx *ctx, int location, int nFields, const char *const *names, const void *deviceBuf);
+
+/* introspection for tests and reports */
+int sih_get_info(sih_ctx *ctx, const char *key, double *value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEAICE_HIP_H */

@@ -1,0 +1,90 @@
+"""Synthetic idealised-forcing cases (deterministic, analytic) used by tests and bench.
+
+The reference's own idealised case is the planar "square" test: analytic wind
+(/root/reference/src/shared/mpas_seaice_testing.F:357-422), ocean gyre (:311-343) and a ramp of
+ice concentration with 2 m ice (:436-525).  Here the same fields are mapped onto the sphere
+through the rotated longitude / latitude (lambda', phi') of ``config_rotate_cartesian_grid``
+(x' = -z, y' = y, z' = x; /root/reference/src/shared/mpas_seaice_mesh.F:2367-2371), with
+X = (lambda' + pi) / 2 pi and Y = (phi' + pi/2) / pi playing the roles of x/Lx and y/Ly.
+Velocity components are (east', north') in that rotated frame, like the solver's.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .pools import Domain
+
+# config_dt per resolution, /root/reference/bld/namelist_files/namelist_defaults_mpassi.xml:8-12
+DT_BY_MESH = {"QU480": 7200.0, "QU240": 3600.0, "QU120": 1800.0, "QU60": 900.0, "QU30": 450.0}
+
+CATEGORY_AREA_FRACTION = np.array([0.10, 0.20, 0.30, 0.25, 0.15])
+CATEGORY_THICKNESS_FACTOR = np.array([0.3, 0.7, 1.0, 1.4, 2.0])
+
+
+def rotated_lonlat(x, y, z, radius, rotate=True):
+    if rotate:
+        xp, yp, zp = -z, y, x
+    else:
+        xp, yp, zp = x, y, z
+    return np.arctan2(yp, xp), np.arcsin(np.clip(zp / radius, -1.0, 1.0))
+
+
+def fill_idealised_state(block, time=0.0, open_water_band=None, rotate=True):
+    """Fill tracers, forcing and initial velocities of one block with the analytic case."""
+    mesh = block.structs["mesh"]
+    nC = block.dimensions["nCells"]
+    nCat = block.dimensions["nCategories"]
+    R = mesh["sphere_radius"] if mesh["on_a_sphere"] else 1.0
+    if mesh["on_a_sphere"]:
+        lon, lat = rotated_lonlat(mesh["xCell"][:nC], mesh["yCell"][:nC], mesh["zCell"][:nC], R, rotate)
+        X = (lon + np.pi) / (2.0 * np.pi)
+        Y = (lat + 0.5 * np.pi) / np.pi
+    else:
+        Lx = mesh["xCell"][:nC].max() - mesh["xCell"][:nC].min() + 1e-30
+        Ly = mesh["yCell"][:nC].max() - mesh["yCell"][:nC].min() + 1e-30
+        X = (mesh["xCell"][:nC] - mesh["xCell"][:nC].min()) / Lx
+        Y = (mesh["yCell"][:nC] - mesh["yCell"][:nC].min()) / Ly
+        lon = (X * 2.0 - 1.0) * np.pi
+        lat = (Y - 0.5) * np.pi
+    area = 0.95 - 0.15 * np.cos(lat) ** 2
+    thick = 2.0 + 0.5 * np.sin(3.0 * lon)
+    if open_water_band is not None:
+        lo, hi = open_water_band
+        area = np.where((lat > lo) & (lat < hi), 0.0, area)
+    frac = CATEGORY_AREA_FRACTION if nCat == 5 else np.full(nCat, 1.0 / nCat)
+    hfac = CATEGORY_THICKNESS_FACTOR if nCat == 5 else np.linspace(0.5, 1.5, nCat)
+    tr = block.structs["tracers"]
+    for k in range(nCat):
+        tr["iceAreaCategory"][0, k, :nC] = area * frac[k]
+        tr["iceVolumeCategory"][0, k, :nC] = area * frac[k] * thick * hfac[k]
+        tr["snowVolumeCategory"][0, k, :nC] = area * frac[k] * 0.2
+    a, b, theta = 5.0, 3.0, 4.0 * 24.0 * 3600.0
+    amp = np.sin((2.0 * np.pi * time) / theta) - b
+    at = block.structs["atmos_coupling"]
+    at["uAirVelocity"][:nC] = a + amp * np.sin(2.0 * np.pi * X) * np.sin(np.pi * Y)
+    at["vAirVelocity"][:nC] = a + amp * np.sin(2.0 * np.pi * Y) * np.sin(np.pi * X)
+    at["airDensity"][:nC] = 1.3
+    oc = block.structs["ocean_coupling"]
+    oc["uOceanVelocity"][:nC] = 0.1 * (2.0 * Y - 1.0)
+    oc["vOceanVelocity"][:nC] = -0.1 * np.sin(lon) * np.cos(lat)
+    oc["seaSurfaceTiltU"][:] = 0.0
+    oc["seaSurfaceTiltV"][:] = 0.0
+    oc["landIceMask"][:] = 0
+    oc["landIceMaskVertex"][:] = 0
+    vs = block.structs["velocity_solver"]
+    for k in ("uVelocity", "vVelocity"):
+        vs[k][:] = 0.0
+    vs["solveVelocityPrevious"][:] = 0
+
+
+def make_domain(mesh_or_meshes, name=None, configs=None, nCategories=5, time=0.0, open_water_band=None):
+    cfg = {}
+    if name in DT_BY_MESH:
+        cfg["config_dt"] = DT_BY_MESH[name]
+    if configs:
+        cfg.update(configs)
+    dom = Domain(mesh_or_meshes, cfg, nCategories=nCategories)
+    for blk in dom.blocklist:
+        fill_idealised_state(blk, time=time, open_water_band=open_water_band,
+                             rotate=dom.configs["config_rotate_cartesian_grid"])
+    return dom

@@ -1,0 +1,530 @@
+// One-time initialisation of the variational EVP operators on the device:
+// metric terms, cellVerticesAtVertex, local tangent-plane coordinates, Wachspress basis
+// gradients and integrals, variational denominator, interior vertices.
+//
+// Each kernel evaluates the same expressions, in the same order, as the reference routine named
+// above it; the file is compiled with -ffp-contract=off so every operation rounds once.
+#include <cmath>
+#include <cstring>
+
+#include "sih_internal.h"
+
+SihField *sih_find_field(sih_ctx *c, const char *name);
+
+// Dunavant (1985) degree-8 rule, 16 points, as carried (14 digits) by
+// src/shared/mpas_seaice_velocity_solver_wachspress.F:1573-1597; normalisation factor 2 (:1426)
+__constant__ double c_dunU[16] = {0.33333333333333, 0.45929258829272, 0.45929258829272, 0.08141482341455,
+                                  0.17056930775176, 0.17056930775176, 0.65886138449648, 0.05054722831703,
+                                  0.05054722831703, 0.89890554336594, 0.26311282963464, 0.72849239295540,
+                                  0.00839477740996, 0.72849239295540, 0.26311282963464, 0.00839477740996};
+__constant__ double c_dunV[16] = {0.33333333333333, 0.45929258829272, 0.08141482341455, 0.45929258829272,
+                                  0.17056930775176, 0.65886138449648, 0.17056930775176, 0.05054722831703,
+                                  0.89890554336594, 0.05054722831703, 0.72849239295540, 0.00839477740996,
+                                  0.26311282963464, 0.26311282963464, 0.00839477740996, 0.72849239295540};
+__constant__ double c_dunW[16] = {0.14431560767779, 0.09509163426728, 0.09509163426728, 0.09509163426728,
+                                  0.10321737053472, 0.10321737053472, 0.10321737053472, 0.03245849762320,
+                                  0.03245849762320, 0.03245849762320, 0.02723031417443, 0.02723031417443,
+                                  0.02723031417443, 0.02723031417443, 0.02723031417443, 0.02723031417443};
+
+struct InitArgs {
+    int nCells, nVertices, nVerticesSolve, M, padC, padV, rotate, onASphere, includeMetric, alternateDenominator;
+    double R;
+    const int *nEdgesOnCell, *voc, *cov;
+    const double *xCell, *yCell, *zCell, *xVertex, *yVertex, *zVertex, *areaTriangle;
+    int *cvav, *gidx, *interiorVertex;
+    double *tanLat, *varDenom;
+    double *gradU, *gradV, *SU, *SV, *SM, *gradU3, *gradV3;
+    int *flag;
+};
+
+// mesh.F:2350-2381
+__device__ inline void rotateForward(double &xp, double &yp, double &zp, double x, double y, double z, int rotate)
+{
+    if (rotate) {
+        xp = -z;
+        yp = y;
+        zp = x;
+    } else {
+        xp = x;
+        yp = y;
+        zp = z;
+    }
+}
+
+// variational_shared.F:293-358; interior_vertices mesh.F:423-488; seaice_cell_vertices_at_vertex mesh.F:632-685
+__global__ void k_init_vertices(InitArgs a)
+{
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= a.nVertices) return;
+    if (a.includeMetric) {
+        double xr, yr, zr;
+        rotateForward(xr, yr, zr, a.xVertex[v], a.yVertex[v], a.zVertex[v], a.rotate);
+        double lat = asin(zr / a.R);
+        a.tanLat[v] = tan(lat) / a.R;
+    } else {
+        a.tanLat[v] = 0.0;
+    }
+    int nInterior = 0;
+    for (int k = 0; k < 3; k++) {
+        int c = a.cov[k * a.padV + v];
+        int j = -1;
+        if (c < a.nCells) {
+            nInterior++;
+            int E = a.nEdgesOnCell[c];
+            for (int s = 0; s < E; s++)
+                if (a.voc[s * a.padC + c] == v) j = s;
+        }
+        a.cvav[k * a.padV + v] = j + 1;  // kept 1-based like the reference's field (0 = not found)
+        // where the divergence partial sum of this (cell, corner) lives; the zero slot otherwise
+        a.gidx[k * a.padV + v] = (j >= 0) ? j * a.padC + c : a.nCells;
+    }
+    if (v < a.nVerticesSolve) a.interiorVertex[v] = (nInterior == 3) ? 1 : 0;
+}
+
+// ---- Wachspress basis on one polygon (wachspress.F:535-1069) --------------------------------
+struct WachCell {
+    int n;
+    double x[SIH_MAXE], y[SIH_MAXE], A[SIH_MAXE], B[SIH_MAXE], kappa[SIH_MAXE];
+};
+
+__device__ inline int wrapIdx(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
+
+// variational_shared.F:191-279 with mesh.F:2021-2061, 2272-2332 (sphere) or :125-177 (plane);
+// then calc_wachspress_coefficients wachspress.F:535-614
+__device__ void wachSetup(WachCell &w, const InitArgs &a, int c)
+{
+    int n = a.nEdgesOnCell[c];
+    w.n = n;
+    if (a.onASphere) {
+        double xc, yc, zc;
+        rotateForward(xc, yc, zc, a.xCell[c], a.yCell[c], a.zCell[c], a.rotate);
+        double e0 = -yc, e1 = xc, e2 = 0.0;
+        double mag = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
+        e0 = e0 / mag;
+        e1 = e1 / mag;
+        e2 = e2 / mag;
+        double n0, n1, n2;
+        if (zc != 0.0) {
+            n0 = -xc;
+            n1 = -yc;
+            n2 = (xc * xc + yc * yc) / zc;
+            mag = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+            n0 = n0 / mag;
+            n1 = n1 / mag;
+            n2 = n2 / mag;
+            if (zc < 0.0) {
+                n0 = -n0;
+                n1 = -n1;
+                n2 = -n2;
+            }
+        } else {
+            n0 = 0.0;
+            n1 = 0.0;
+            n2 = 1.0;
+        }
+        for (int i = 0; i < n; i++) {
+            int v = a.voc[i * a.padC + c];
+            double px, py, pz;
+            rotateForward(px, py, pz, a.xVertex[v], a.yVertex[v], a.zVertex[v], a.rotate);
+            w.x[i] = px * e0 + py * e1 + pz * e2;
+            w.y[i] = px * n0 + py * n1 + pz * n2;
+        }
+    } else {
+        for (int i = 0; i < n; i++) {
+            int v = a.voc[i * a.padC + c];
+            w.x[i] = a.xVertex[v] - a.xCell[c];
+            w.y[i] = a.yVertex[v] - a.yCell[c];
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        int i1 = wrapIdx(i - 1, n), i2 = i;
+        double den = w.x[i1] * w.y[i2] - w.x[i2] * w.y[i1];
+        w.A[i] = (w.y[i2] - w.y[i1]) / den;
+        w.B[i] = (w.x[i1] - w.x[i2]) / (w.x[i1] * w.y[i2] - w.x[i2] * w.y[i1]);
+    }
+    w.kappa[0] = 1.0;
+    for (int j = 1; j < n; j++) {
+        int i0 = j - 1, i1 = j, i2 = wrapIdx(j + 1, n);
+        w.kappa[j] = w.kappa[j - 1] * (w.A[i2] * (w.x[i0] - w.x[i1]) + w.B[i2] * (w.y[i0] - w.y[i1])) /
+                     (w.A[i0] * (w.x[i1] - w.x[i0]) + w.B[i0] * (w.y[i1] - w.y[i0]));
+    }
+}
+
+__device__ inline double wachEdge(const WachCell &w, int k, double x, double y) { return 1.0 - w.A[k] * x - w.B[k] * y; }
+
+// numerator j = kappa_j * prod over edges k not in {j, j+1}, ascending k (wachspress.F:628-668, 864-925)
+__device__ double wachNumerator(const WachCell &w, int j, double x, double y)
+{
+    int skip2 = wrapIdx(j + 1, w.n);
+    double num = 1.0;
+    for (int k = 0; k < w.n; k++)
+        if (k != j && k != skip2) num = num * wachEdge(w, k, x, y);
+    return num * w.kappa[j];
+}
+
+// wachspress.F:939-1035
+__device__ void wachNumeratorDerivative(const WachCell &w, int j, double x, double y, double &dU, double &dV)
+{
+    int skip2 = wrapIdx(j + 1, w.n);
+    double sumU = 0.0, sumV = 0.0;
+    for (int k = 0; k < w.n; k++) {
+        if (k == j || k == skip2) continue;
+        double pU = 1.0, pV = 1.0;
+        for (int l = 0; l < k; l++) {
+            if (l == j || l == skip2) continue;
+            double e = wachEdge(w, l, x, y);
+            pU = pU * e;
+            pV = pV * e;
+        }
+        pU = pU * (-w.A[k]);
+        pV = pV * (-w.B[k]);
+        for (int l = k + 1; l < w.n; l++) {
+            if (l == j || l == skip2) continue;
+            double e = wachEdge(w, l, x, y);
+            pU = pU * e;
+            pV = pV * e;
+        }
+        sumU = sumU + pU;
+        sumV = sumV + pV;
+    }
+    dU = sumU * w.kappa[j];
+    dV = sumV * w.kappa[j];
+}
+
+// wachspress.F:763-850
+__device__ void wachBasisDerivative(const WachCell &w, int i, double x, double y, double &dU, double &dV)
+{
+    double den = 0.0, sU = 0.0, sV = 0.0, numi = 0.0, dUi = 0.0, dVi = 0.0;
+    for (int j = 0; j < w.n; j++) {
+        double num = wachNumerator(w, j, x, y);
+        den = den + num;
+        double du, dv;
+        wachNumeratorDerivative(w, j, x, y, du, dv);
+        sU = sU + du;
+        sV = sV + dv;
+        if (j == i) {
+            numi = num;
+            dUi = du;
+            dVi = dv;
+        }
+    }
+    dU = dUi / den - (numi / (den * den)) * sU;
+    dV = dVi / den - (numi / (den * den)) * sV;
+}
+
+// calculate_wachspress_derivatives, wachspress.F:1083-1206: one thread per (cell, basis vertex)
+__global__ void k_wach_gradients(InitArgs a)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int c = t % a.nCells, ib = t / a.nCells;
+    if (ib >= a.M) return;
+    const int M = a.M;
+    for (int g = 0; g < M; g++) {  // host index (iBasis, iGradient) -> lead g*M + ib
+        a.gradU[(size_t)(g * M + ib) * a.padC + c] = 0.0;
+        a.gradV[(size_t)(g * M + ib) * a.padC + c] = 0.0;
+    }
+    WachCell w;
+    wachSetup(w, a, c);
+    if (ib >= w.n) return;
+    int gs[3] = {ib, wrapIdx(ib - 1, w.n), wrapIdx(ib + 1, w.n)};
+    for (int q = 0; q < 3; q++) {
+        int g = gs[q];
+        double du, dv;
+        wachBasisDerivative(w, ib, w.x[g], w.y[g], du, dv);
+        a.gradU[(size_t)(g * M + ib) * a.padC + c] = du;
+        a.gradV[(size_t)(g * M + ib) * a.padC + c] = dv;
+    }
+}
+
+// integrate_wachspress / integrate_wachspress_polygon, wachspress.F:179-467:
+// one thread per (cell, velocity vertex j); accumulates the column (:, j) of the three integrals
+__global__ void k_wach_integrals(InitArgs a)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int c = t % a.nCells, j = t / a.nCells;
+    if (j >= a.M) return;
+    const int M = a.M;
+    double SU[SIH_MAXE], SV[SIH_MAXE], SM[SIH_MAXE];
+    for (int s = 0; s < SIH_MAXE; s++) SU[s] = SV[s] = SM[s] = 0.0;
+    WachCell w;
+    wachSetup(w, a, c);
+    if (j < w.n) {
+        for (int tri = 0; tri < w.n; tri++) {
+            int i1 = tri, i2 = wrapIdx(tri + 1, w.n);
+            // get_triangle_mapping (:485-517) from the unit triangle (1,0),(0,1)
+            double x1 = 1.0, y1 = 0.0, x2 = 0.0, y2 = 1.0;
+            double u1 = w.x[i1], v1 = w.y[i1], u2 = w.x[i2], v2 = w.y[i2];
+            double m11 = (u2 * y1 - u1 * y2) / (x2 * y1 - x1 * y2);
+            double m12 = (u1 * x2 - u2 * x1) / (y1 * x2 - y2 * x1);
+            double m21 = (v2 * y1 - v1 * y2) / (x2 * y1 - x1 * y2);
+            double m22 = (v1 * x2 - v2 * x1) / (y1 * x2 - y2 * x1);
+            double jac = m11 * m22 - m12 * m21;
+            double sU[SIH_MAXE], sV[SIH_MAXE], sM[SIH_MAXE];
+            for (int s = 0; s < SIH_MAXE; s++) sU[s] = sV[s] = sM[s] = 0.0;
+            for (int p = 0; p < 16; p++) {
+                double px = m11 * c_dunU[p] + m12 * c_dunV[p];
+                double py = m21 * c_dunU[p] + m22 * c_dunV[p];
+                double num[SIH_MAXE], den = 0.0;
+                for (int s = 0; s < w.n; s++) {
+                    num[s] = wachNumerator(w, s, px, py);
+                    den = den + num[s];
+                }
+                double dNu, dNv;
+                wachBasisDerivative(w, j, px, py, dNu, dNv);
+                double Nj = num[j] / den;
+                for (int s = 0; s < w.n; s++) {
+                    double tmp = jac * c_dunW[p] * (num[s] / den);
+                    sU[s] = sU[s] + tmp * dNu;
+                    sV[s] = sV[s] + tmp * dNv;
+                    sM[s] = sM[s] + tmp * Nj;
+                }
+            }
+            for (int s = 0; s < w.n; s++) {
+                SU[s] = SU[s] + sU[s] / 2.0;
+                SV[s] = SV[s] + sV[s] / 2.0;
+                SM[s] = SM[s] + sM[s] / 2.0;
+            }
+        }
+    }
+    for (int s = 0; s < M; s++) {  // host index (iStress s, iVelocity j) -> lead j*M + s
+        size_t k = (size_t)(j * M + s) * a.padC + c;
+        a.SU[k] = (s < SIH_MAXE) ? SU[s] : 0.0;
+        a.SV[k] = (s < SIH_MAXE) ? SV[s] : 0.0;
+        a.SM[k] = (s < SIH_MAXE) ? SM[s] : 0.0;
+    }
+}
+
+// Compact form of the basis gradients.  The Wachspress gradient matrix (iBasis, iGradient) is
+// non-zero only for iBasis in {iGradient-1, iGradient, iGradient+1} (cyclic; wachspress.F:1178-1191),
+// so corner g needs three coefficients.  They are stored in ascending-iBasis order, the order in
+// which the reference's dense loop meets them, so that the strain sums round identically.
+// flag[0] is raised if any other entry is non-zero (then the dense kernel must be used).
+__global__ void k_pack_gradients(InitArgs a)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.nCells) return;
+    const int M = a.M;
+    int E = a.nEdgesOnCell[c];
+    bool dense = false;
+    for (int g = 0; g < M; g++) {
+        int b3[3];
+        if (g < E) {
+            int p = wrapIdx(g - 1, E), n = wrapIdx(g + 1, E);
+            if (g == 0) {
+                b3[0] = 0;
+                b3[1] = n;
+                b3[2] = p;
+            } else if (g == E - 1) {
+                b3[0] = n;
+                b3[1] = p;
+                b3[2] = g;
+            } else {
+                b3[0] = p;
+                b3[1] = g;
+                b3[2] = n;
+            }
+        }
+        for (int q = 0; q < 3; q++) {
+            double gu = 0.0, gv = 0.0;
+            if (g < E) {
+                gu = a.gradU[(size_t)(g * M + b3[q]) * a.padC + c];
+                gv = a.gradV[(size_t)(g * M + b3[q]) * a.padC + c];
+            }
+            a.gradU3[(size_t)(q * M + g) * a.padC + c] = gu;
+            a.gradV3[(size_t)(q * M + g) * a.padC + c] = gv;
+        }
+        if (g < E) {
+            for (int b = 0; b < E; b++) {
+                if (b == b3[0] || b == b3[1] || b == b3[2]) continue;
+                if (a.gradU[(size_t)(g * M + b) * a.padC + c] != 0.0 || a.gradV[(size_t)(g * M + b) * a.padC + c] != 0.0)
+                    dense = true;
+            }
+        }
+    }
+    if (dense) atomicOr(a.flag, 1);
+}
+
+// variational_denominator, variational.F:358-445
+__global__ void k_var_denominator(InitArgs a)
+{
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= a.nVertices) return;
+    if (a.alternateDenominator) {
+        double d = 0.0;
+        for (int k = 0; k < 3; k++) {
+            int c = a.cov[k * a.padV + v];
+            int j = a.cvav[k * a.padV + v] - 1;
+            if (c >= a.nCells || j < 0) continue;
+            int E = a.nEdgesOnCell[c];
+            for (int s = 0; s < E; s++) d = d + a.SM[(size_t)(j * a.M + s) * a.padC + c];
+        }
+        a.varDenom[v] = d;
+    } else {
+        a.varDenom[v] = a.areaTriangle[v];
+    }
+}
+
+__global__ void k_zero_int(int *p, int n)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) p[t] = 0;
+}
+
+void sih_bind_dev(sih_ctx *c);
+
+static InitArgs makeInitArgs(sih_ctx *c)
+{
+    auto fi = [&](const char *n) { return (int *)sih_find_field(c, n)->d; };
+    auto fd = [&](const char *n) { return (double *)sih_find_field(c, n)->d; };
+    InitArgs a{};
+    a.nCells = c->nCells;
+    a.nVertices = c->nVertices;
+    a.nVerticesSolve = c->nVerticesSolve;
+    a.M = c->M;
+    a.padC = c->padC;
+    a.padV = c->padV;
+    a.rotate = c->cfg.rotateCartesianGrid;
+    a.onASphere = c->onASphere;
+    a.includeMetric = (c->cfg.includeMetricTerms && c->onASphere) ? 1 : 0;
+    a.alternateDenominator = c->cfg.variationalDenominator == 1;
+    a.R = c->R;
+    a.nEdgesOnCell = fi("_nEdgesOnCell");
+    a.voc = fi("_voc");
+    a.cov = fi("_cov");
+    a.xCell = fd("xCell");
+    a.yCell = fd("yCell");
+    a.zCell = fd("zCell");
+    a.xVertex = fd("xVertex");
+    a.yVertex = fd("yVertex");
+    a.zVertex = fd("zVertex");
+    a.areaTriangle = fd("areaTriangle");
+    a.cvav = fi("cellVerticesAtVertex");
+    a.gidx = fi("_gidx");
+    a.interiorVertex = fi("interiorVertex");
+    a.tanLat = fd("tanLatVertexRotatedOverRadius");
+    a.varDenom = fd("variationalDenominator");
+    a.gradU = fd("basisGradientU");
+    a.gradV = fd("basisGradientV");
+    a.SU = fd("basisIntegralsU");
+    a.SV = fd("basisIntegralsV");
+    a.SM = fd("basisIntegralsMetric");
+    a.gradU3 = fd("_gradU3");
+    a.gradV3 = fd("_gradV3");
+    a.flag = c->d_flag;
+    return a;
+}
+
+static int packStatic(sih_ctx *c, const InitArgs &a)
+{
+    hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(64), 0, c->stream, c->d_flag, 16);
+    hipLaunchKernelGGL(k_pack_gradients, dim3((c->nCells + 255) / 256), dim3(256), 0, c->stream, a);
+    HIPCHK(hipGetLastError());
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->sparseGrad = (flag == 0);
+    return SIH_OK;
+}
+
+extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
+{
+    if (!c || !cfg) {
+        sih_set_error("sih_evp_init: null argument");
+        return SIH_ERR_ARG;
+    }
+    if (cfg->constitutiveRelation < 1 || cfg->constitutiveRelation > 3) {
+        sih_set_error("config_constitutive_relation_type unknown");
+        return SIH_ERR_ARG;
+    }
+    if (cfg->oceanStressType < 1 || cfg->oceanStressType > 2) {
+        sih_set_error("config_ocean_stress_type unknown");
+        return SIH_ERR_ARG;
+    }
+    if (cfg->variationalBasis != 0 && cfg->variationalBasis != 1) {
+        sih_set_error("Unknown variational basis type (the library computes 'wachspress'; pass 0 and upload others)");
+        return SIH_ERR_UNSUPPORTED;
+    }
+    if (cfg->variationalBasis == 1 && cfg->wachspressIntegrationOrder != 8) {
+        sih_set_error("only the dunavant order-8 rule (the reference default) is implemented on the device");
+        return SIH_ERR_UNSUPPORTED;
+    }
+    if (cfg->variationalDenominator < 0 || cfg->variationalDenominator > 1) {
+        sih_set_error("Unknown variational denominator type");
+        return SIH_ERR_ARG;
+    }
+    if (cfg->dynamicsSubcycleNumber < 1 || cfg->elasticSubcycleNumber < 1 || !(cfg->dt > 0.0) || cfg->nCategories < 1) {
+        sih_set_error("sih_evp_init: dt, subcycle numbers and nCategories must be positive");
+        return SIH_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    c->cfg = *cfg;
+    // category tracers are sized by nCategories, known only now
+    if (!sih_find_field(c, "iceAreaCategory")) {
+        const char *cats[3] = {"iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory"};
+        for (const char *n : cats) {
+            SihField f;
+            f.name = n;
+            f.loc = LOC_CELL;
+            f.lead = cfg->nCategories;
+            f.isInt = false;
+            size_t bytes = (size_t)f.lead * c->padC * 8;
+            HIPCHK(hipMalloc(&f.d, bytes));
+            HIPCHK(hipMemsetAsync(f.d, 0, bytes, c->stream));
+            c->allocs.push_back(f.d);
+            c->fields[n] = f;
+        }
+    } else if (sih_find_field(c, "iceAreaCategory")->lead != cfg->nCategories) {
+        sih_set_error("sih_evp_init: nCategories cannot change after the first initialisation");
+        return SIH_ERR_STATE;
+    }
+    InitArgs a = makeInitArgs(c);
+    dim3 block(256);
+    hipLaunchKernelGGL(k_init_vertices, dim3((c->nVertices + 255) / 256), block, 0, c->stream, a);
+    if (cfg->variationalBasis == 1) {
+        long tot = (long)c->nCells * c->M;
+        hipLaunchKernelGGL(k_wach_gradients, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, c->stream, a);
+        hipLaunchKernelGGL(k_wach_integrals, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, c->stream, a);
+    }
+    hipLaunchKernelGGL(k_var_denominator, dim3((c->nVertices + 255) / 256), block, 0, c->stream, a);
+    HIPCHK(hipGetLastError());
+    int rc = packStatic(c, a);
+    if (rc) return rc;
+    // time steps and EVP constants: velocity_solver.F:155-157, constitutive_relation.F:125, 158-159
+    double dtDyn = cfg->dt / (double)cfg->dynamicsSubcycleNumber;
+    double dtE = dtDyn / (double)cfg->elasticSubcycleNumber;
+    double dv = cfg->minEdgeLengthGlobal > 0.0 ? cfg->minEdgeLengthGlobal : c->minDvEdge;
+    double gamma = 0.25 * 1.0e11 * dtDyn;
+    c->inited = true;
+    sih_bind_dev(c);
+    c->dev.dtDyn = dtDyn;
+    c->dev.dtE = dtE;
+    c->dev.dampT = 0.36 * dtDyn;
+    c->dev.brlx = dv > 0.0 ? (2.0 * 0.86 * 5.5e-3 * gamma) / (dv * dv) : 0.0;
+    if (cfg->constitutiveRelation == 2 && !(dv > 0.0)) {
+        sih_set_error("evp_revised needs dvEdge (minEdgeLengthGlobal)");
+        return SIH_ERR_ARG;
+    }
+    if (c->graphExec) {
+        hipGraphExecDestroy(c->graphExec);
+        c->graphExec = nullptr;
+        c->graphN = 0;
+    }
+    return SIH_OK;
+}
+
+extern "C" int sih_evp_static_changed(sih_ctx *c)
+{
+    if (!c || !c->inited) {
+        sih_set_error("sih_evp_static_changed: context not initialised");
+        return SIH_ERR_STATE;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    InitArgs a = makeInitArgs(c);
+    int rc = packStatic(c, a);
+    if (c->graphExec) {
+        hipGraphExecDestroy(c->graphExec);
+        c->graphExec = nullptr;
+        c->graphN = 0;
+    }
+    return rc;
+}

@@ -1,0 +1,904 @@
+// Time-step kernels of the EVP velocity solver: pre-subcycle, the subcycle pair (fused cell kernel +
+// fused vertex kernel) and post-subcycle.
+//
+// Device data are structure-of-arrays: corner quantity (s, cell) at [s * padC + cell], so one thread
+// per cell (or vertex) gives fully coalesced 8-byte-per-lane streams for every array; the only
+// gathers are the vertex values a cell reads through verticesOnCell and the per-corner partial sums
+// a vertex reads through its three (cell, corner) pairs.
+//
+// Arithmetic follows the cited reference statements in the same order; the file is compiled with
+// -ffp-contract=off (the kernels are bandwidth-bound, fused multiply-add buys nothing here).
+#include <cmath>
+
+#include "sih_internal.h"
+
+SihField *sih_find_field(sih_ctx *c, const char *name);
+
+// velocity_solver.F:61-65; constitutive_relation.F:41-47; column/constants/cice/ice_constants_colpkg.F90
+#define SIN_TURN 0.0
+#define COS_TURN 1.0
+#define AREA_MIN 0.001
+#define MASS_MIN 0.01
+#define ECC2 4.0
+#define PUNY 1.0e-11
+#define RHOI 917.0
+#define RHOS 330.0
+#define RHOW 1026.0
+#define DRAGIO 0.00536
+#define PSTAR 2.75e4
+#define CSTAR 20.0
+#define GRAVIT 9.80616
+
+void sih_bind_dev(sih_ctx *c)
+{
+    auto fi = [&](const char *n) { return (int *)sih_find_field(c, n)->d; };
+    auto fd = [&](const char *n) { return (double *)sih_find_field(c, n)->d; };
+    SihDev &d = c->dev;
+    d.nCells = c->nCells;
+    d.nCellsSolve = c->nCellsSolve;
+    d.nVertices = c->nVertices;
+    d.nVerticesSolve = c->nVerticesSolve;
+    d.M = c->M;
+    d.D = c->D;
+    d.nCat = c->cfg.nCategories;
+    d.padC = c->padC;
+    d.padV = c->padV;
+    d.nEdgesOnCell = fi("_nEdgesOnCell");
+    d.voc = fi("_voc");
+    d.coc = fi("_coc");
+    d.cov = fi("_cov");
+    d.cvav = fi("cellVerticesAtVertex");
+    d.gidx = fi("_gidx");
+    d.interiorVertex = fi("interiorVertex");
+    d.landIceMask = fi("landIceMask");
+    d.landIceMaskVertex = fi("landIceMaskVertex");
+    d.solveStress = fi("solveStress");
+    d.solveVelocity = fi("solveVelocity");
+    d.solveVelocityPrevious = fi("solveVelocityPrevious");
+    d.areaCell = fd("areaCell");
+    d.areaTriangle = fd("areaTriangle");
+    d.fVertex = fd("fVertex");
+    d.tanLat = fd("tanLatVertexRotatedOverRadius");
+    d.varDenom = fd("variationalDenominator");
+    d.gradU = fd("basisGradientU");
+    d.gradV = fd("basisGradientV");
+    d.gradU3 = fd("_gradU3");
+    d.gradV3 = fd("_gradV3");
+    d.SU = fd("basisIntegralsU");
+    d.SV = fd("basisIntegralsV");
+    d.SM = fd("basisIntegralsMetric");
+    d.u = fd("uVelocity");
+    d.v = fd("vVelocity");
+    d.uInit = fd("uVelocityInitial");
+    d.vInit = fd("vVelocityInitial");
+    d.strain11 = fd("strain11");
+    d.strain22 = fd("strain22");
+    d.strain12 = fd("strain12");
+    d.stress11 = fd("stress11");
+    d.stress22 = fd("stress22");
+    d.stress12 = fd("stress12");
+    d.Prep = fd("replacementPressure");
+    d.prin1 = fd("principalStress1");
+    d.prin2 = fd("principalStress2");
+    d.partU = fd("_partU");
+    d.partV = fd("_partV");
+    d.divU = fd("stressDivergenceU");
+    d.divV = fd("stressDivergenceV");
+    d.icePressure = fd("icePressure");
+    d.airCellU = fd("airStressCellU");
+    d.airCellV = fd("airStressCellV");
+    d.airVertU = fd("airStressVertexU");
+    d.airVertV = fd("airStressVertexV");
+    d.uOcnVert = fd("uOceanVelocityVertex");
+    d.vOcnVert = fd("vOceanVelocityVertex");
+    d.ocnStressU = fd("oceanStressU");
+    d.ocnStressV = fd("oceanStressV");
+    d.ocnCoeff = fd("oceanStressCoeff");
+    d.ocnStressCellU = fd("oceanStressCellU");
+    d.ocnStressCellV = fd("oceanStressCellV");
+    d.tiltVertU = fd("seaSurfaceTiltVertexU");
+    d.tiltVertV = fd("seaSurfaceTiltVertexV");
+    d.tiltForceU = fd("surfaceTiltForceU");
+    d.tiltForceV = fd("surfaceTiltForceV");
+    d.massF = fd("totalMassVertexfVertex");
+    d.divergence = fd("divergence");
+    d.shear = fd("shear");
+    d.ridgeConv = fd("ridgeConvergence");
+    d.ridgeShear = fd("ridgeShear");
+    d.iceAreaVertex = fd("iceAreaVertex");
+    d.totalMassVertex = fd("totalMassVertex");
+    d.iceAreaCellInitial = fd("iceAreaCellInitial");
+    d.totalMassCell = fd("totalMassCell");
+    d.iceAreaCell = fd("iceAreaCell");
+    d.iceVolumeCell = fd("iceVolumeCell");
+    d.snowVolumeCell = fd("snowVolumeCell");
+    d.iceAreaCat = fd("iceAreaCategory");
+    d.iceVolCat = fd("iceVolumeCategory");
+    d.snowVolCat = fd("snowVolumeCategory");
+    d.uOcn = fd("uOceanVelocity");
+    d.vOcn = fd("vOceanVelocity");
+    d.tiltU = fd("seaSurfaceTiltU");
+    d.tiltV = fd("seaSurfaceTiltV");
+    d.uAir = fd("uAirVelocity");
+    d.vAir = fd("vAirVelocity");
+    d.airDensity = fd("airDensity");
+    d.relation = c->cfg.constitutiveRelation;
+    d.useOcean = c->cfg.useOceanStress;
+    d.quadratic = c->cfg.oceanStressType == 1;
+    d.useAir = c->cfg.useAirStress;
+    d.tiltMode = c->cfg.surfaceTilt;
+    d.useColumn = c->cfg.useColumnPackage;
+}
+
+__device__ inline double sign1(double x) { return copysign(1.0, x); }
+
+// =========================================================================== pre-subcycle kernels
+
+// stage 0: aggregate_mass_and_area, velocity_solver.F:685-752 (loops to nCells, halo included) and
+// iceAreaCellInitial = iceAreaCell (:819)
+__global__ void k_pre0_cells(SihDev d)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nCells) return;
+    double a = 0.0, vi = 0.0, vs = 0.0;
+    for (int k = 0; k < d.nCat; k++) {
+        a = a + d.iceAreaCat[(size_t)k * d.padC + c];
+        vi = vi + d.iceVolCat[(size_t)k * d.padC + c];
+        vs = vs + d.snowVolCat[(size_t)k * d.padC + c];
+    }
+    d.iceAreaCell[c] = a;
+    d.iceVolumeCell[c] = vi;
+    d.snowVolumeCell[c] = vs;
+    d.totalMassCell[c] = vi * RHOI + vs * RHOS;
+    d.iceAreaCellInitial[c] = a;
+}
+
+// seaice_interpolate_cell_to_vertex, mesh.F:2835-2851 (the sentinel slot holds area 0, value 0)
+__device__ inline double interpC2V(const SihDev &d, int v, const double *cellVar)
+{
+    double acc = 0.0, tot = 0.0;
+    for (int k = 0; k < 3; k++) {
+        int c = d.cov[k * d.padV + v];
+        acc = acc + d.areaCell[c] * cellVar[c];
+        tot = tot + d.areaCell[c];
+    }
+    return acc / tot;
+}
+
+// stage 1a: area/mass to vertices (:883-891) and velocity_calculation_mask (:1073-1150)
+__global__ void k_pre1_vertices(SihDev d, int calcMasks)
+{
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= d.nVertices) return;
+    if (v < d.nVerticesSolve) {
+        double av = interpC2V(d, v, d.iceAreaCellInitial);
+        double mv = interpC2V(d, v, d.totalMassCell);
+        d.iceAreaVertex[v] = av;
+        d.totalMassVertex[v] = mv;
+        if (calcMasks) {
+            int s = 0;
+            if (d.interiorVertex[v] == 1 && d.landIceMaskVertex[v] == 0 && av > AREA_MIN && mv > MASS_MIN) s = 1;
+            d.solveVelocity[v] = s;
+        }
+    } else if (calcMasks) {
+        d.solveVelocity[v] = 0;
+    }
+}
+
+// stage 1b: stress_calculation_mask, velocity_solver.F:961-1059
+__global__ void k_pre1_cells(SihDev d)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nCells) return;
+    int s = 0;
+    if (d.iceAreaCellInitial[c] > AREA_MIN && d.totalMassCell[c] > MASS_MIN && d.landIceMask[c] == 0) {
+        s = 1;
+    } else {
+        int E = d.nEdgesOnCell[c];
+        for (int i = 0; i < E; i++) {
+            int nb = d.coc[i * d.padC + c];
+            if (d.iceAreaCellInitial[nb] > AREA_MIN && d.totalMassCell[nb] > MASS_MIN && d.landIceMask[nb] == 0) {
+                s = 1;
+                break;
+            }
+        }
+    }
+    d.solveStress[c] = s;
+}
+
+// stage 2: new_ice_velocities, velocity_solver.F:1238-1277
+__global__ void k_pre2_vertices(SihDev d)
+{
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= d.nVertices) return;
+    if (v < d.nVerticesSolve) {
+        double uo = interpC2V(d, v, d.uOcn);
+        double vo = interpC2V(d, v, d.vOcn);
+        d.uOcnVert[v] = uo;
+        d.vOcnVert[v] = vo;
+        if (d.solveVelocity[v] == 1) {
+            if (d.solveVelocityPrevious[v] == 0) {
+                d.u[v] = uo;
+                d.v[v] = vo;
+            }
+        } else {
+            d.u[v] = 0.0;
+            d.v[v] = 0.0;
+            d.divU[v] = 0.0;
+            d.divV[v] = 0.0;
+            d.ocnStressU[v] = 0.0;
+            d.ocnStressV[v] = 0.0;
+        }
+    }
+    d.solveVelocityPrevious[v] = d.solveVelocity[v];
+    d.uInit[v] = d.u[v];
+    d.vInit[v] = d.v[v];
+}
+
+// stage 3: ice_strength (Hibler branch :1419-1435) and constant_air_stress (:1665-1728)
+__global__ void k_pre3_cells(SihDev d)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nCellsSolve) return;
+    if (d.solveStress[c] == 1)
+        d.icePressure[c] = PSTAR * d.iceVolumeCell[c] * exp(-CSTAR * (1.0 - d.iceAreaCell[c]));
+    else
+        d.icePressure[c] = 0.0;
+    if (d.useAir) {
+        double ua = d.uAir[c], va = d.vAir[c];
+        double windSpeed = sqrt(ua * ua + va * va);
+        d.airCellU[c] = d.airDensity[c] * windSpeed * 0.0012 * ua * d.iceAreaCell[c];
+        d.airCellV[c] = d.airDensity[c] * windSpeed * 0.0012 * va * d.iceAreaCell[c];
+    } else {
+        d.airCellU[c] = 0.0;
+        d.airCellV[c] = 0.0;
+    }
+}
+
+// stage 4 (vertices): air stress to vertices (:1638-1646), coriolis_force_coefficient (:1742-1788),
+// ocean_stress (:1802-1883), surface_tilt (:1897-2213), vertex part of init_subcycle_variables (:2287-2310)
+__global__ void k_pre4_vertices(SihDev d)
+{
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= d.nVertices) return;
+    d.divU[v] = 0.0;
+    d.divV[v] = 0.0;
+    if (v >= d.nVerticesSolve) {
+        if (!d.useOcean) {
+            d.ocnStressU[v] = 0.0;
+            d.ocnStressV[v] = 0.0;
+        }
+        if (d.tiltMode == 0) {
+            d.tiltForceU[v] = 0.0;
+            d.tiltForceV[v] = 0.0;
+        }
+        return;
+    }
+    d.airVertU[v] = interpC2V(d, v, d.airCellU);
+    d.airVertV[v] = interpC2V(d, v, d.airCellV);
+    double m = d.totalMassVertex[v], f = d.fVertex[v];
+    d.massF[v] = m * f;
+    int solve = d.solveVelocity[v] == 1;
+    double uo = d.uOcnVert[v], vo = d.vOcnVert[v];
+    if (d.useOcean && solve) {
+        d.ocnStressU[v] = uo * COS_TURN - vo * SIN_TURN * sign1(f);
+        d.ocnStressV[v] = uo * SIN_TURN * sign1(f) + vo * COS_TURN;
+    } else {
+        d.ocnStressU[v] = 0.0;
+        d.ocnStressV[v] = 0.0;
+    }
+    if (d.tiltMode == 2) {
+        d.tiltVertU[v] = interpC2V(d, v, d.tiltU);
+        d.tiltVertV[v] = interpC2V(d, v, d.tiltV);
+    }
+    if (d.tiltMode != 0 && solve) {
+        if (d.tiltMode == 1) {
+            d.tiltForceU[v] = -f * m * vo;
+            d.tiltForceV[v] = f * m * uo;
+        } else {
+            d.tiltForceU[v] = -GRAVIT * m * d.tiltVertU[v];
+            d.tiltForceV[v] = -GRAVIT * m * d.tiltVertV[v];
+        }
+    } else {
+        d.tiltForceU[v] = 0.0;
+        d.tiltForceV[v] = 0.0;
+    }
+    if (!solve) {
+        d.u[v] = 0.0;
+        d.v[v] = 0.0;
+        d.ocnCoeff[v] = 0.0;
+    }
+}
+
+// stage 4 (cells): cell part of init_subcycle_variables (:2322-2345); also clears the per-corner
+// divergence partial sums, which unsolved cells never write (their stresses are zero all step long)
+__global__ void k_pre4_cells(SihDev d)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nCells) return;
+    bool unsolved = d.solveStress[c] != 1;
+    for (int s = 0; s < d.M; s++) {
+        size_t k = (size_t)s * d.padC + c;
+        d.strain11[k] = 0.0;
+        d.strain22[k] = 0.0;
+        d.strain12[k] = 0.0;
+        d.partU[k] = 0.0;
+        d.partV[k] = 0.0;
+        if (unsolved) {
+            d.stress11[k] = 0.0;
+            d.stress22[k] = 0.0;
+            d.stress12[k] = 0.0;
+        }
+    }
+}
+
+// =========================================================================== subcycle kernels
+
+// Fused cell kernel: seaice_strain_tensor_variational (variational.F:575-670), the constitutive
+// relation (constitutive_relation.F:178-373 via variational.F:777-975) and the cell-local inner sums of
+// seaice_stress_divergence_variational (variational.F:1151-1170).  The latter are the per-(cell, corner)
+// partial sums stressDivergenceUCell / VCell; the vertex kernel adds the three of them in
+// cellsOnVertex order exactly as the reference loop does (:1172-1173), so no rounding changes.
+template <int M, bool SPARSE, bool LAST>
+__global__ void __launch_bounds__(256) k_sub_cells(SihDev d)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nCells) return;
+    const int P = d.padC;
+    if (d.solveStress[c] != 1) {
+        if (LAST && d.relation == 1) {
+#pragma unroll
+            for (int s = 0; s < M; s++) d.Prep[(size_t)s * P + c] = 0.0;
+        }
+        return;
+    }
+    const int E = d.nEdgesOnCell[c];
+    double u[M], v[M], t[M];
+#pragma unroll
+    for (int s = 0; s < M; s++) {
+        u[s] = 0.0;
+        v[s] = 0.0;
+        t[s] = 0.0;
+        if (s < E) {
+            int iv = d.voc[(size_t)s * P + c];
+            u[s] = d.u[iv];
+            v[s] = d.v[iv];
+            t[s] = d.tanLat[iv];
+        }
+    }
+    double uLast = 0.0, vLast = 0.0;
+#pragma unroll
+    for (int s = 0; s < M; s++)
+        if (s == E - 1) {
+            uLast = u[s];
+            vLast = v[s];
+        }
+    const double P_ice = d.icePressure[c];
+    const double dtE = d.dtE, T = d.dampT;
+    double s11[M], s22[M], s12[M];
+#pragma unroll
+    for (int g = 0; g < M; g++) {
+        s11[g] = 0.0;
+        s22[g] = 0.0;
+        s12[g] = 0.0;
+        if (g < E) {
+            double e11 = 0.0, e22 = 0.0, e12 = 0.0;
+            if (SPARSE) {
+                // the three non-zero basis gradients of corner g, met in ascending basis-vertex order
+                double x0u, x1u, x2u, x0v, x1v, x2v;
+                const bool isLast = (g == E - 1);
+                if (g == 0) {
+                    x0u = u[0];
+                    x0v = v[0];
+                    x1u = u[1];
+                    x1v = v[1];
+                    x2u = uLast;
+                    x2v = vLast;
+                } else {
+                    const int gn = (g + 1 < M) ? g + 1 : g;
+                    x0u = isLast ? u[0] : u[g - 1];
+                    x0v = isLast ? v[0] : v[g - 1];
+                    x1u = isLast ? u[g - 1] : u[g];
+                    x1v = isLast ? v[g - 1] : v[g];
+                    x2u = isLast ? u[g] : u[gn];
+                    x2v = isLast ? v[g] : v[gn];
+                }
+                const double xu[3] = {x0u, x1u, x2u}, xv[3] = {x0v, x1v, x2v};
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    double gu = d.gradU3[(size_t)(q * M + g) * P + c];
+                    double gv = d.gradV3[(size_t)(q * M + g) * P + c];
+                    e11 = e11 + xu[q] * gu;
+                    e22 = e22 + xv[q] * gv;
+                    e12 = e12 + 0.5 * (xu[q] * gv + xv[q] * gu);
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < M; b++) {
+                    if (b < E) {
+                        double gu = d.gradU[(size_t)(g * M + b) * P + c];
+                        double gv = d.gradV[(size_t)(g * M + b) * P + c];
+                        e11 = e11 + u[b] * gu;
+                        e22 = e22 + v[b] * gv;
+                        e12 = e12 + 0.5 * (u[b] * gv + v[b] * gu);
+                    }
+                }
+            }
+            e11 = e11 - v[g] * t[g];
+            e12 = e12 + u[g] * t[g] * 0.5;
+            const size_t k = (size_t)g * P + c;
+            if (LAST) {
+                d.strain11[k] = e11;
+                d.strain22[k] = e22;
+                d.strain12[k] = e12;
+            }
+            double a11, a22, a12;
+            if (d.relation == 3) {
+                a11 = 1.0 * e11;
+                a22 = 1.0 * e22;
+                a12 = 1.0 * e12;
+            } else {
+                a11 = d.stress11[k];
+                a22 = d.stress22[k];
+                a12 = d.stress12[k];
+                double eD = e11 + e22, eT = e11 - e22, eS = e12 * 2.0;
+                double st1 = a11 + a22, st2 = a11 - a22;
+                double Delta = sqrt(eD * eD + (eT * eT + eS * eS) / ECC2);
+                double pc = P_ice / fmax(Delta, PUNY);
+                if (LAST) d.Prep[k] = pc * Delta;
+                double den;
+                if (d.relation == 1) {
+                    pc = (pc * dtE) / (2.0 * T);
+                    den = 1.0 + (0.5 * dtE) / T;
+                } else {
+                    pc = (pc * 2.0 * 5.5e-3) / 0.86;
+                    den = 1.0 + (2.0 * 5.5e-3) / 0.86;
+                }
+                st1 = (st1 + pc * (eD - Delta)) / den;
+                st2 = (st2 + (pc / ECC2) * eT) / den;
+                a12 = (a12 + (pc / ECC2) * eS * 0.5) / den;
+                a11 = 0.5 * (st1 + st2);
+                a22 = 0.5 * (st1 - st2);
+            }
+            d.stress11[k] = a11;
+            d.stress22[k] = a22;
+            d.stress12[k] = a12;
+            s11[g] = a11;
+            s22[g] = a22;
+            s12[g] = a12;
+        } else if (LAST && d.relation == 1) {
+            d.Prep[(size_t)g * P + c] = 0.0;
+        }
+    }
+    // per-corner partial sums of the stress divergence
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+        if (j < E) {
+            double cu = 0.0, cv = 0.0;
+            const double tj = t[j];
+#pragma unroll
+            for (int s = 0; s < M; s++) {
+                if (s < E) {
+                    const size_t kb = (size_t)(j * M + s) * P + c;
+                    const double bu = d.SU[kb], bv = d.SV[kb], bm = d.SM[kb];
+                    cu = cu - s11[s] * bu - s12[s] * bv - s12[s] * bm * tj;
+                    cv = cv - s22[s] * bv - s12[s] * bu + s11[s] * bm * tj;
+                }
+            }
+            d.partU[(size_t)j * P + c] = cu;
+            d.partV[(size_t)j * P + c] = cv;
+        }
+    }
+}
+
+// Fused vertex kernel: outer sum and division of seaice_stress_divergence_variational
+// (variational.F:1139-1178), ocean_stress_coefficient (velocity_solver.F:2986-3082) and solve_velocity
+// (:3096-3208) or solve_velocity_revised (:3222-3342).
+template <bool LAST>
+__global__ void __launch_bounds__(256) k_sub_vertices(SihDev d)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= d.nVerticesSolve) return;
+    if (d.solveVelocity[v] != 1) {
+        if (LAST && !d.useOcean) d.ocnCoeff[v] = 0.0;
+        return;
+    }
+    const int PV = d.padV;
+    double dU = 0.0, dV = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int g = d.gidx[k * PV + v];
+        dU = dU + d.partU[g];
+        dV = dV + d.partV[g];
+    }
+    const double den0 = d.varDenom[v];
+    dU = dU / den0;
+    dV = dV / den0;
+    double uu = d.u[v], vv = d.v[v];
+    const double uo = d.uOcnVert[v], vo = d.vOcnVert[v];
+    double coeff = 0.0;
+    if (d.useOcean) {
+        if (d.quadratic) {
+            double du = uo - uu, dv = vo - vv;
+            coeff = DRAGIO * RHOW * d.iceAreaVertex[v] * sqrt(du * du + dv * dv);
+        } else {
+            coeff = DRAGIO * RHOW * d.iceAreaVertex[v];
+        }
+    }
+    const double m = d.totalMassVertex[v], mf = d.massF[v];
+    double l11, l22, r1, r2;
+    const double l12 = -mf - coeff * SIN_TURN * sign1(mf);
+    const double l21 = mf + coeff * SIN_TURN * sign1(mf);
+    if (d.relation == 2) {
+        const double brlx = d.brlx, dtD = d.dtDyn;
+        l11 = (brlx + 1.0) * (m / dtD) + coeff * COS_TURN;
+        l22 = (brlx + 1.0) * (m / dtD) + coeff * COS_TURN;
+        r1 = dU + d.airVertU[v] + d.tiltForceU[v] + coeff * d.ocnStressU[v] + (m * (brlx * uu + d.uInit[v])) / dtD;
+        r2 = dV + d.airVertV[v] + d.tiltForceV[v] + coeff * d.ocnStressV[v] + (m * (brlx * vv + d.vInit[v])) / dtD;
+    } else {
+        const double dtE = d.dtE;
+        l11 = m / dtE + coeff * COS_TURN;
+        l22 = m / dtE + coeff * COS_TURN;
+        r1 = dU + d.airVertU[v] + d.tiltForceU[v] + coeff * d.ocnStressU[v] + (m * uu) / dtE;
+        r2 = dV + d.airVertV[v] + d.tiltForceV[v] + coeff * d.ocnStressV[v] + (m * vv) / dtE;
+    }
+    if (d.relation != 3) {  // the linear relation has no velocity solve (velocity_solver.F:2529-2541)
+        const double den = l11 * l22 - l12 * l21;
+        d.u[v] = (l22 * r1 - l12 * r2) / den;
+        d.v[v] = (l11 * r2 - l21 * r1) / den;
+    }
+    if (LAST) {
+        d.divU[v] = dU;
+        d.divV[v] = dV;
+        d.ocnCoeff[v] = coeff;
+    }
+}
+
+// =========================================================================== post-subcycle kernels
+
+// seaice_final_divergence_shear_variational (variational.F:1198-1330) and principal_stresses
+// (velocity_solver.F:3534-3610)
+__global__ void k_post0_cells(SihDev d)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nCells) return;
+    const int E = d.nEdgesOnCell[c];
+    const int P = d.padC;
+    double div = 0.0, shr = 0.0, dAvg = 0.0;
+    const bool solve = d.solveStress[c] == 1;
+    if (solve) {
+        double dS = 0.0, tS = 0.0, sS = 0.0, dA = 0.0;
+        for (int i = 0; i < E; i++) {
+            size_t k = (size_t)i * P + c;
+            double e11 = d.strain11[k], e22 = d.strain22[k], e12 = d.strain12[k];
+            double sd = e11 + e22, st = e11 - e22, ss = e12 * 2.0;
+            double Delta = sqrt(sd * sd + (st * st + ss * ss) / ECC2);
+            dS = dS + sd;
+            tS = tS + st;
+            sS = sS + ss;
+            dA = dA + Delta;
+        }
+        double en = (double)E;
+        div = dS / en;
+        shr = sqrt(tS * tS + sS * sS) / en;
+        dAvg = dA / en;
+    }
+    if (d.useColumn) {
+        if (solve) {
+            d.ridgeConv[c] = -fmin(div, 0.0);
+            d.ridgeShear[c] = 0.5 * (dAvg - fabs(div));
+        } else {
+            d.ridgeConv[c] = 0.0;
+            d.ridgeShear[c] = 0.0;
+        }
+    }
+    d.divergence[c] = div * 100.0 * 86400.0;
+    d.shear[c] = shr * 100.0 * 86400.0;
+    if (c < d.nCellsSolve) {
+        for (int i = 0; i < E; i++) {
+            size_t k = (size_t)i * P + c;
+            double rp = d.Prep[k];
+            if (rp > PUNY) {
+                double a11 = d.stress11[k], a22 = d.stress22[k], a12 = d.stress12[k];
+                double sq = (a11 + a22) * (a11 + a22) - 4.0 * a11 * a22 + 4.0 * (a12 * a12);
+                double p1 = 0.5 * (a11 + a22) + 0.5 * sqrt(sq);
+                double p2 = 0.5 * (a11 + a22) - 0.5 * sqrt(sq);
+                d.prin1[k] = p1 / rp;
+                d.prin2[k] = p2 / rp;
+            } else {
+                d.prin1[k] = 1.0e30;
+                d.prin2[k] = 1.0e30;
+            }
+        }
+    }
+}
+
+// ocean_stress_final, vertex part: coefficient refresh (:3674) and :3709-3732
+__global__ void k_post0_vertices(SihDev d)
+{
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= d.nVertices) return;
+    if (!d.useOcean) {
+        d.ocnCoeff[v] = 0.0;
+        d.ocnStressU[v] = 0.0;
+        d.ocnStressV[v] = 0.0;
+        return;
+    }
+    if (v >= d.nVerticesSolve) return;
+    if (d.solveVelocity[v] == 1) {
+        double uo = d.uOcnVert[v], vo = d.vOcnVert[v], uu = d.u[v], vv = d.v[v], f = d.fVertex[v];
+        double coeff;
+        if (d.quadratic) {
+            double du = uo - uu, dv = vo - vv;
+            coeff = DRAGIO * RHOW * d.iceAreaVertex[v] * sqrt(du * du + dv * dv);
+        } else {
+            coeff = DRAGIO * RHOW * d.iceAreaVertex[v];
+        }
+        d.ocnCoeff[v] = coeff;
+        double su = coeff * ((uo - uu) * COS_TURN - (vo - vv) * SIN_TURN * sign1(f));
+        double sv = coeff * ((vo - vv) * COS_TURN + (uo - uu) * SIN_TURN * sign1(f));
+        d.ocnStressU[v] = su / d.iceAreaVertex[v];
+        d.ocnStressV[v] = sv / d.iceAreaVertex[v];
+    } else {
+        d.ocnStressU[v] = 0.0;
+        d.ocnStressV[v] = 0.0;
+    }
+}
+
+// seaice_interpolate_vertex_to_cell, mesh.F:2906-2976
+__global__ void k_post1_cells(SihDev d)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nCells) return;
+    if (!d.useOcean) {
+        d.ocnStressCellU[c] = 0.0;
+        d.ocnStressCellV[c] = 0.0;
+        return;
+    }
+    if (c >= d.nCellsSolve) return;
+    const int E = d.nEdgesOnCell[c];
+    double aU = 0.0, aV = 0.0, tot = 0.0;
+    for (int i = 0; i < E; i++) {
+        int v = d.voc[(size_t)i * d.padC + c];
+        double w = (double)(float)d.interiorVertex[v];
+        aU = aU + d.areaTriangle[v] * d.ocnStressU[v] * w;
+        aV = aV + d.areaTriangle[v] * d.ocnStressV[v] * w;
+        tot = tot + d.areaTriangle[v] * w;
+    }
+    if (tot > 0.0) {
+        aU = aU / tot;
+        aV = aV / tot;
+    }
+    d.ocnStressCellU[c] = aU;
+    d.ocnStressCellV[c] = aV;
+}
+
+// velocity_solver.F:3816-3825
+__global__ void k_post1_vertices(SihDev d)
+{
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= d.nVerticesSolve || !d.useOcean) return;
+    if (d.solveVelocity[v] == 1) {
+        d.ocnStressU[v] = d.ocnStressU[v] * d.iceAreaVertex[v];
+        d.ocnStressV[v] = d.ocnStressV[v] * d.iceAreaVertex[v];
+    }
+}
+
+// =========================================================================== launchers
+static inline dim3 gridFor(int n) { return dim3((unsigned)((n + 255) / 256)); }
+
+static int checkInit(sih_ctx *c, const char *who)
+{
+    if (!c) {
+        sih_set_error(std::string(who) + ": null context");
+        return SIH_ERR_ARG;
+    }
+    if (!c->inited) {
+        sih_set_error(std::string(who) + ": sih_evp_init has not been called");
+        return SIH_ERR_STATE;
+    }
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return sih_hip_fail(e, "hipSetDevice", __FILE__, __LINE__);
+    return SIH_OK;
+}
+
+extern "C" int sih_evp_pre_subcycle(sih_ctx *c, int stage)
+{
+    int rc = checkInit(c, "sih_evp_pre_subcycle");
+    if (rc) return rc;
+    if (stage < -1 || stage > 4) {
+        sih_set_error("sih_evp_pre_subcycle: stage must be -1..4");
+        return SIH_ERR_ARG;
+    }
+    const SihDev &d = c->dev;
+    dim3 b(256), gc = gridFor(c->nCells), gv = gridFor(c->nVertices);
+    hipStream_t s = c->stream;
+    if (stage == -1 || stage == 0) hipLaunchKernelGGL(k_pre0_cells, gc, b, 0, s, d);
+    if (stage == -1 || stage == 1) {
+        hipLaunchKernelGGL(k_pre1_vertices, gv, b, 0, s, d, c->cfg.calcVelocityMasks);
+        if (c->cfg.calcVelocityMasks) hipLaunchKernelGGL(k_pre1_cells, gc, b, 0, s, d);
+    }
+    if (stage == -1 || stage == 2) hipLaunchKernelGGL(k_pre2_vertices, gv, b, 0, s, d);
+    if (stage == -1 || stage == 3) hipLaunchKernelGGL(k_pre3_cells, gc, b, 0, s, d);
+    if (stage == -1 || stage == 4) {
+        hipLaunchKernelGGL(k_pre4_vertices, gv, b, 0, s, d);
+        hipLaunchKernelGGL(k_pre4_cells, gc, b, 0, s, d);
+    }
+    HIPCHK(hipGetLastError());
+    return SIH_OK;
+}
+
+template <int M>
+static void launchCells(sih_ctx *c, bool last)
+{
+    dim3 b(256), g = gridFor(c->nCells);
+    const SihDev &d = c->dev;
+    if (c->sparseGrad) {
+        if (last)
+            hipLaunchKernelGGL((k_sub_cells<M, true, true>), g, b, 0, c->stream, d);
+        else
+            hipLaunchKernelGGL((k_sub_cells<M, true, false>), g, b, 0, c->stream, d);
+    } else {
+        if (last)
+            hipLaunchKernelGGL((k_sub_cells<M, false, true>), g, b, 0, c->stream, d);
+        else
+            hipLaunchKernelGGL((k_sub_cells<M, false, false>), g, b, 0, c->stream, d);
+    }
+}
+
+static void launchCellKernel(sih_ctx *c, bool last)
+{
+    switch (c->M) {
+        case 3: launchCells<3>(c, last); break;
+        case 4: launchCells<4>(c, last); break;
+        case 5: launchCells<5>(c, last); break;
+        case 6: launchCells<6>(c, last); break;
+        case 7: launchCells<7>(c, last); break;
+        case 8: launchCells<8>(c, last); break;
+        case 9: launchCells<9>(c, last); break;
+        default: launchCells<10>(c, last); break;
+    }
+}
+
+static void launchVertexKernel(sih_ctx *c, bool last)
+{
+    dim3 b(256), g = gridFor(c->nVerticesSolve);
+    if (last)
+        hipLaunchKernelGGL(k_sub_vertices<true>, g, b, 0, c->stream, c->dev);
+    else
+        hipLaunchKernelGGL(k_sub_vertices<false>, g, b, 0, c->stream, c->dev);
+}
+
+extern "C" int sih_evp_subcycle(sih_ctx *c, int n, int last)
+{
+    int rc = checkInit(c, "sih_evp_subcycle");
+    if (rc) return rc;
+    if (n < 0) {
+        sih_set_error("sih_evp_subcycle: n must be >= 0");
+        return SIH_ERR_ARG;
+    }
+    for (int it = 0; it < n; it++) {
+        bool l = last && it == n - 1;
+        launchCellKernel(c, l);
+        launchVertexKernel(c, l);
+    }
+    HIPCHK(hipGetLastError());
+    return SIH_OK;
+}
+
+extern "C" int sih_evp_post_subcycle(sih_ctx *c, int stage)
+{
+    int rc = checkInit(c, "sih_evp_post_subcycle");
+    if (rc) return rc;
+    if (stage < -1 || stage > 1) {
+        sih_set_error("sih_evp_post_subcycle: stage must be -1..1");
+        return SIH_ERR_ARG;
+    }
+    const SihDev &d = c->dev;
+    dim3 b(256), gc = gridFor(c->nCells), gv = gridFor(c->nVertices);
+    if (stage == -1 || stage == 0) {
+        hipLaunchKernelGGL(k_post0_cells, gc, b, 0, c->stream, d);
+        hipLaunchKernelGGL(k_post0_vertices, gv, b, 0, c->stream, d);
+    }
+    if (stage == -1 || stage == 1) {
+        hipLaunchKernelGGL(k_post1_cells, gc, b, 0, c->stream, d);
+        hipLaunchKernelGGL(k_post1_vertices, gv, b, 0, c->stream, d);
+    }
+    HIPCHK(hipGetLastError());
+    return SIH_OK;
+}
+
+extern "C" int sih_evp_run(sih_ctx *c)
+{
+    int rc = checkInit(c, "sih_evp_run");
+    if (rc) return rc;
+    if ((rc = sih_evp_pre_subcycle(c, -1))) return rc;
+    if ((rc = sih_evp_subcycle(c, c->cfg.elasticSubcycleNumber, 1))) return rc;
+    if ((rc = sih_evp_post_subcycle(c, -1))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SIH_OK;
+}
+
+static int ensureEvents(sih_ctx *c, size_t n)
+{
+    while (c->events.size() < n) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        c->events.push_back(e);
+    }
+    return SIH_OK;
+}
+
+extern "C" int sih_evp_subcycle_timed(sih_ctx *c, int n, int useGraph, int sampleEvery, double *totalMs, double *cellMs,
+                                      double *vertexMs)
+{
+    int rc = checkInit(c, "sih_evp_subcycle_timed");
+    if (rc) return rc;
+    if (n < 1 || !totalMs) {
+        sih_set_error("sih_evp_subcycle_timed: bad argument");
+        return SIH_ERR_ARG;
+    }
+    if (cellMs) *cellMs = 0.0;
+    if (vertexMs) *vertexMs = 0.0;
+    if (useGraph) {
+        if (!c->graphExec || c->graphN != n) {
+            if (c->graphExec) {
+                hipGraphExecDestroy(c->graphExec);
+                c->graphExec = nullptr;
+            }
+            hipGraph_t graph;
+            HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            for (int it = 0; it < n; it++) {
+                launchCellKernel(c, false);
+                launchVertexKernel(c, false);
+            }
+            HIPCHK(hipStreamEndCapture(c->stream, &graph));
+            HIPCHK(hipGraphInstantiate(&c->graphExec, graph, nullptr, nullptr, 0));
+            HIPCHK(hipGraphDestroy(graph));
+            c->graphN = n;
+        }
+        if ((rc = ensureEvents(c, 2))) return rc;
+        HIPCHK(hipEventRecord(c->events[0], c->stream));
+        HIPCHK(hipGraphLaunch(c->graphExec, c->stream));
+        HIPCHK(hipEventRecord(c->events[1], c->stream));
+        HIPCHK(hipEventSynchronize(c->events[1]));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, c->events[0], c->events[1]));
+        *totalMs = ms;
+        return SIH_OK;
+    }
+    int nSamples = (sampleEvery > 0) ? (n + sampleEvery - 1) / sampleEvery : 0;
+    if ((rc = ensureEvents(c, 2 + 3 * (size_t)nSamples))) return rc;
+    HIPCHK(hipEventRecord(c->events[0], c->stream));
+    int si = 0;
+    for (int it = 0; it < n; it++) {
+        bool sample = sampleEvery > 0 && (it % sampleEvery) == 0;
+        if (sample) HIPCHK(hipEventRecord(c->events[2 + 3 * si], c->stream));
+        launchCellKernel(c, false);
+        if (sample) HIPCHK(hipEventRecord(c->events[2 + 3 * si + 1], c->stream));
+        launchVertexKernel(c, false);
+        if (sample) {
+            HIPCHK(hipEventRecord(c->events[2 + 3 * si + 2], c->stream));
+            si++;
+        }
+    }
+    HIPCHK(hipEventRecord(c->events[1], c->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventSynchronize(c->events[1]));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, c->events[0], c->events[1]));
+    *totalMs = ms;
+    double sc = 0.0, sv = 0.0;
+    for (int k = 0; k < si; k++) {
+        float a = 0.f, b = 0.f;
+        HIPCHK(hipEventElapsedTime(&a, c->events[2 + 3 * k], c->events[2 + 3 * k + 1]));
+        HIPCHK(hipEventElapsedTime(&b, c->events[2 + 3 * k + 1], c->events[2 + 3 * k + 2]));
+        sc += a;
+        sv += b;
+    }
+    if (si > 0) {
+        if (cellMs) *cellMs = sc / si;
+        if (vertexMs) *vertexMs = sv / si;
+    }
+    return SIH_OK;
+}

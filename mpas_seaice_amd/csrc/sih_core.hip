@@ -1,0 +1,579 @@
+// Context, device field registry, layout conversion and halo pack/unpack of libseaice_hip.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+#include "sih_internal.h"
+
+static thread_local std::string g_err;
+
+void sih_set_error(const std::string &s) { g_err = s; }
+
+int sih_hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    g_err = buf;
+    return SIH_ERR_HIP;
+}
+
+extern "C" const char *sih_last_error(void) { return g_err.c_str(); }
+
+static int roundUp(int n, int m) { return ((n + m - 1) / m) * m; }
+
+// ------------------------------------------------------------------------------------------
+// layout conversion kernels: host layout (lead fastest, entity slowest, host numbering)
+//   <-> device SoA (entity fastest, internal numbering)
+template <typename T>
+__global__ void k_put(T *__restrict__ dst, const T *__restrict__ src, const int *__restrict__ perm, int n, int L,
+                      int pad)
+{
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)n * L) return;
+    int l = (int)(t / n), i = (int)(t % n);
+    int h = perm ? perm[i] : i;
+    dst[(size_t)l * pad + i] = src[(size_t)h * L + l];
+}
+
+template <typename T>
+__global__ void k_get(T *__restrict__ dst, const T *__restrict__ src, const int *__restrict__ perm, int n, int L,
+                      int pad)
+{
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)n * L) return;
+    int l = (int)(t / n), i = (int)(t % n);
+    int h = perm ? perm[i] : i;
+    dst[(size_t)h * L + l] = src[(size_t)l * pad + i];
+}
+
+template <typename T>
+__global__ void k_pack(T *__restrict__ buf, const T *__restrict__ f, const int *__restrict__ idx, int n)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) buf[t] = f[idx[t]];
+}
+
+template <typename T>
+__global__ void k_unpack(const T *__restrict__ buf, T *__restrict__ f, const int *__restrict__ idx, int n)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) f[idx[t]] = buf[t];
+}
+
+// ------------------------------------------------------------------------------------------
+static int locCount(const sih_ctx *c, SihLoc loc)
+{
+    return loc == LOC_CELL ? c->nCells : loc == LOC_VERTEX ? c->nVertices : c->nEdges;
+}
+static int locPad(const sih_ctx *c, SihLoc loc) { return loc == LOC_CELL ? c->padC : loc == LOC_VERTEX ? c->padV : c->padE; }
+static const int *locPerm(const sih_ctx *c, SihLoc loc)
+{
+    return loc == LOC_CELL ? c->d_cellPerm : loc == LOC_VERTEX ? c->d_vertPerm : nullptr;
+}
+
+static int devAlloc(sih_ctx *c, void **p, size_t bytes)
+{
+    HIPCHK(hipMalloc(p, bytes));
+    HIPCHK(hipMemsetAsync(*p, 0, bytes, c->stream));
+    c->allocs.push_back(*p);
+    return SIH_OK;
+}
+
+static int addField(sih_ctx *c, const char *name, SihLoc loc, int lead, bool isInt)
+{
+    SihField f;
+    f.name = name;
+    f.loc = loc;
+    f.lead = lead;
+    f.isInt = isInt;
+    f.d = nullptr;
+    size_t bytes = (size_t)lead * locPad(c, loc) * (isInt ? 4 : 8);
+    int rc = devAlloc(c, &f.d, bytes);
+    if (rc) return rc;
+    c->fields[name] = f;
+    return SIH_OK;
+}
+
+SihField *sih_find_field(sih_ctx *c, const char *name)
+{
+    auto it = c->fields.find(name);
+    if (it == c->fields.end()) return nullptr;
+    return &it->second;
+}
+
+static int ensureStage(sih_ctx *c, size_t bytes)
+{
+    if (c->stageBytes >= bytes) return SIH_OK;
+    if (c->d_stage) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipFree(c->d_stage));
+        c->d_stage = nullptr;
+        c->stageBytes = 0;
+    }
+    size_t nb = std::max(bytes, (size_t)1 << 20);
+    HIPCHK(hipMalloc(&c->d_stage, nb));
+    c->stageBytes = nb;
+    return SIH_OK;
+}
+
+// Morton key of a point in the unit cube
+static uint64_t mortonKey(double x, double y, double z)
+{
+    auto spread = [](uint64_t v) {
+        v &= 0x1fffff;
+        v = (v | v << 32) & 0x1f00000000ffffULL;
+        v = (v | v << 16) & 0x1f0000ff0000ffULL;
+        v = (v | v << 8) & 0x100f00f00f00f00fULL;
+        v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
+        v = (v | v << 2) & 0x1249249249249249ULL;
+        return v;
+    };
+    auto q = [](double t) {
+        double s = std::min(std::max(t, 0.0), 1.0) * 2097151.0;
+        return (uint64_t)s;
+    };
+    return spread(q(x)) | (spread(q(y)) << 1) | (spread(q(z)) << 2);
+}
+
+extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **out)
+{
+    if (!m || !out) {
+        sih_set_error("sih_block_create: null argument");
+        return SIH_ERR_ARG;
+    }
+    if (m->maxEdges < 3 || m->maxEdges > SIH_MAXE || m->vertexDegree != 3) {
+        sih_set_error("sih_block_create: maxEdges must be in [3,10] and vertexDegree 3");
+        return SIH_ERR_UNSUPPORTED;
+    }
+    if (m->nCells < 1 || m->nVertices < 1 || m->nCellsSolve > m->nCells || m->nVerticesSolve > m->nVertices ||
+        !m->nEdgesOnCell || !m->verticesOnCell || !m->cellsOnCell || !m->cellsOnVertex || !m->xCell || !m->xVertex ||
+        !m->areaCell || !m->areaTriangle || !m->fVertex) {
+        sih_set_error("sih_block_create: inconsistent mesh description");
+        return SIH_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(device));
+    sih_ctx *c = new sih_ctx();
+    c->device = device;
+    HIPCHK(hipStreamCreate(&c->ownStream));
+    c->stream = c->ownStream;
+    c->nCells = m->nCells;
+    c->nCellsSolve = m->nCellsSolve;
+    c->nVertices = m->nVertices;
+    c->nVerticesSolve = m->nVerticesSolve;
+    c->nEdges = m->nEdges;
+    c->nEdgesSolve = m->nEdgesSolve;
+    c->M = m->maxEdges;
+    c->D = m->vertexDegree;
+    c->onASphere = m->onASphere;
+    c->R = m->sphereRadius;
+    c->padC = roundUp(c->nCells + 1, 64);
+    c->padV = roundUp(c->nVertices + 1, 64);
+    c->padE = roundUp(std::max(c->nEdges, 0) + 1, 64);
+    c->renumber = m->renumber != 0;
+    const int nC = c->nCells, nV = c->nVertices, M = c->M;
+
+    // validate connectivity before anything is dereferenced on the device
+    for (int i = 0; i < nC; i++) {
+        int E = m->nEdgesOnCell[i];
+        if (E < 3 || E > M) {
+            sih_set_error("sih_block_create: nEdgesOnCell out of range");
+            delete c;
+            return SIH_ERR_ARG;
+        }
+        for (int s = 0; s < E; s++) {
+            int v = m->verticesOnCell[(size_t)i * M + s];
+            int nb = m->cellsOnCell[(size_t)i * M + s];
+            if (v < 1 || v > nV + 1 || nb < 0 || nb > nC + 1) {
+                sih_set_error("sih_block_create: verticesOnCell / cellsOnCell index out of range");
+                delete c;
+                return SIH_ERR_ARG;
+            }
+        }
+    }
+    for (size_t k = 0; k < (size_t)nV * 3; k++) {
+        int cc = m->cellsOnVertex[k];
+        if (cc < 0 || cc > nC + 1) {
+            sih_set_error("sih_block_create: cellsOnVertex index out of range");
+            delete c;
+            return SIH_ERR_ARG;
+        }
+    }
+    if (m->dvEdge && m->nEdgesSolve > 0) {
+        double mn = 1.0e30;
+        for (int e = 0; e < m->nEdgesSolve; e++) mn = std::min(mn, m->dvEdge[e]);
+        c->minDvEdge = mn;
+    }
+
+    // ---- internal numbering: owned entities first (as in MPAS), each group along a Morton curve;
+    //      vertices follow the cell they are first met at.
+    c->cellPerm.resize(nC);
+    std::iota(c->cellPerm.begin(), c->cellPerm.end(), 0);
+    c->vertPerm.resize(nV);
+    std::iota(c->vertPerm.begin(), c->vertPerm.end(), 0);
+    if (c->renumber) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        const double *xyz[3] = {m->xCell, m->yCell, m->zCell};
+        for (int k = 0; k < 3; k++)
+            for (int i = 0; i < nC; i++) {
+                lo[k] = std::min(lo[k], xyz[k][i]);
+                hi[k] = std::max(hi[k], xyz[k][i]);
+            }
+        std::vector<uint64_t> key(nC);
+        for (int i = 0; i < nC; i++) {
+            double q[3];
+            for (int k = 0; k < 3; k++) q[k] = hi[k] > lo[k] ? (xyz[k][i] - lo[k]) / (hi[k] - lo[k]) : 0.0;
+            key[i] = mortonKey(q[0], q[1], q[2]);
+        }
+        auto cmp = [&](int a, int b) { return key[a] != key[b] ? key[a] < key[b] : a < b; };
+        std::sort(c->cellPerm.begin(), c->cellPerm.begin() + c->nCellsSolve, cmp);
+        std::sort(c->cellPerm.begin() + c->nCellsSolve, c->cellPerm.end(), cmp);
+    }
+    c->cellInv.assign(nC + 1, nC);
+    for (int i = 0; i < nC; i++) c->cellInv[c->cellPerm[i]] = i;
+    if (c->renumber) {
+        std::vector<int> vkey(nV, nC);
+        for (int v = 0; v < nV; v++)
+            for (int k = 0; k < 3; k++) {
+                int cc = m->cellsOnVertex[(size_t)v * 3 + k];
+                if (cc >= 1 && cc <= nC) vkey[v] = std::min(vkey[v], c->cellInv[cc - 1]);
+            }
+        auto cmp = [&](int a, int b) { return vkey[a] != vkey[b] ? vkey[a] < vkey[b] : a < b; };
+        std::sort(c->vertPerm.begin(), c->vertPerm.begin() + c->nVerticesSolve, cmp);
+        std::sort(c->vertPerm.begin() + c->nVerticesSolve, c->vertPerm.end(), cmp);
+    }
+    c->vertInv.assign(nV + 1, nV);
+    for (int i = 0; i < nV; i++) c->vertInv[c->vertPerm[i]] = i;
+
+    int rc;
+    if ((rc = devAlloc(c, (void **)&c->d_cellPerm, sizeof(int) * c->padC))) return rc;
+    if ((rc = devAlloc(c, (void **)&c->d_vertPerm, sizeof(int) * c->padV))) return rc;
+    HIPCHK(hipMemcpyAsync(c->d_cellPerm, c->cellPerm.data(), sizeof(int) * nC, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_vertPerm, c->vertPerm.data(), sizeof(int) * nV, hipMemcpyHostToDevice, c->stream));
+    if ((rc = devAlloc(c, (void **)&c->d_flag, 64))) return rc;
+
+    // ---- field registry
+    struct Spec {
+        const char *name;
+        SihLoc loc;
+        int lead;
+        bool isInt;
+    };
+    const int MM = M * M;
+    const Spec specs[] = {
+        // connectivity in internal numbering
+        {"_nEdgesOnCell", LOC_CELL, 1, true}, {"_voc", LOC_CELL, M, true}, {"_coc", LOC_CELL, M, true},
+        {"_cov", LOC_VERTEX, 3, true}, {"_cvav", LOC_VERTEX, 3, true}, {"_gidx", LOC_VERTEX, 3, true},
+        // geometry
+        {"xCell", LOC_CELL, 1, false}, {"yCell", LOC_CELL, 1, false}, {"zCell", LOC_CELL, 1, false},
+        {"xVertex", LOC_VERTEX, 1, false}, {"yVertex", LOC_VERTEX, 1, false}, {"zVertex", LOC_VERTEX, 1, false},
+        {"areaCell", LOC_CELL, 1, false}, {"areaTriangle", LOC_VERTEX, 1, false}, {"fVertex", LOC_VERTEX, 1, false},
+        // boundary
+        {"interiorVertex", LOC_VERTEX, 1, true},
+        // velocity_solver pool
+        {"uVelocity", LOC_VERTEX, 1, false}, {"vVelocity", LOC_VERTEX, 1, false},
+        {"uVelocityInitial", LOC_VERTEX, 1, false}, {"vVelocityInitial", LOC_VERTEX, 1, false},
+        {"solveStress", LOC_CELL, 1, true}, {"solveVelocity", LOC_VERTEX, 1, true},
+        {"solveVelocityPrevious", LOC_VERTEX, 1, true}, {"icePressure", LOC_CELL, 1, false},
+        {"stressDivergenceU", LOC_VERTEX, 1, false}, {"stressDivergenceV", LOC_VERTEX, 1, false},
+        {"airStressCellU", LOC_CELL, 1, false}, {"airStressCellV", LOC_CELL, 1, false},
+        {"airStressVertexU", LOC_VERTEX, 1, false}, {"airStressVertexV", LOC_VERTEX, 1, false},
+        {"uOceanVelocityVertex", LOC_VERTEX, 1, false}, {"vOceanVelocityVertex", LOC_VERTEX, 1, false},
+        {"oceanStressU", LOC_VERTEX, 1, false}, {"oceanStressV", LOC_VERTEX, 1, false},
+        {"oceanStressCoeff", LOC_VERTEX, 1, false}, {"oceanStressCellU", LOC_CELL, 1, false},
+        {"oceanStressCellV", LOC_CELL, 1, false}, {"seaSurfaceTiltVertexU", LOC_VERTEX, 1, false},
+        {"seaSurfaceTiltVertexV", LOC_VERTEX, 1, false}, {"surfaceTiltForceU", LOC_VERTEX, 1, false},
+        {"surfaceTiltForceV", LOC_VERTEX, 1, false}, {"totalMassVertexfVertex", LOC_VERTEX, 1, false},
+        {"divergence", LOC_CELL, 1, false}, {"shear", LOC_CELL, 1, false},
+        // velocity_variational pool
+        {"strain11", LOC_CELL, M, false}, {"strain22", LOC_CELL, M, false}, {"strain12", LOC_CELL, M, false},
+        {"stress11", LOC_CELL, M, false}, {"stress22", LOC_CELL, M, false}, {"stress12", LOC_CELL, M, false},
+        {"replacementPressure", LOC_CELL, M, false}, {"principalStress1", LOC_CELL, M, false},
+        {"principalStress2", LOC_CELL, M, false}, {"basisGradientU", LOC_CELL, MM, false},
+        {"basisGradientV", LOC_CELL, MM, false}, {"basisIntegralsU", LOC_CELL, MM, false},
+        {"basisIntegralsV", LOC_CELL, MM, false}, {"basisIntegralsMetric", LOC_CELL, MM, false},
+        {"tanLatVertexRotatedOverRadius", LOC_VERTEX, 1, false}, {"variationalDenominator", LOC_VERTEX, 1, false},
+        {"cellVerticesAtVertex", LOC_VERTEX, 3, true},
+        // compact gradients and per-corner divergence partial sums (library-internal)
+        {"_gradU3", LOC_CELL, 3 * M, false}, {"_gradV3", LOC_CELL, 3 * M, false},
+        {"_partU", LOC_CELL, M, false}, {"_partV", LOC_CELL, M, false},
+        // icestate, aggregates, coupling
+        {"iceAreaVertex", LOC_VERTEX, 1, false}, {"totalMassVertex", LOC_VERTEX, 1, false},
+        {"iceAreaCellInitial", LOC_CELL, 1, false}, {"totalMassCell", LOC_CELL, 1, false},
+        {"iceAreaCell", LOC_CELL, 1, false}, {"iceVolumeCell", LOC_CELL, 1, false},
+        {"snowVolumeCell", LOC_CELL, 1, false}, {"uOceanVelocity", LOC_CELL, 1, false},
+        {"vOceanVelocity", LOC_CELL, 1, false}, {"seaSurfaceTiltU", LOC_CELL, 1, false},
+        {"seaSurfaceTiltV", LOC_CELL, 1, false}, {"landIceMask", LOC_CELL, 1, true},
+        {"landIceMaskVertex", LOC_VERTEX, 1, true}, {"uAirVelocity", LOC_CELL, 1, false},
+        {"vAirVelocity", LOC_CELL, 1, false}, {"airDensity", LOC_CELL, 1, false},
+        {"ridgeConvergence", LOC_CELL, 1, false}, {"ridgeShear", LOC_CELL, 1, false},
+    };
+    for (const Spec &s : specs)
+        if ((rc = addField(c, s.name, s.loc, s.lead, s.isInt))) return rc;
+
+    // ---- connectivity in internal numbering (built on the host, uploaded as SoA)
+    {
+        std::vector<int> ne(c->padC, 0), voc((size_t)M * c->padC, nV), coc((size_t)M * c->padC, nC);
+        for (int i = 0; i < nC; i++) {
+            int h = c->cellPerm[i];
+            int E = m->nEdgesOnCell[h];
+            ne[i] = E;
+            for (int s = 0; s < E; s++) {
+                int v = m->verticesOnCell[(size_t)h * M + s];
+                int nb = m->cellsOnCell[(size_t)h * M + s];
+                voc[(size_t)s * c->padC + i] = (v >= 1 && v <= nV) ? c->vertInv[v - 1] : nV;
+                coc[(size_t)s * c->padC + i] = (nb >= 1 && nb <= nC) ? c->cellInv[nb - 1] : nC;
+            }
+        }
+        std::vector<int> cov((size_t)3 * c->padV, nC);
+        for (int i = 0; i < nV; i++) {
+            int h = c->vertPerm[i];
+            for (int k = 0; k < 3; k++) {
+                int cc = m->cellsOnVertex[(size_t)h * 3 + k];
+                cov[(size_t)k * c->padV + i] = (cc >= 1 && cc <= nC) ? c->cellInv[cc - 1] : nC;
+            }
+        }
+        HIPCHK(hipMemcpyAsync(c->fields["_nEdgesOnCell"].d, ne.data(), ne.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->fields["_voc"].d, voc.data(), voc.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->fields["_coc"].d, coc.data(), coc.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->fields["_cov"].d, cov.data(), cov.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    *out = c;
+    struct G {
+        const char *n;
+        const double *p;
+        size_t cnt;
+    };
+    const G geo[] = {{"xCell", m->xCell, (size_t)nC},       {"yCell", m->yCell, (size_t)nC},
+                     {"zCell", m->zCell, (size_t)nC},       {"xVertex", m->xVertex, (size_t)nV},
+                     {"yVertex", m->yVertex, (size_t)nV},   {"zVertex", m->zVertex, (size_t)nV},
+                     {"areaCell", m->areaCell, (size_t)nC}, {"areaTriangle", m->areaTriangle, (size_t)nV},
+                     {"fVertex", m->fVertex, (size_t)nV}};
+    for (const G &g : geo)
+        if ((rc = sih_field_put(c, g.n, g.p, g.cnt))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SIH_OK;
+}
+
+extern "C" int sih_block_destroy(sih_ctx *c)
+{
+    if (!c) return SIH_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (c->graphExec) hipGraphExecDestroy(c->graphExec);
+    for (hipEvent_t e : c->events) hipEventDestroy(e);
+    for (void *p : c->allocs) hipFree(p);
+    for (int k = 0; k < 2; k++) {
+        if (c->d_send[k]) hipFree(c->d_send[k]);
+        if (c->d_recv[k]) hipFree(c->d_recv[k]);
+    }
+    if (c->d_stage) hipFree(c->d_stage);
+    if (c->ownStream) hipStreamDestroy(c->ownStream);
+    delete c;
+    return SIH_OK;
+}
+
+extern "C" int sih_set_stream(sih_ctx *c, void *s)
+{
+    if (!c) return SIH_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->ownStream;
+    if (c->graphExec) {  // a captured graph is tied to nothing stream-specific, but rebuild to be safe
+        hipGraphExecDestroy(c->graphExec);
+        c->graphExec = nullptr;
+        c->graphN = 0;
+    }
+    return SIH_OK;
+}
+
+extern "C" int sih_sync(sih_ctx *c)
+{
+    if (!c) return SIH_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SIH_OK;
+}
+
+extern "C" size_t sih_field_count(sih_ctx *c, const char *name, int *elemSize)
+{
+    SihField *f = c ? sih_find_field(c, name) : nullptr;
+    if (!f) return 0;
+    if (elemSize) *elemSize = f->isInt ? 4 : 8;
+    return (size_t)f->lead * locCount(c, f->loc);
+}
+
+static int putget(sih_ctx *c, const char *name, void *host, size_t count, bool put)
+{
+    if (!c || !name || !host) {
+        sih_set_error("sih_field_put/get: null argument");
+        return SIH_ERR_ARG;
+    }
+    SihField *f = sih_find_field(c, name);
+    if (!f) {
+        sih_set_error(std::string("unknown field: ") + name);
+        return SIH_ERR_ARG;
+    }
+    int n = locCount(c, f->loc), pad = locPad(c, f->loc), L = f->lead;
+    if (count != (size_t)n * L) {
+        sih_set_error(std::string("field ") + name + ": element count mismatch");
+        return SIH_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    size_t es = f->isInt ? 4 : 8, bytes = count * es;
+    int rc = ensureStage(c, bytes);
+    if (rc) return rc;
+    const int *perm = c->renumber ? locPerm(c, f->loc) : nullptr;
+    long total = (long)n * L;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (put) {
+        HIPCHK(hipMemcpyAsync(c->d_stage, host, bytes, hipMemcpyHostToDevice, c->stream));
+        if (f->isInt)
+            hipLaunchKernelGGL(k_put<int>, grid, block, 0, c->stream, (int *)f->d, (const int *)c->d_stage, perm, n, L, pad);
+        else
+            hipLaunchKernelGGL(k_put<double>, grid, block, 0, c->stream, (double *)f->d, (const double *)c->d_stage, perm,
+                               n, L, pad);
+        HIPCHK(hipGetLastError());
+        // the staging buffer is reused by the next call
+        HIPCHK(hipStreamSynchronize(c->stream));
+    } else {
+        if (f->isInt)
+            hipLaunchKernelGGL(k_get<int>, grid, block, 0, c->stream, (int *)c->d_stage, (const int *)f->d, perm, n, L, pad);
+        else
+            hipLaunchKernelGGL(k_get<double>, grid, block, 0, c->stream, (double *)c->d_stage, (const double *)f->d, perm,
+                               n, L, pad);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(host, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return SIH_OK;
+}
+
+extern "C" int sih_field_put(sih_ctx *c, const char *name, const void *host, size_t count)
+{
+    if (name && name[0] == '_') {
+        sih_set_error("fields starting with '_' are library-internal");
+        return SIH_ERR_ARG;
+    }
+    int rc = putget(c, name, const_cast<void *>(host), count, true);
+    if (rc == SIH_OK && c->inited && (!strncmp(name, "basisGradient", 13) || !strncmp(name, "basisIntegrals", 14)))
+        c->sparseGrad = false;  // stale until sih_evp_static_changed()
+    return rc;
+}
+
+extern "C" int sih_field_get(sih_ctx *c, const char *name, void *host, size_t count)
+{
+    return putget(c, name, host, count, false);
+}
+
+// ------------------------------------------------------------------------------------------ halo
+extern "C" int sih_halo_set_lists(sih_ctx *c, int location, int nSend, const int32_t *sendIdx, int nRecv,
+                                  const int32_t *recvIdx)
+{
+    if (!c || location < 0 || location > 1 || nSend < 0 || nRecv < 0 || (nSend && !sendIdx) || (nRecv && !recvIdx)) {
+        sih_set_error("sih_halo_set_lists: bad argument");
+        return SIH_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    const std::vector<int> &inv = location == 0 ? c->cellInv : c->vertInv;
+    int n = location == 0 ? c->nCells : c->nVertices;
+    std::vector<int> s(nSend), r(nRecv);
+    for (int i = 0; i < nSend; i++) {
+        if (sendIdx[i] < 1 || sendIdx[i] > n) {
+            sih_set_error("sih_halo_set_lists: send index out of range");
+            return SIH_ERR_ARG;
+        }
+        s[i] = inv[sendIdx[i] - 1];
+    }
+    for (int i = 0; i < nRecv; i++) {
+        if (recvIdx[i] < 1 || recvIdx[i] > n) {
+            sih_set_error("sih_halo_set_lists: recv index out of range");
+            return SIH_ERR_ARG;
+        }
+        r[i] = inv[recvIdx[i] - 1];
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->d_send[location]) HIPCHK(hipFree(c->d_send[location]));
+    if (c->d_recv[location]) HIPCHK(hipFree(c->d_recv[location]));
+    c->d_send[location] = c->d_recv[location] = nullptr;
+    if (nSend) {
+        HIPCHK(hipMalloc((void **)&c->d_send[location], sizeof(int) * nSend));
+        HIPCHK(hipMemcpy(c->d_send[location], s.data(), sizeof(int) * nSend, hipMemcpyHostToDevice));
+    }
+    if (nRecv) {
+        HIPCHK(hipMalloc((void **)&c->d_recv[location], sizeof(int) * nRecv));
+        HIPCHK(hipMemcpy(c->d_recv[location], r.data(), sizeof(int) * nRecv, hipMemcpyHostToDevice));
+    }
+    c->nSend[location] = nSend;
+    c->nRecv[location] = nRecv;
+    return SIH_OK;
+}
+
+static int haloPackUnpack(sih_ctx *c, int location, int nFields, const char *const *names, void *buf, bool pack)
+{
+    if (!c || location < 0 || location > 1 || nFields < 0 || !names) {
+        sih_set_error("sih_halo_pack/unpack: bad argument");
+        return SIH_ERR_ARG;
+    }
+    int n = pack ? c->nSend[location] : c->nRecv[location];
+    const int *idx = pack ? c->d_send[location] : c->d_recv[location];
+    if (n == 0 || nFields == 0) return SIH_OK;
+    if (!buf) {
+        sih_set_error("sih_halo_pack/unpack: null buffer");
+        return SIH_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    for (int f = 0; f < nFields; f++) {
+        SihField *fl = sih_find_field(c, names[f]);
+        if (!fl || (int)fl->loc != location || fl->lead != 1) {
+            sih_set_error(std::string("sih_halo_pack/unpack: not a scalar field of this location: ") + names[f]);
+            return SIH_ERR_ARG;
+        }
+        dim3 grid((n + 255) / 256), block(256);
+        if (fl->isInt) {
+            int *b = (int *)buf + (size_t)f * n;
+            if (pack)
+                hipLaunchKernelGGL(k_pack<int>, grid, block, 0, c->stream, b, (const int *)fl->d, idx, n);
+            else
+                hipLaunchKernelGGL(k_unpack<int>, grid, block, 0, c->stream, (const int *)b, (int *)fl->d, idx, n);
+        } else {
+            double *b = (double *)buf + (size_t)f * n;
+            if (pack)
+                hipLaunchKernelGGL(k_pack<double>, grid, block, 0, c->stream, b, (const double *)fl->d, idx, n);
+            else
+                hipLaunchKernelGGL(k_unpack<double>, grid, block, 0, c->stream, (const double *)b, (double *)fl->d, idx, n);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return SIH_OK;
+}
+
+extern "C" int sih_halo_pack(sih_ctx *c, int location, int nFields, const char *const *names, void *deviceBuf)
+{
+    return haloPackUnpack(c, location, nFields, names, deviceBuf, true);
+}
+
+extern "C" int sih_halo_unpack(sih_ctx *c, int location, int nFields, const char *const *names, const void *deviceBuf)
+{
+    return haloPackUnpack(c, location, nFields, names, const_cast<void *>(deviceBuf), false);
+}
+
+extern "C" int sih_get_info(sih_ctx *c, const char *key, double *value)
+{
+    if (!c || !key || !value) return SIH_ERR_ARG;
+    std::string k = key;
+    if (k == "sparseGradient") *value = c->sparseGrad ? 1.0 : 0.0;
+    else if (k == "dampingTimescale") *value = c->dev.dampT;
+    else if (k == "elasticTimeStep") *value = c->dev.dtE;
+    else if (k == "dynamicsTimeStep") *value = c->dev.dtDyn;
+    else if (k == "numericalInertiaCoefficient") *value = c->dev.brlx;
+    else if (k == "padC") *value = c->padC;
+    else if (k == "padV") *value = c->padV;
+    else if (k == "minDvEdge") *value = c->minDvEdge;
+    else {
+        sih_set_error("sih_get_info: unknown key " + k);
+        return SIH_ERR_ARG;
+    }
+    return SIH_OK;
+}

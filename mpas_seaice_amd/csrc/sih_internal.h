@@ -1,0 +1,86 @@
+// Internal definitions of libseaice_hip (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "seaice_hip.h"
+
+#define SIH_MAXE 10  // largest maxEdges the kernels are instantiated for
+
+enum SihLoc { LOC_CELL = 0, LOC_VERTEX = 1, LOC_EDGE = 2 };
+
+// A device-resident field: structure-of-arrays, element (l, i) of a field with `lead` leading
+// entries per mesh entity lives at d[l * pad + i], i being the library's internal entity index.
+struct SihField {
+    std::string name;
+    SihLoc loc;
+    int lead;
+    bool isInt;
+    void *d;
+};
+
+// everything the time-step kernels need, by value
+struct SihDev {
+    int nCells, nCellsSolve, nVertices, nVerticesSolve, M, D, nCat;
+    int padC, padV;
+    // connectivity (internal numbering, 0-based; "none" = nCells / nVertices, a zero-filled slot)
+    const int *nEdgesOnCell, *voc, *coc, *cov, *cvav, *gidx;
+    const int *interiorVertex, *landIceMask, *landIceMaskVertex;
+    int *solveStress, *solveVelocity, *solveVelocityPrevious;
+    // geometry
+    const double *areaCell, *areaTriangle, *fVertex, *tanLat, *varDenom;
+    const double *gradU, *gradV, *gradU3, *gradV3, *SU, *SV, *SM;
+    // state
+    double *u, *v, *uInit, *vInit;
+    double *strain11, *strain22, *strain12, *stress11, *stress22, *stress12, *Prep, *prin1, *prin2;
+    double *partU, *partV;
+    double *divU, *divV, *icePressure;
+    double *airCellU, *airCellV, *airVertU, *airVertV;
+    double *uOcnVert, *vOcnVert, *ocnStressU, *ocnStressV, *ocnCoeff, *ocnStressCellU, *ocnStressCellV;
+    double *tiltVertU, *tiltVertV, *tiltForceU, *tiltForceV, *massF;
+    double *divergence, *shear, *ridgeConv, *ridgeShear;
+    double *iceAreaVertex, *totalMassVertex, *iceAreaCellInitial, *totalMassCell;
+    double *iceAreaCell, *iceVolumeCell, *snowVolumeCell;
+    const double *iceAreaCat, *iceVolCat, *snowVolCat;
+    const double *uOcn, *vOcn, *tiltU, *tiltV, *uAir, *vAir, *airDensity;
+    // scalars
+    double dtDyn, dtE, dampT, brlx;
+    int relation, useOcean, quadratic, useAir, tiltMode, useColumn;
+};
+
+struct sih_ctx {
+    int device = 0;
+    hipStream_t ownStream = nullptr, stream = nullptr;
+    int nCells = 0, nCellsSolve = 0, nVertices = 0, nVerticesSolve = 0, nEdges = 0, nEdgesSolve = 0;
+    int M = 0, D = 0, onASphere = 0;
+    double R = 1.0;
+    int padC = 0, padV = 0, padE = 0;
+    bool renumber = false;
+    std::vector<int> cellPerm, cellInv, vertPerm, vertInv;  // perm: internal -> host (0-based); inv: host -> internal
+    int *d_cellPerm = nullptr, *d_vertPerm = nullptr;
+    std::map<std::string, SihField> fields;
+    std::vector<void *> allocs;
+    sih_evp_config cfg{};
+    bool inited = false, sparseGrad = false;
+    double minDvEdge = 0.0;
+    SihDev dev{};
+    void *d_stage = nullptr;
+    size_t stageBytes = 0;
+    int nSend[2] = {0, 0}, nRecv[2] = {0, 0};
+    int *d_send[2] = {nullptr, nullptr}, *d_recv[2] = {nullptr, nullptr};
+    hipGraphExec_t graphExec = nullptr;
+    int graphN = 0;
+    int *d_flag = nullptr;
+    std::vector<hipEvent_t> events;
+};
+
+void sih_set_error(const std::string &s);
+int sih_hip_fail(hipError_t e, const char *what, const char *file, int line);
+#define HIPCHK(x)                                                             \
+    do {                                                                      \
+        hipError_t e_ = (x);                                                  \
+        if (e_ != hipSuccess) return sih_hip_fail(e_, #x, __FILE__, __LINE__); \
+    } while (0)

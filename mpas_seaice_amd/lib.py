@@ -1,0 +1,234 @@
+"""ctypes binding of libseaice_hip.so (the C ABI declared in include/seaice_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, an exception is
+raised (the reference treats the same conditions as MPAS_LOG_CRIT aborts).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libseaice_hip.so")
+_lib = None
+
+
+class SeaiceHipError(RuntimeError):
+    pass
+
+
+class MeshDesc(ctypes.Structure):
+    _fields_ = [
+        ("nCells", ctypes.c_int32), ("nCellsSolve", ctypes.c_int32),
+        ("nVertices", ctypes.c_int32), ("nVerticesSolve", ctypes.c_int32),
+        ("nEdges", ctypes.c_int32), ("nEdgesSolve", ctypes.c_int32),
+        ("maxEdges", ctypes.c_int32), ("vertexDegree", ctypes.c_int32),
+        ("onASphere", ctypes.c_int32), ("sphereRadius", ctypes.c_double),
+        ("nEdgesOnCell", ctypes.c_void_p), ("verticesOnCell", ctypes.c_void_p),
+        ("cellsOnCell", ctypes.c_void_p), ("edgesOnCell", ctypes.c_void_p),
+        ("cellsOnVertex", ctypes.c_void_p), ("cellsOnEdge", ctypes.c_void_p),
+        ("verticesOnEdge", ctypes.c_void_p),
+        ("xCell", ctypes.c_void_p), ("yCell", ctypes.c_void_p), ("zCell", ctypes.c_void_p),
+        ("xVertex", ctypes.c_void_p), ("yVertex", ctypes.c_void_p), ("zVertex", ctypes.c_void_p),
+        ("areaCell", ctypes.c_void_p), ("areaTriangle", ctypes.c_void_p), ("fVertex", ctypes.c_void_p),
+        ("dvEdge", ctypes.c_void_p), ("dcEdge", ctypes.c_void_p),
+        ("renumber", ctypes.c_int32),
+    ]
+
+
+class EvpConfig(ctypes.Structure):
+    _fields_ = [
+        ("dt", ctypes.c_double),
+        ("dynamicsSubcycleNumber", ctypes.c_int32), ("elasticSubcycleNumber", ctypes.c_int32),
+        ("constitutiveRelation", ctypes.c_int32), ("variationalBasis", ctypes.c_int32),
+        ("variationalDenominator", ctypes.c_int32), ("wachspressIntegrationOrder", ctypes.c_int32),
+        ("rotateCartesianGrid", ctypes.c_int32), ("includeMetricTerms", ctypes.c_int32),
+        ("useAirStress", ctypes.c_int32), ("useOceanStress", ctypes.c_int32),
+        ("oceanStressType", ctypes.c_int32), ("surfaceTilt", ctypes.c_int32),
+        ("calcVelocityMasks", ctypes.c_int32), ("useColumnPackage", ctypes.c_int32),
+        ("nCategories", ctypes.c_int32), ("minEdgeLengthGlobal", ctypes.c_double),
+    ]
+
+
+EXPORTS = [
+    "sih_block_create", "sih_block_destroy", "sih_last_error", "sih_set_stream", "sih_sync",
+    "sih_evp_init", "sih_evp_static_changed", "sih_field_put", "sih_field_get", "sih_field_count",
+    "sih_evp_pre_subcycle", "sih_evp_subcycle", "sih_evp_post_subcycle", "sih_evp_run",
+    "sih_evp_subcycle_timed", "sih_halo_set_lists", "sih_halo_pack", "sih_halo_unpack", "sih_get_info",
+]
+
+
+def load():
+    """Load the shared library (no GPU needed for loading / symbol lookup)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SeaiceHipError(
+            f"{LIB_PATH} is missing: build it with `python -m mpas_seaice_amd.build` "
+            "(there is no CPU fallback for the solver)")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.sih_last_error.restype = ctypes.c_char_p
+    lib.sih_field_count.restype = ctypes.c_size_t
+    lib.sih_field_count.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+    lib.sih_block_create.argtypes = [ctypes.POINTER(MeshDesc), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    lib.sih_block_destroy.argtypes = [ctypes.c_void_p]
+    lib.sih_set_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.sih_sync.argtypes = [ctypes.c_void_p]
+    lib.sih_evp_init.argtypes = [ctypes.c_void_p, ctypes.POINTER(EvpConfig)]
+    lib.sih_evp_static_changed.argtypes = [ctypes.c_void_p]
+    lib.sih_field_put.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t]
+    lib.sih_field_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t]
+    lib.sih_evp_pre_subcycle.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.sih_evp_subcycle.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    lib.sih_evp_post_subcycle.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.sih_evp_run.argtypes = [ctypes.c_void_p]
+    lib.sih_evp_subcycle_timed.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                           ctypes.POINTER(ctypes.c_double)]
+    lib.sih_halo_set_lists.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                       ctypes.c_int, ctypes.c_void_p]
+    lib.sih_halo_pack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                  ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
+    lib.sih_halo_unpack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                    ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
+    lib.sih_get_info.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().sih_last_error()
+        raise SeaiceHipError(f"{what}: error {rc}: {msg.decode() if msg else ''}")
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else None
+
+
+class BlockContext:
+    """One MPAS block resident on one GPU (wraps a ``sih_ctx*``)."""
+
+    def __init__(self, mesh_pool, dims, device=0, renumber=True):
+        lib = load()
+        self._lib = lib
+        self._keep = []
+        d = MeshDesc()
+        for k in ("nCells", "nCellsSolve", "nVertices", "nVerticesSolve", "nEdges", "nEdgesSolve", "maxEdges",
+                  "vertexDegree"):
+            setattr(d, k, int(dims[k]))
+        d.onASphere = int(bool(mesh_pool["on_a_sphere"]))
+        d.sphereRadius = float(mesh_pool["sphere_radius"])
+        for k in ("nEdgesOnCell", "verticesOnCell", "cellsOnCell", "edgesOnCell", "cellsOnVertex", "cellsOnEdge",
+                  "verticesOnEdge"):
+            a = mesh_pool.get(k)
+            if a is not None:
+                assert a.dtype == np.int32 and a.flags["F_CONTIGUOUS"], k
+                self._keep.append(a)
+            setattr(d, k, _ptr(a))
+        for k in ("xCell", "yCell", "zCell", "xVertex", "yVertex", "zVertex", "areaCell", "areaTriangle", "fVertex",
+                  "dvEdge", "dcEdge"):
+            a = mesh_pool.get(k)
+            if a is not None:
+                assert a.dtype == np.float64, k
+            setattr(d, k, _ptr(a))
+        d.renumber = int(bool(renumber))
+        self.dims = dict(dims)
+        h = ctypes.c_void_p()
+        check(lib.sih_block_create(ctypes.byref(d), int(device), ctypes.byref(h)), "sih_block_create")
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.sih_block_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- thin wrappers -------------------------------------------------------------------------
+    def evp_init(self, cfg: EvpConfig):
+        check(self._lib.sih_evp_init(self.handle, ctypes.byref(cfg)), "sih_evp_init")
+
+    def static_changed(self):
+        check(self._lib.sih_evp_static_changed(self.handle), "sih_evp_static_changed")
+
+    def field_count(self, name):
+        es = ctypes.c_int(0)
+        n = self._lib.sih_field_count(self.handle, name.encode(), ctypes.byref(es))
+        return int(n), int(es.value)
+
+    def put(self, name, arr):
+        n, es = self.field_count(name)
+        if n == 0:
+            raise SeaiceHipError(f"unknown field {name}")
+        assert arr.dtype == (np.int32 if es == 4 else np.float64), (name, arr.dtype)
+        assert arr.flags["F_CONTIGUOUS"] or arr.flags["C_CONTIGUOUS"], name
+        assert arr.size >= n, (name, arr.size, n)
+        check(self._lib.sih_field_put(self.handle, name.encode(), _ptr(arr), n), f"sih_field_put({name})")
+
+    def get(self, name, arr):
+        n, es = self.field_count(name)
+        if n == 0:
+            raise SeaiceHipError(f"unknown field {name}")
+        assert arr.dtype == (np.int32 if es == 4 else np.float64), (name, arr.dtype)
+        assert arr.flags["F_CONTIGUOUS"] or arr.flags["C_CONTIGUOUS"], name
+        assert arr.size >= n, (name, arr.size, n)
+        check(self._lib.sih_field_get(self.handle, name.encode(), _ptr(arr), n), f"sih_field_get({name})")
+
+    def pre_subcycle(self, stage=-1):
+        check(self._lib.sih_evp_pre_subcycle(self.handle, stage), "sih_evp_pre_subcycle")
+
+    def subcycle(self, n, last=False):
+        check(self._lib.sih_evp_subcycle(self.handle, int(n), int(bool(last))), "sih_evp_subcycle")
+
+    def post_subcycle(self, stage=-1):
+        check(self._lib.sih_evp_post_subcycle(self.handle, stage), "sih_evp_post_subcycle")
+
+    def run(self):
+        check(self._lib.sih_evp_run(self.handle), "sih_evp_run")
+
+    def subcycle_timed(self, n, use_graph=False, sample_every=0):
+        t = ctypes.c_double(0)
+        tc = ctypes.c_double(0)
+        tv = ctypes.c_double(0)
+        check(self._lib.sih_evp_subcycle_timed(self.handle, int(n), int(bool(use_graph)), int(sample_every),
+                                               ctypes.byref(t), ctypes.byref(tc), ctypes.byref(tv)),
+              "sih_evp_subcycle_timed")
+        return t.value, tc.value, tv.value
+
+    def sync(self):
+        check(self._lib.sih_sync(self.handle), "sih_sync")
+
+    def set_stream(self, stream_ptr):
+        check(self._lib.sih_set_stream(self.handle, ctypes.c_void_p(stream_ptr) if stream_ptr else None),
+              "sih_set_stream")
+
+    def halo_set_lists(self, location, send_idx, recv_idx):
+        s = np.ascontiguousarray(send_idx, dtype=np.int32)
+        r = np.ascontiguousarray(recv_idx, dtype=np.int32)
+        check(self._lib.sih_halo_set_lists(self.handle, int(location), s.size, _ptr(s) if s.size else None,
+                                           r.size, _ptr(r) if r.size else None), "sih_halo_set_lists")
+
+    def _names(self, names):
+        arr = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])
+        return arr
+
+    def halo_pack(self, location, names, device_ptr):
+        check(self._lib.sih_halo_pack(self.handle, int(location), len(names), self._names(names),
+                                      ctypes.c_void_p(device_ptr)), "sih_halo_pack")
+
+    def halo_unpack(self, location, names, device_ptr):
+        check(self._lib.sih_halo_unpack(self.handle, int(location), len(names), self._names(names),
+                                        ctypes.c_void_p(device_ptr)), "sih_halo_unpack")
+
+    def info(self, key):
+        v = ctypes.c_double(0)
+        check(self._lib.sih_get_info(self.handle, key.encode(), ctypes.byref(v)), "sih_get_info")
+        return v.value

@@ -1,0 +1,170 @@
+"""Host-side stand-in for the MPAS block / pool containers the reference solver is written against.
+
+The reference reaches every field through ``MPAS_pool_get_subpool(block % structs, "<pool>")`` and
+``MPAS_pool_get_array(pool, "<name>")`` (e.g. /root/reference/src/shared/mpas_seaice_velocity_solver.F:
+1218-1236).  Here a pool is a dict name -> numpy array, a block owns a dict of pools plus its
+dimensions, and a domain owns the block list and the configs -- enough structure for the host
+mirror of ``seaice_init_velocity_solver`` / ``seaice_run_velocity_solver`` to read like the
+reference.  Field names, pools and dimension order follow /root/reference/src/Registry.xml
+(:2251-2367 mesh, :2439-2524 tracers, :3683-3688 boundary, :3691-3727 velocity_solver,
+:3747-3765 velocity_variational).
+
+Arrays are allocated like MPAS does: one extra slot past nCells / nVertices / nEdges so that the
+``n+1`` "no neighbour" sentinel can be dereferenced, Fortran-ordered, float64 / int32.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# defaults of the namelist options the velocity solver and advection read
+# (/root/reference/src/Registry.xml:317-340, 566-670)
+DEFAULT_CONFIGS = {
+    "config_dt": 3600.0,
+    "config_dynamics_subcycle_number": 1,
+    "config_elastic_subcycle_number": 120,
+    "config_use_velocity_solver": True,
+    "config_strain_scheme": "variational",
+    "config_stress_divergence_scheme": "variational",
+    "config_constitutive_relation_type": "evp",
+    "config_variational_basis": "wachspress",
+    "config_variational_denominator_type": "original",
+    "config_wachspress_integration_type": "dunavant",
+    "config_wachspress_integration_order": 8,
+    "config_average_variational_strain": False,
+    "config_rotate_cartesian_grid": True,
+    "config_include_metric_terms": True,
+    "config_use_air_stress": True,
+    "config_use_ocean_stress": True,
+    "config_use_surface_tilt": True,
+    "config_geostrophic_surface_tilt": True,
+    "config_ocean_stress_type": "quadratic",
+    "config_calc_velocity_masks": True,
+    "config_use_column_package": False,
+    "config_use_column_vertical_thermodynamics": False,
+    "config_use_special_boundaries_velocity": False,
+    "config_use_special_boundaries_velocity_masks": False,
+    "config_use_halo_exch": True,
+    "config_aggregate_halo_exch": False,
+    "config_reuse_halo_exch": False,
+    "config_num_halos": 2,
+    "config_advection_type": "incremental_remap",
+    "config_earth_radius": 6371229.0,
+}
+
+
+class Block:
+    def __init__(self, mesh, configs, nCategories=5, blockID=0):
+        self.blockID = blockID
+        self.configs = configs
+        self.dimensions = {k: int(mesh[k]) for k in (
+            "nCells", "nCellsSolve", "nVertices", "nVerticesSolve", "nEdges", "nEdgesSolve",
+            "maxEdges", "vertexDegree")}
+        self.dimensions["nCategories"] = nCategories
+        self.dimensions["ONE"] = 1
+        self.structs = {}
+        self.halo = None  # filled by the partitioner for multi-block runs
+        self._alloc(mesh)
+
+    # -- allocation -------------------------------------------------------------------------
+    def _alloc(self, mesh):
+        d = self.dimensions
+        nC, nV, nE, M, D, nCat = d["nCells"], d["nVertices"], d["nEdges"], d["maxEdges"], d["vertexDegree"], d["nCategories"]
+
+        def rc(*lead):
+            return np.zeros(tuple(lead) + (nC + 1,), dtype=np.float64, order="F")
+
+        def rv(*lead):
+            return np.zeros(tuple(lead) + (nV + 1,), dtype=np.float64, order="F")
+
+        def ic():
+            return np.zeros(nC + 1, dtype=np.int32)
+
+        def iv(*lead):
+            return np.zeros(tuple(lead) + (nV + 1,), dtype=np.int32, order="F")
+
+        meshp = {"on_a_sphere": mesh["on_a_sphere"], "sphere_radius": mesh["sphere_radius"]}
+
+        def pad1(a, fill):
+            out = np.full(a.shape[:-1] + (a.shape[-1] + 1,), fill, dtype=a.dtype, order="F")
+            out[..., :-1] = a
+            return out
+        for k in ("xCell", "yCell", "zCell", "latCell", "lonCell", "areaCell", "fCell"):
+            meshp[k] = pad1(np.asarray(mesh[k], dtype=np.float64), 0.0)
+        for k in ("xVertex", "yVertex", "zVertex", "latVertex", "lonVertex", "areaTriangle", "fVertex",
+                  "kiteAreasOnVertex"):
+            meshp[k] = pad1(np.asarray(mesh[k], dtype=np.float64), 0.0)
+        for k in ("xEdge", "yEdge", "zEdge", "dcEdge", "dvEdge", "latEdge", "lonEdge", "fEdge"):
+            meshp[k] = pad1(np.asarray(mesh[k], dtype=np.float64), 0.0)
+        meshp["nEdgesOnCell"] = pad1(mesh["nEdgesOnCell"].astype(np.int32), 0)
+        meshp["verticesOnCell"] = pad1(mesh["verticesOnCell"].astype(np.int32), nV + 1)
+        meshp["edgesOnCell"] = pad1(mesh["edgesOnCell"].astype(np.int32), nE + 1)
+        meshp["cellsOnCell"] = pad1(mesh["cellsOnCell"].astype(np.int32), nC + 1)
+        meshp["cellsOnVertex"] = pad1(mesh["cellsOnVertex"].astype(np.int32), nC + 1)
+        meshp["cellsOnEdge"] = pad1(mesh["cellsOnEdge"].astype(np.int32), nC + 1)
+        meshp["verticesOnEdge"] = pad1(mesh["verticesOnEdge"].astype(np.int32), nV + 1)
+        if "edgesOnVertex" in mesh:
+            meshp["edgesOnVertex"] = pad1(mesh["edgesOnVertex"].astype(np.int32), nE + 1)
+        self.structs["mesh"] = meshp
+
+        self.structs["boundary"] = {"interiorVertex": iv(), "interiorCell": ic(),
+                                    "interiorEdge": np.zeros(nE + 1, dtype=np.int32)}
+        vs = {"dynamicsTimeStep": np.zeros(1), "elasticTimeStep": np.zeros(1)}
+        for k in ("uVelocity", "vVelocity", "uVelocityInitial", "vVelocityInitial", "stressDivergenceU",
+                  "stressDivergenceV", "airStressVertexU", "airStressVertexV", "uOceanVelocityVertex",
+                  "vOceanVelocityVertex", "oceanStressU", "oceanStressV", "oceanStressCoeff",
+                  "seaSurfaceTiltVertexU", "seaSurfaceTiltVertexV", "surfaceTiltForceU", "surfaceTiltForceV",
+                  "totalMassVertexfVertex"):
+            vs[k] = rv()
+        for k in ("icePressure", "airStressCellU", "airStressCellV", "oceanStressCellU", "oceanStressCellV",
+                  "divergence", "shear", "uVelocityCell", "vVelocityCell"):
+            vs[k] = rc()
+        vs["solveStress"] = ic()
+        vs["dynamicallyLockedCellsMask"] = ic()
+        vs["solveVelocity"] = iv()
+        vs["solveVelocityPrevious"] = iv()
+        self.structs["velocity_solver"] = vs
+
+        vv = {}
+        for k in ("strain11", "strain22", "strain12", "stress11", "stress22", "stress12",
+                  "principalStress1", "principalStress2", "replacementPressure"):
+            vv[k] = rc(M)
+        for k in ("basisIntegralsU", "basisIntegralsV", "basisIntegralsMetric", "basisGradientU", "basisGradientV"):
+            vv[k] = rc(M, M)
+        vv["tanLatVertexRotatedOverRadius"] = rv()
+        vv["variationalDenominator"] = rv()
+        vv["cellVerticesAtVertex"] = iv(D)
+        self.structs["velocity_variational"] = vv
+
+        self.structs["icestate"] = {k: (rv() if "Vertex" in k else rc()) for k in (
+            "iceAreaVertex", "totalMassVertex", "iceAreaCellInitial", "totalMassCell", "openWaterArea")}
+        self.structs["tracers_aggregate"] = {k: rc() for k in ("iceAreaCell", "iceVolumeCell", "snowVolumeCell")}
+        self.structs["tracers"] = {k: rc(1, nCat) for k in ("iceAreaCategory", "iceVolumeCategory",
+                                                            "snowVolumeCategory")}
+        self.structs["ocean_coupling"] = {"uOceanVelocity": rc(), "vOceanVelocity": rc(),
+                                          "seaSurfaceTiltU": rc(), "seaSurfaceTiltV": rc(),
+                                          "landIceMask": ic(), "landIceMaskVertex": iv()}
+        self.structs["atmos_coupling"] = {"uAirVelocity": rc(), "vAirVelocity": rc(), "airDensity": rc()}
+        self.structs["ridging"] = {"ridgeConvergence": rc(), "ridgeShear": rc()}
+
+
+class Domain:
+    """``domain % blocklist`` + ``domain % configs`` (one process may hold several blocks)."""
+
+    def __init__(self, meshes, configs=None, nCategories=5):
+        cfg = dict(DEFAULT_CONFIGS)
+        if configs:
+            cfg.update(configs)
+        self.configs = cfg
+        if not isinstance(meshes, (list, tuple)):
+            meshes = [meshes]
+        self.blocklist = [Block(m, cfg, nCategories=nCategories, blockID=i) for i, m in enumerate(meshes)]
+        self.dminfo = None      # communicator description for multi-process runs
+        self.solver_state = {}  # module-level "save" variables of the reference modules
+
+
+def mpas_pool_get_subpool(block, name):
+    return block.structs[name]
+
+
+def mpas_pool_get_array(pool, name):
+    return pool[name]

@@ -1,0 +1,220 @@
+"""Host-side mirror of the reference's velocity-solver interface, driving the HIP library.
+
+Same entry points, argument meaning and call order as the reference modules they replace:
+
+  seaice_mesh_pool_create(domain)          /root/reference/src/shared/mpas_seaice_mesh_pool.F:76
+  seaice_init_velocity_solver(domain)      /root/reference/src/shared/mpas_seaice_velocity_solver.F:85
+  seaice_run_velocity_solver(domain,clock) /root/reference/src/shared/mpas_seaice_velocity_solver.F:562
+  seaice_mesh_pool_destroy(domain)         /root/reference/src/shared/mpas_seaice_mesh_pool.F:188
+
+The pools stay the source of truth at dynamics-step granularity: inputs are uploaded at entry and
+every field the reference solver leaves in the pools is downloaded at exit, so restart / analysis /
+coupling code sees the same state.  This is the logic the Fortran ISO_C_BINDING shim carries in a
+real MPAS build; it is written in Python here because the MPAS framework the Fortran shim needs
+(pools, dmpar) is not available outside a host model.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import lib as _lib
+
+RELATION = {"evp": 1, "evp_revised": 2, "linear": 3}
+
+# (pool, field) moved host -> device at the start of every seaice_run_velocity_solver
+RUN_INPUTS = [
+    ("tracers", "iceAreaCategory"), ("tracers", "iceVolumeCategory"), ("tracers", "snowVolumeCategory"),
+    ("ocean_coupling", "uOceanVelocity"), ("ocean_coupling", "vOceanVelocity"),
+    ("ocean_coupling", "landIceMask"), ("ocean_coupling", "landIceMaskVertex"),
+    ("atmos_coupling", "uAirVelocity"), ("atmos_coupling", "vAirVelocity"), ("atmos_coupling", "airDensity"),
+    ("velocity_solver", "uVelocity"), ("velocity_solver", "vVelocity"),
+    ("velocity_solver", "solveVelocityPrevious"),
+    ("velocity_solver", "stressDivergenceU"), ("velocity_solver", "stressDivergenceV"),
+    ("velocity_solver", "oceanStressU"), ("velocity_solver", "oceanStressV"),
+    ("velocity_variational", "stress11"), ("velocity_variational", "stress22"),
+    ("velocity_variational", "stress12"),
+]
+# (pool, field) moved device -> host at the end
+RUN_OUTPUTS = [
+    ("velocity_solver", k) for k in (
+        "uVelocity", "vVelocity", "uVelocityInitial", "vVelocityInitial", "solveStress", "solveVelocity",
+        "solveVelocityPrevious", "icePressure", "stressDivergenceU", "stressDivergenceV", "airStressCellU",
+        "airStressCellV", "airStressVertexU", "airStressVertexV", "uOceanVelocityVertex", "vOceanVelocityVertex",
+        "oceanStressU", "oceanStressV", "oceanStressCoeff", "oceanStressCellU", "oceanStressCellV",
+        "surfaceTiltForceU", "surfaceTiltForceV", "totalMassVertexfVertex", "divergence", "shear")
+] + [
+    ("velocity_variational", k) for k in (
+        "strain11", "strain22", "strain12", "stress11", "stress22", "stress12", "replacementPressure",
+        "principalStress1", "principalStress2")
+] + [
+    ("icestate", k) for k in ("iceAreaVertex", "totalMassVertex", "iceAreaCellInitial", "totalMassCell")
+] + [
+    ("tracers_aggregate", k) for k in ("iceAreaCell", "iceVolumeCell", "snowVolumeCell")
+]
+STATIC_OUTPUTS = [
+    ("boundary", "interiorVertex"),
+] + [("velocity_variational", k) for k in (
+    "tanLatVertexRotatedOverRadius", "cellVerticesAtVertex", "basisGradientU", "basisGradientV",
+    "basisIntegralsU", "basisIntegralsV", "basisIntegralsMetric", "variationalDenominator")]
+
+
+def _evp_config(domain, block):
+    cfg = domain.configs
+    c = _lib.EvpConfig()
+    c.dt = float(cfg["config_dt"])
+    c.dynamicsSubcycleNumber = int(cfg["config_dynamics_subcycle_number"])
+    c.elasticSubcycleNumber = int(cfg["config_elastic_subcycle_number"])
+    rel = cfg["config_constitutive_relation_type"]
+    if rel not in RELATION:
+        raise _lib.SeaiceHipError("config_constitutive_relation_type unknown: " + str(rel))
+    c.constitutiveRelation = RELATION[rel]
+    if cfg["config_strain_scheme"] != "variational" or cfg["config_stress_divergence_scheme"] != "variational":
+        raise _lib.SeaiceHipError("only the variational strain / stress-divergence schemes are implemented")
+    if cfg["config_average_variational_strain"]:
+        raise _lib.SeaiceHipError("config_average_variational_strain is not implemented")
+    basis = cfg["config_variational_basis"]
+    if basis == "wachspress":
+        if cfg["config_wachspress_integration_type"] != "dunavant":
+            raise _lib.SeaiceHipError("only dunavant integration is implemented")
+        c.variationalBasis = 1
+    elif basis == "none":
+        c.variationalBasis = 0
+    else:
+        raise _lib.SeaiceHipError("Unknown variational basis type: " + str(basis))
+    den = cfg["config_variational_denominator_type"]
+    if den not in ("original", "alternate"):
+        raise _lib.SeaiceHipError("Unknown variational denominator type: " + str(den))
+    c.variationalDenominator = 1 if den == "alternate" else 0
+    c.wachspressIntegrationOrder = int(cfg["config_wachspress_integration_order"])
+    c.rotateCartesianGrid = int(bool(cfg["config_rotate_cartesian_grid"]))
+    c.includeMetricTerms = int(bool(cfg["config_include_metric_terms"]))
+    c.useAirStress = int(bool(cfg["config_use_air_stress"]))
+    c.useOceanStress = int(bool(cfg["config_use_ocean_stress"]))
+    ost = cfg["config_ocean_stress_type"]
+    if ost not in ("quadratic", "linear"):
+        raise _lib.SeaiceHipError("config_ocean_stress_type unknown: " + str(ost))
+    c.oceanStressType = 1 if ost == "quadratic" else 2
+    c.surfaceTilt = 0 if not cfg["config_use_surface_tilt"] else (1 if cfg["config_geostrophic_surface_tilt"] else 2)
+    c.calcVelocityMasks = int(bool(cfg["config_calc_velocity_masks"]))
+    if cfg["config_use_column_package"] and cfg["config_use_column_vertical_thermodynamics"]:
+        raise _lib.SeaiceHipError("colpkg_ice_strength (column package) is outside this solver's scope")
+    c.useColumnPackage = int(bool(cfg["config_use_column_package"]))
+    c.nCategories = int(block.dimensions["nCategories"])
+    c.minEdgeLengthGlobal = float(domain.solver_state.get("dvEdgeMinGlobal", 0.0))
+    return c
+
+
+def seaice_mesh_pool_create(domain, device=0, renumber=True):
+    """One device context per block.  Unlike the reference (mesh_pool.F:103-105) several blocks per
+    process are accepted; ``device`` may be an int or a list with one ordinal per block."""
+    for i, b in enumerate(domain.blocklist):
+        dev = device[i] if isinstance(device, (list, tuple)) else device
+        b.ctx = _lib.BlockContext(b.structs["mesh"], b.dimensions, device=dev, renumber=renumber)
+
+
+def seaice_mesh_pool_destroy(domain):
+    for b in domain.blocklist:
+        if getattr(b, "ctx", None) is not None:
+            b.ctx.close()
+            b.ctx = None
+
+
+def seaice_init_velocity_solver(domain):
+    cfg = domain.configs
+    # global minimum edge length (mpas_dmpar_min_real in seaice_init_evp, constitutive_relation.F:132-149)
+    dvmin = min(float(b.structs["mesh"]["dvEdge"][:b.dimensions["nEdgesSolve"]].min()) for b in domain.blocklist)
+    comm = getattr(domain, "comm", None)
+    if comm is not None:
+        dvmin = comm.allreduce_min(dvmin)
+    domain.solver_state["dvEdgeMinGlobal"] = dvmin
+    for b in domain.blocklist:
+        vs = b.structs["velocity_solver"]
+        vs["dynamicsTimeStep"][0] = cfg["config_dt"] / float(cfg["config_dynamics_subcycle_number"])
+        vs["elasticTimeStep"][0] = vs["dynamicsTimeStep"][0] / float(cfg["config_elastic_subcycle_number"])
+        if not cfg["config_use_velocity_solver"]:
+            continue
+        b.ctx.evp_init(_evp_config(domain, b))
+        if cfg["config_variational_basis"] == "none":
+            vv = b.structs["velocity_variational"]
+            for k in ("basisGradientU", "basisGradientV", "basisIntegralsU", "basisIntegralsV", "basisIntegralsMetric"):
+                b.ctx.put(k, vv[k])
+            b.ctx.static_changed()
+        for pool, name in STATIC_OUTPUTS:
+            b.ctx.get(name, b.structs[pool][name])
+    if comm is not None:
+        comm.halo_exchange(domain, ["interiorVertex"])
+        for b in domain.blocklist:
+            b.ctx.get("interiorVertex", b.structs["boundary"]["interiorVertex"])
+
+
+def _upload(domain, b):
+    cfg = domain.configs
+    for pool, name in RUN_INPUTS:
+        b.ctx.put(name, b.structs[pool][name])
+    if cfg["config_use_surface_tilt"] and not cfg["config_geostrophic_surface_tilt"]:
+        b.ctx.put("seaSurfaceTiltU", b.structs["ocean_coupling"]["seaSurfaceTiltU"])
+        b.ctx.put("seaSurfaceTiltV", b.structs["ocean_coupling"]["seaSurfaceTiltV"])
+    if not cfg["config_calc_velocity_masks"]:
+        b.ctx.put("solveStress", b.structs["velocity_solver"]["solveStress"])
+        b.ctx.put("solveVelocity", b.structs["velocity_solver"]["solveVelocity"])
+
+
+def _download(domain, b):
+    for pool, name in RUN_OUTPUTS:
+        b.ctx.get(name, b.structs[pool][name])
+    if domain.configs["config_use_column_package"]:
+        b.ctx.get("ridgeConvergence", b.structs["ridging"]["ridgeConvergence"])
+        b.ctx.get("ridgeShear", b.structs["ridging"]["ridgeShear"])
+
+
+def velocity_solver_pre_subcycle(domain):
+    comm = getattr(domain, "comm", None)
+    ex = comm is not None and domain.configs["config_use_halo_exch"]
+    after = {0: ["iceAreaCellInitial", "totalMassCell"], 1: ["solveVelocity"], 2: ["uVelocity", "vVelocity"],
+             3: ["icePressure", "airStressCellU", "airStressCellV"], 4: []}
+    if not ex:
+        for b in domain.blocklist:
+            b.ctx.pre_subcycle(-1)
+        return
+    for stage in range(5):
+        for b in domain.blocklist:
+            b.ctx.pre_subcycle(stage)
+        if after[stage]:
+            comm.halo_exchange(domain, after[stage])
+
+
+def subcycle_velocity_solver(domain, clock=None):
+    n = int(domain.configs["config_elastic_subcycle_number"])
+    comm = getattr(domain, "comm", None)
+    ex = comm is not None and domain.configs["config_use_halo_exch"]
+    if not ex:
+        for b in domain.blocklist:
+            b.ctx.subcycle(n, last=True)
+        return
+    for it in range(n):
+        for b in domain.blocklist:
+            b.ctx.subcycle(1, last=(it == n - 1))
+        comm.halo_exchange(domain, ["uVelocity", "vVelocity"])
+
+
+def velocity_solver_post_subcycle(domain):
+    comm = getattr(domain, "comm", None)
+    ex = comm is not None and domain.configs["config_use_halo_exch"]
+    for b in domain.blocklist:
+        b.ctx.post_subcycle(0)
+    if ex and domain.configs["config_use_ocean_stress"]:
+        comm.halo_exchange(domain, ["oceanStressU", "oceanStressV"])
+    for b in domain.blocklist:
+        b.ctx.post_subcycle(1)
+
+
+def seaice_run_velocity_solver(domain, clock=None):
+    if not domain.configs["config_use_velocity_solver"]:
+        return
+    for b in domain.blocklist:
+        _upload(domain, b)
+    velocity_solver_pre_subcycle(domain)
+    subcycle_velocity_solver(domain, clock)
+    velocity_solver_post_subcycle(domain)
+    for b in domain.blocklist:
+        _download(domain, b)

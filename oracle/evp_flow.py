@@ -1,0 +1,309 @@
+"""TEST INFRASTRUCTURE ONLY: the reference's velocity-solver call flow executed with the CPU oracle.
+
+Walks the same sequence as the reference driver routines
+(/root/reference/src/shared/mpas_seaice_velocity_solver.F: seaice_init_velocity_solver :85,
+velocity_solver_pre_subcycle :613, subcycle_velocity_solver :2404, velocity_solver_post_subcycle
+:3360) over the pool containers of ``mpas_seaice_amd.pools`` and calls ``liboracle.so`` for every
+loop.  Parity status: see the header of evp_oracle.c ("parity unpinned" at bit level).
+
+``halo`` is an optional callable ``halo(domain, pool_name, field_names)`` standing for
+``mpas_dmpar_field_halo_exch``; a single full-sphere block needs none.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = ctypes.CDLL(path)
+    return _LIB
+
+
+def call(name, *args):
+    """Call an oracle routine: numpy arrays -> pointers, ints -> c_int, floats -> c_double."""
+    fn = getattr(lib(), name)
+    fn.restype = None
+    cargs = []
+    for a in args:
+        if isinstance(a, np.ndarray):
+            assert a.flags["F_CONTIGUOUS"] or a.flags["C_CONTIGUOUS"], name
+            cargs.append(ctypes.c_void_p(a.ctypes.data))
+        elif isinstance(a, (bool, np.bool_)):
+            cargs.append(ctypes.c_int(int(a)))
+        elif isinstance(a, (int, np.integer)):
+            cargs.append(ctypes.c_int(int(a)))
+        elif isinstance(a, (float, np.floating)):
+            cargs.append(ctypes.c_double(float(a)))
+        else:
+            raise TypeError(f"{name}: unsupported argument {type(a)}")
+    fn(*cargs)
+
+
+def num_threads():
+    f = lib().ora_num_threads
+    f.restype = ctypes.c_int
+    return int(f())
+
+
+def set_num_threads(n):
+    lib().ora_set_num_threads(ctypes.c_int(int(n)))
+
+
+RELATION = {"evp": 1, "evp_revised": 2, "linear": 3}
+
+
+# ------------------------------------------------------------------------------------ init
+def seaice_init_mesh_boundary(domain):
+    """interior_vertices of init_boundary (/root/reference/src/shared/mpas_seaice_mesh.F:372-488)."""
+    for b in domain.blocklist:
+        d = b.dimensions
+        m = b.structs["mesh"]
+        call("ora_interior_vertices", b.structs["boundary"]["interiorVertex"], d["nVerticesSolve"],
+             d["vertexDegree"], d["nCells"], m["cellsOnVertex"])
+    if halo_needed(domain):
+        domain.halo(domain, "boundary", ["interiorVertex"])
+
+
+def halo_needed(domain):
+    return getattr(domain, "halo", None) is not None and domain.configs["config_use_halo_exch"]
+
+
+def seaice_init_velocity_solver(domain):
+    cfg = domain.configs
+    st = domain.solver_state
+    seaice_init_mesh_boundary(domain)
+    for b in domain.blocklist:
+        vs = b.structs["velocity_solver"]
+        vs["dynamicsTimeStep"][0] = cfg["config_dt"] / float(cfg["config_dynamics_subcycle_number"])
+        vs["elasticTimeStep"][0] = vs["dynamicsTimeStep"][0] / float(cfg["config_elastic_subcycle_number"])
+    # seaice_init_evp, constitutive_relation.F:75-164
+    dvmin = 1.0e30
+    for b in domain.blocklist:
+        vs = b.structs["velocity_solver"]
+        st["dampingTimescale"] = 0.36 * vs["dynamicsTimeStep"][0]
+        dvmin = min(dvmin, float(b.structs["mesh"]["dvEdge"][:b.dimensions["nEdgesSolve"]].min()))
+    if getattr(domain, "allreduce_min", None) is not None:
+        dvmin = domain.allreduce_min(dvmin)
+    for b in domain.blocklist:
+        gamma = 0.25 * 1.0e11 * b.structs["velocity_solver"]["dynamicsTimeStep"][0]
+        st["numericalInertiaCoefficient"] = (2.0 * 0.86 * 5.5e-3 * gamma) / dvmin ** 2
+    for b in domain.blocklist:
+        d = b.dimensions
+        m = b.structs["mesh"]
+        vv = b.structs["velocity_variational"]
+        nC, nV, M, D = d["nCells"], d["nVertices"], d["maxEdges"], d["vertexDegree"]
+        rot = cfg["config_rotate_cartesian_grid"]
+        call("ora_metric_terms", vv["tanLatVertexRotatedOverRadius"], nV, m["xVertex"], m["yVertex"], m["zVertex"],
+             float(m["sphere_radius"]), rot, bool(cfg["config_include_metric_terms"] and m["on_a_sphere"]))
+        call("ora_cell_vertices_at_vertex", vv["cellVerticesAtVertex"], nV, D, M, nC, m["nEdgesOnCell"],
+             m["verticesOnCell"], m["cellsOnVertex"])
+        xl = np.zeros((M, nC), order="F")
+        yl = np.zeros((M, nC), order="F")
+        call("ora_calc_local_coords", xl, yl, nC, M, m["nEdgesOnCell"], m["verticesOnCell"], m["xVertex"],
+             m["yVertex"], m["zVertex"], m["xCell"], m["yCell"], m["zCell"], rot, bool(m["on_a_sphere"]))
+        assert cfg["config_variational_basis"] == "wachspress"
+        assert cfg["config_wachspress_integration_type"] == "dunavant" and cfg["config_wachspress_integration_order"] == 8
+        call("ora_wachspress_init", nC, M, m["nEdgesOnCell"], xl, yl, vv["basisGradientU"], vv["basisGradientV"],
+             vv["basisIntegralsU"], vv["basisIntegralsV"], vv["basisIntegralsMetric"])
+        call("ora_variational_denominator", vv["variationalDenominator"], nV, D, M, m["nEdgesOnCell"],
+             m["areaTriangle"], m["cellsOnVertex"], vv["cellVerticesAtVertex"], vv["basisIntegralsMetric"],
+             cfg["config_variational_denominator_type"] == "alternate")
+        b._xLocal, b._yLocal = xl, yl
+
+
+# ------------------------------------------------------------------------------------ run
+def _interp_c2v(b, vert, cell):
+    d = b.dimensions
+    m = b.structs["mesh"]
+    call("ora_interpolate_cell_to_vertex", vert, cell, d["nVerticesSolve"], d["vertexDegree"], m["cellsOnVertex"],
+         m["areaCell"])
+
+
+def velocity_solver_pre_subcycle(domain):
+    cfg = domain.configs
+    no_column = (not cfg["config_use_column_package"]) or (
+        cfg["config_use_column_package"] and not cfg["config_use_column_vertical_thermodynamics"])
+    ex = halo_needed(domain)
+    for b in domain.blocklist:
+        d = b.dimensions
+        tr, ta, ic = b.structs["tracers"], b.structs["tracers_aggregate"], b.structs["icestate"]
+        call("ora_aggregate_mass_and_area", d["nCells"], d["nCategories"], tr["iceAreaCategory"],
+             tr["iceVolumeCategory"], tr["snowVolumeCategory"], ta["iceAreaCell"], ta["iceVolumeCell"],
+             ta["snowVolumeCell"], ic["totalMassCell"])
+        if no_column:
+            ic["iceAreaCellInitial"][:] = ta["iceAreaCell"]
+    if ex:
+        domain.halo(domain, "icestate", ["iceAreaCellInitial", "totalMassCell"])
+    for b in domain.blocklist:
+        ic = b.structs["icestate"]
+        _interp_c2v(b, ic["iceAreaVertex"], ic["iceAreaCellInitial"])
+        _interp_c2v(b, ic["totalMassVertex"], ic["totalMassCell"])
+    if cfg["config_calc_velocity_masks"]:
+        for b in domain.blocklist:
+            d = b.dimensions
+            m, vs, ic, oc = b.structs["mesh"], b.structs["velocity_solver"], b.structs["icestate"], b.structs["ocean_coupling"]
+            call("ora_stress_calculation_mask", vs["solveStress"], d["nCells"], d["maxEdges"], m["nEdgesOnCell"],
+                 m["cellsOnCell"], ic["iceAreaCellInitial"], ic["totalMassCell"], oc["landIceMask"])
+            call("ora_velocity_calculation_mask", vs["solveVelocity"], d["nVerticesSolve"], d["nVertices"],
+                 b.structs["boundary"]["interiorVertex"], oc["landIceMaskVertex"], ic["iceAreaVertex"],
+                 ic["totalMassVertex"])
+    if ex:
+        domain.halo(domain, "velocity_solver", ["solveVelocity"])
+    for b in domain.blocklist:
+        d = b.dimensions
+        vs, oc = b.structs["velocity_solver"], b.structs["ocean_coupling"]
+        _interp_c2v(b, vs["uOceanVelocityVertex"], oc["uOceanVelocity"])
+        _interp_c2v(b, vs["vOceanVelocityVertex"], oc["vOceanVelocity"])
+        call("ora_new_ice_velocities", d["nVerticesSolve"], d["nVertices"] + 1, vs["solveVelocity"],
+             vs["solveVelocityPrevious"], vs["uVelocity"], vs["vVelocity"], vs["uVelocityInitial"],
+             vs["vVelocityInitial"], vs["uOceanVelocityVertex"], vs["vOceanVelocityVertex"],
+             vs["stressDivergenceU"], vs["stressDivergenceV"], vs["oceanStressU"], vs["oceanStressV"])
+    if ex:
+        domain.halo(domain, "velocity_solver", ["uVelocity", "vVelocity"])
+    for b in domain.blocklist:
+        d = b.dimensions
+        vs, ta = b.structs["velocity_solver"], b.structs["tracers_aggregate"]
+        assert no_column, "colpkg_ice_strength is outside the hot path"
+        call("ora_ice_strength_hibler", d["nCellsSolve"], vs["solveStress"], ta["iceAreaCell"], ta["iceVolumeCell"],
+             vs["icePressure"])
+    if ex:
+        domain.halo(domain, "velocity_solver", ["icePressure"])
+    for b in domain.blocklist:
+        d = b.dimensions
+        vs, at, ta = b.structs["velocity_solver"], b.structs["atmos_coupling"], b.structs["tracers_aggregate"]
+        if no_column:
+            call("ora_constant_air_stress", d["nCellsSolve"], at["uAirVelocity"], at["vAirVelocity"], at["airDensity"],
+                 ta["iceAreaCell"], vs["airStressCellU"], vs["airStressCellV"])
+        if not cfg["config_use_air_stress"]:
+            vs["airStressCellU"][:] = 0.0
+            vs["airStressCellV"][:] = 0.0
+    if ex:
+        domain.halo(domain, "velocity_solver", ["airStressCellU", "airStressCellV"])
+    for b in domain.blocklist:
+        d = b.dimensions
+        m, vs, ic, oc = b.structs["mesh"], b.structs["velocity_solver"], b.structs["icestate"], b.structs["ocean_coupling"]
+        _interp_c2v(b, vs["airStressVertexU"], vs["airStressCellU"])
+        _interp_c2v(b, vs["airStressVertexV"], vs["airStressCellV"])
+        call("ora_coriolis_force_coefficient", d["nVerticesSolve"], ic["totalMassVertex"], m["fVertex"],
+             vs["totalMassVertexfVertex"])
+        call("ora_ocean_stress", d["nVerticesSolve"], d["nVertices"] + 1, cfg["config_use_ocean_stress"],
+             vs["solveVelocity"], vs["uOceanVelocityVertex"], vs["vOceanVelocityVertex"], m["fVertex"],
+             vs["oceanStressU"], vs["oceanStressV"])
+    mode = 0
+    if cfg["config_use_surface_tilt"]:
+        mode = 1 if cfg["config_geostrophic_surface_tilt"] else 2
+    if mode == 2 and ex:
+        domain.halo(domain, "ocean_coupling", ["seaSurfaceTiltU", "seaSurfaceTiltV"])
+    for b in domain.blocklist:
+        d = b.dimensions
+        m, vs, ic, oc = b.structs["mesh"], b.structs["velocity_solver"], b.structs["icestate"], b.structs["ocean_coupling"]
+        if mode == 2:
+            _interp_c2v(b, vs["seaSurfaceTiltVertexU"], oc["seaSurfaceTiltU"])
+            _interp_c2v(b, vs["seaSurfaceTiltVertexV"], oc["seaSurfaceTiltV"])
+        call("ora_surface_tilt", d["nVerticesSolve"], d["nVertices"] + 1, mode, vs["solveVelocity"],
+             ic["totalMassVertex"], m["fVertex"], vs["uOceanVelocityVertex"], vs["vOceanVelocityVertex"],
+             vs["seaSurfaceTiltVertexU"], vs["seaSurfaceTiltVertexV"], vs["surfaceTiltForceU"],
+             vs["surfaceTiltForceV"])
+        vv = b.structs["velocity_variational"]
+        call("ora_init_subcycle_variables", d["nCells"] + 1, d["nVerticesSolve"], d["nVertices"] + 1, d["maxEdges"],
+             _pad_mask(vs["solveStress"]), vs["solveVelocity"], vs["stressDivergenceU"], vs["stressDivergenceV"],
+             vs["uVelocity"], vs["vVelocity"], vs["oceanStressCoeff"], vv["strain11"], vv["strain22"],
+             vv["strain12"], vv["stress11"], vv["stress22"], vv["stress12"])
+
+
+def _pad_mask(a):
+    return a
+
+
+def _subcycle_args(domain, b):
+    cfg, st = domain.configs, domain.solver_state
+    d = b.dimensions
+    m, vs, vv, ic = b.structs["mesh"], b.structs["velocity_solver"], b.structs["velocity_variational"], b.structs["icestate"]
+    return (d["nCells"], d["nVerticesSolve"], d["nVertices"] + 1, d["maxEdges"], d["vertexDegree"],
+            m["nEdgesOnCell"], m["verticesOnCell"], m["cellsOnVertex"], vv["cellVerticesAtVertex"],
+            vs["solveStress"], vs["solveVelocity"], vv["basisGradientU"], vv["basisGradientV"],
+            vv["basisIntegralsU"], vv["basisIntegralsV"], vv["basisIntegralsMetric"], vv["variationalDenominator"],
+            vv["tanLatVertexRotatedOverRadius"], vs["icePressure"], ic["totalMassVertex"],
+            vs["totalMassVertexfVertex"], ic["iceAreaVertex"], vs["airStressVertexU"], vs["airStressVertexV"],
+            vs["surfaceTiltForceU"], vs["surfaceTiltForceV"], vs["oceanStressU"], vs["oceanStressV"],
+            vs["uOceanVelocityVertex"], vs["vOceanVelocityVertex"], vs["uVelocityInitial"], vs["vVelocityInitial"],
+            vs["uVelocity"], vs["vVelocity"], vv["strain11"], vv["strain22"], vv["strain12"], vv["stress11"],
+            vv["stress22"], vv["stress12"], vv["replacementPressure"], vs["stressDivergenceU"],
+            vs["stressDivergenceV"], vs["oceanStressCoeff"], float(vs["elasticTimeStep"][0]),
+            float(vs["dynamicsTimeStep"][0]), float(st["dampingTimescale"]),
+            float(st["numericalInertiaCoefficient"]), RELATION[cfg["config_constitutive_relation_type"]],
+            bool(cfg["config_use_ocean_stress"]), cfg["config_ocean_stress_type"] == "quadratic")
+
+
+def subcycle_velocity_solver(domain, n_subcycles=None):
+    cfg = domain.configs
+    n = cfg["config_elastic_subcycle_number"] if n_subcycles is None else n_subcycles
+    if not halo_needed(domain):
+        for b in domain.blocklist:
+            call("ora_evp_subcycle_loop", n, *_subcycle_args(domain, b))
+        return
+    for _ in range(n):
+        for b in domain.blocklist:
+            call("ora_evp_subcycle_loop", 1, *_subcycle_args(domain, b))
+        domain.halo(domain, "velocity_solver", ["uVelocity", "vVelocity"])
+
+
+def velocity_solver_post_subcycle(domain):
+    cfg = domain.configs
+    for b in domain.blocklist:
+        d = b.dimensions
+        m, vs, vv, ic = b.structs["mesh"], b.structs["velocity_solver"], b.structs["velocity_variational"], b.structs["icestate"]
+        rg = b.structs["ridging"]
+        call("ora_final_divergence_shear", d["nCells"], d["maxEdges"], m["nEdgesOnCell"], vs["solveStress"],
+             vv["strain11"], vv["strain22"], vv["strain12"], vs["divergence"], vs["shear"],
+             bool(cfg["config_use_column_package"]), rg["ridgeConvergence"], rg["ridgeShear"])
+        call("ora_principal_stresses", d["nCellsSolve"], d["maxEdges"], m["nEdgesOnCell"], vv["stress11"],
+             vv["stress22"], vv["stress12"], vv["replacementPressure"], vv["principalStress1"],
+             vv["principalStress2"])
+        call("ora_ocean_stress_coefficient", d["nVerticesSolve"], d["nVertices"] + 1, cfg["config_use_ocean_stress"],
+             cfg["config_ocean_stress_type"] == "quadratic", vs["solveVelocity"], vs["oceanStressCoeff"],
+             vs["uOceanVelocityVertex"], vs["vOceanVelocityVertex"], vs["uVelocity"], vs["vVelocity"],
+             ic["iceAreaVertex"])
+        call("ora_ocean_stress_final_vertex", d["nVerticesSolve"], d["nVertices"] + 1, cfg["config_use_ocean_stress"],
+             vs["solveVelocity"], vs["oceanStressCoeff"], vs["uOceanVelocityVertex"], vs["vOceanVelocityVertex"],
+             vs["uVelocity"], vs["vVelocity"], m["fVertex"], ic["iceAreaVertex"], vs["oceanStressU"],
+             vs["oceanStressV"])
+    if cfg["config_use_ocean_stress"]:
+        if halo_needed(domain):
+            domain.halo(domain, "velocity_solver", ["oceanStressU", "oceanStressV"])
+        for b in domain.blocklist:
+            d = b.dimensions
+            m, vs, ic = b.structs["mesh"], b.structs["velocity_solver"], b.structs["icestate"]
+            iv = b.structs["boundary"]["interiorVertex"]
+            for cellf, vertf in (("oceanStressCellU", "oceanStressU"), ("oceanStressCellV", "oceanStressV")):
+                call("ora_interpolate_vertex_to_cell", vs[cellf], vs[vertf], d["nCellsSolve"], d["maxEdges"],
+                     m["nEdgesOnCell"], m["verticesOnCell"], m["areaTriangle"], iv)
+            call("ora_ocean_stress_final_rescale", d["nVerticesSolve"], vs["solveVelocity"], ic["iceAreaVertex"],
+                 vs["oceanStressU"], vs["oceanStressV"])
+    else:
+        for b in domain.blocklist:
+            b.structs["velocity_solver"]["oceanStressCellU"][:] = 0.0
+            b.structs["velocity_solver"]["oceanStressCellV"][:] = 0.0
+
+
+def seaice_run_velocity_solver(domain, clock=None):
+    if domain.configs["config_use_velocity_solver"]:
+        velocity_solver_pre_subcycle(domain)
+        subcycle_velocity_solver(domain)
+        velocity_solver_post_subcycle(domain)

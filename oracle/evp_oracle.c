@@ -1,0 +1,1070 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- CPU restatement (oracle) of the reference's EVP velocity solver.
+ *
+ * Nothing in the product path may call into this file: only tests/, the smoke check and the
+ * cpu_baseline leg of bench.py use it, as the checker / reported baseline.
+ *
+ * PARITY STATUS: "parity unpinned" at the bit level.  The reference ships no golden vectors
+ * for this path and its Fortran cannot be built here (every source file uses the MPAS framework
+ * modules mpass_derived_types / mpass_pool_routines / ..., which are not in the repository).
+ * This restatement is pinned by (i) the analytic known-answer cases the reference's own test
+ * scripts define (spherical-harmonic strain field, planar linear / sinusoid fields), and (ii)
+ * invariants of the scheme (partition of unity, exactness for linear fields, area partition).
+ *
+ * Every routine follows the arithmetic of the reference routine cited above it, statement by
+ * statement, in the same evaluation order.  Arrays use the reference's Fortran layout
+ * (column-major, first index fastest) and its 1-based connectivity with the nX+1 sentinel.
+ * Build with -ffp-contract=off so each source-level operation rounds once.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* 1-based Fortran-style accessors */
+#define IX2(i, c, M) ((size_t)((c) - 1) * (size_t)(M) + (size_t)((i) - 1))
+#define IX3(i, j, c, M) (((size_t)((c) - 1) * (size_t)(M) + (size_t)((j) - 1)) * (size_t)(M) + (size_t)((i) - 1))
+
+/* constants: src/shared/mpas_seaice_velocity_solver.F:61-65,
+ * src/shared/mpas_seaice_velocity_solver_constitutive_relation.F:41-47,
+ * src/column/constants/cice/ice_constants_colpkg.F90 (rhoi, rhos, rhow, dragio, Pstar, Cstar) */
+static const double sinOceanTurningAngle = 0.0;
+static const double cosOceanTurningAngle = 1.0;
+static const double seaiceAreaMinimum = 0.001;
+static const double seaiceMassMinimum = 0.01;
+static const double eccentricitySquared = 4.0;
+static const double puny = 1.0e-11;
+static const double seaiceDensityIce = 917.0;
+static const double seaiceDensitySnow = 330.0;
+static const double seaiceDensitySeaWater = 1026.0;
+static const double seaiceIceOceanDragCoefficient = 0.00536;
+static const double seaiceIceStrengthConstantHiblerP = 2.75e4;
+static const double seaiceIceStrengthConstantHiblerC = 20.0;
+static const double seaiceGravity = 9.80616;
+
+int ora_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void ora_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+static double sign1(double x) { return copysign(1.0, x); } /* Fortran sign(1.0, x) */
+
+static int wrapped_index(int input, int n)
+{ /* variational_shared.F:372-385, modulo(input-1,n)+1 */
+    int m = (input - 1) % n;
+    if (m < 0) m += n;
+    return m + 1;
+}
+
+/* ------------------------------------------------------------------ mesh helpers */
+
+/* mpas_seaice_mesh.F:2350-2381 */
+static void grid_rotation_forward(double *xp, double *yp, double *zp, double x, double y, double z, int rotate)
+{
+    if (rotate) {
+        *xp = -z;
+        *yp = y;
+        *zp = x;
+    } else {
+        *xp = x;
+        *yp = y;
+        *zp = z;
+    }
+}
+
+/* mpas_seaice_mesh.F:2272-2332 */
+static void local_east_north(double xP, double yP, double zP, double e[3], double n[3])
+{
+    double mag;
+    e[0] = -yP;
+    e[1] = xP;
+    e[2] = 0.0;
+    mag = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    e[0] = e[0] / mag;
+    e[1] = e[1] / mag;
+    e[2] = e[2] / mag;
+    if (zP != 0.0) {
+        n[0] = -xP;
+        n[1] = -yP;
+        n[2] = (xP * xP + yP * yP) / zP;
+        mag = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        n[0] = n[0] / mag;
+        n[1] = n[1] / mag;
+        n[2] = n[2] / mag;
+        if (zP < 0.0) {
+            n[0] = -n[0];
+            n[1] = -n[1];
+            n[2] = -n[2];
+        }
+    } else {
+        n[0] = 0.0;
+        n[1] = 0.0;
+        n[2] = 1.0;
+    }
+}
+
+/* mpas_seaice_velocity_solver_variational_shared.F:42-279 (+ mesh.F:2021-2061, 1758-1769) */
+void ora_calc_local_coords(double *xLocal, double *yLocal, int nCells, int maxEdges, const int *nEdgesOnCell,
+                           const int *verticesOnCell, const double *xVertex, const double *yVertex,
+                           const double *zVertex, const double *xCell, const double *yCell, const double *zCell,
+                           int rotate, int onASphere)
+{
+    for (int c = 1; c <= nCells; c++) {
+        if (onASphere) {
+            double xc, yc, zc, e[3], n[3];
+            grid_rotation_forward(&xc, &yc, &zc, xCell[c - 1], yCell[c - 1], zCell[c - 1], rotate);
+            for (int i = 1; i <= nEdgesOnCell[c - 1]; i++) {
+                int v = verticesOnCell[IX2(i, c, maxEdges)];
+                double p[3];
+                grid_rotation_forward(&p[0], &p[1], &p[2], xVertex[v - 1], yVertex[v - 1], zVertex[v - 1], rotate);
+                local_east_north(xc, yc, zc, e, n);
+                xLocal[IX2(i, c, maxEdges)] = p[0] * e[0] + p[1] * e[1] + p[2] * e[2];
+                yLocal[IX2(i, c, maxEdges)] = p[0] * n[0] + p[1] * n[1] + p[2] * n[2];
+            }
+        } else {
+            for (int i = 1; i <= nEdgesOnCell[c - 1]; i++) {
+                int v = verticesOnCell[IX2(i, c, maxEdges)];
+                xLocal[IX2(i, c, maxEdges)] = xVertex[v - 1] - xCell[c - 1];
+                yLocal[IX2(i, c, maxEdges)] = yVertex[v - 1] - yCell[c - 1];
+            }
+        }
+    }
+}
+
+/* variational_shared.F:293-358 */
+void ora_metric_terms(double *tanLatVertexRotatedOverRadius, int nVertices, const double *xVertex,
+                      const double *yVertex, const double *zVertex, double sphereRadius, int rotate,
+                      int includeMetricTerms)
+{
+    for (int v = 0; v < nVertices; v++) {
+        if (includeMetricTerms) {
+            double xr, yr, zr;
+            grid_rotation_forward(&xr, &yr, &zr, xVertex[v], yVertex[v], zVertex[v], rotate);
+            double lat = asin(zr / sphereRadius);
+            tanLatVertexRotatedOverRadius[v] = tan(lat) / sphereRadius;
+        } else {
+            tanLatVertexRotatedOverRadius[v] = 0.0;
+        }
+    }
+}
+
+/* mpas_seaice_mesh.F:632-685 */
+void ora_cell_vertices_at_vertex(int *cellVerticesAtVertex, int nVertices, int vertexDegree, int maxEdges,
+                                 int nCells, const int *nEdgesOnCell, const int *verticesOnCell,
+                                 const int *cellsOnVertex)
+{
+    for (int v = 1; v <= nVertices; v++) {
+        for (int k = 1; k <= vertexDegree; k++) {
+            cellVerticesAtVertex[IX2(k, v, vertexDegree)] = 0;
+            int c = cellsOnVertex[IX2(k, v, vertexDegree)];
+            if (c < 1 || c > nCells) continue; /* the reference reads the sentinel slot (nEdgesOnCell = 0 there) */
+            for (int i = 1; i <= nEdgesOnCell[c - 1]; i++) {
+                if (verticesOnCell[IX2(i, c, maxEdges)] == v) cellVerticesAtVertex[IX2(k, v, vertexDegree)] = i;
+            }
+        }
+    }
+}
+
+/* mpas_seaice_mesh.F:423-488 */
+void ora_interior_vertices(int *interiorVertex, int nVerticesSolve, int vertexDegree, int nCells,
+                           const int *cellsOnVertex)
+{
+    for (int v = 1; v <= nVerticesSolve; v++) {
+        int n = 0;
+        for (int k = 1; k <= vertexDegree; k++) {
+            int c = cellsOnVertex[IX2(k, v, vertexDegree)];
+            if (c >= 1 && c <= nCells) n++;
+        }
+        interiorVertex[v - 1] = (n == vertexDegree) ? 1 : 0;
+    }
+}
+
+/* ------------------------------------------------------------------ Wachspress basis */
+
+/* D. A. Dunavant (1985) degree-8 rule, 16 points, to the 14 digits the reference carries
+ * (mpas_seaice_velocity_solver_wachspress.F:1573-1597); normalisation factor 2 (:1426). */
+#define NQ 16
+static const double dunU[NQ] = {0.33333333333333, 0.45929258829272, 0.45929258829272, 0.08141482341455,
+                                0.17056930775176, 0.17056930775176, 0.65886138449648, 0.05054722831703,
+                                0.05054722831703, 0.89890554336594, 0.26311282963464, 0.72849239295540,
+                                0.00839477740996, 0.72849239295540, 0.26311282963464, 0.00839477740996};
+static const double dunV[NQ] = {0.33333333333333, 0.45929258829272, 0.08141482341455, 0.45929258829272,
+                                0.17056930775176, 0.65886138449648, 0.17056930775176, 0.05054722831703,
+                                0.89890554336594, 0.05054722831703, 0.72849239295540, 0.00839477740996,
+                                0.26311282963464, 0.26311282963464, 0.00839477740996, 0.72849239295540};
+static const double dunW[NQ] = {0.14431560767779, 0.09509163426728, 0.09509163426728, 0.09509163426728,
+                                0.10321737053472, 0.10321737053472, 0.10321737053472, 0.03245849762320,
+                                0.03245849762320, 0.03245849762320, 0.02723031417443, 0.02723031417443,
+                                0.02723031417443, 0.02723031417443, 0.02723031417443, 0.02723031417443};
+static const double dunNorm = 2.0;
+
+#define MAXE 16
+
+typedef struct {
+    int n;
+    double A[MAXE + 1], B[MAXE + 1], kappa[MAXE + 1]; /* 1-based */
+    int nSub[MAXE + 1];
+    int sub[MAXE + 1][MAXE + 1];
+} wach_cell;
+
+/* wachspress.F:535-614 (coefficients) and :628-668 (index subsets) */
+static void wach_setup(wach_cell *w, int n, const double *x, const double *y /* 1-based */)
+{
+    w->n = n;
+    for (int i = 1; i <= n; i++) {
+        int i1 = i - 1, i2 = i;
+        if (i1 < 1) i1 = i1 + n;
+        w->A[i] = (y[i2] - y[i1]) / (x[i1] * y[i2] - x[i2] * y[i1]);
+        w->B[i] = (x[i1] - x[i2]) / (x[i1] * y[i2] - x[i2] * y[i1]);
+    }
+    w->kappa[1] = 1.0;
+    for (int j = 2; j <= n; j++) {
+        int i0 = j - 1, i1 = j, i2 = j + 1;
+        if (i2 > n) i2 = i2 - n;
+        w->kappa[j] = w->kappa[j - 1] * (w->A[i2] * (x[i0] - x[i1]) + w->B[i2] * (y[i0] - y[i1])) /
+                      (w->A[i0] * (x[i1] - x[i0]) + w->B[i0] * (y[i1] - y[i0]));
+    }
+    for (int j = 1; j <= n; j++) {
+        int i1 = j, i2 = wrapped_index(j + 1, n);
+        w->nSub[j] = 0;
+        for (int k = 1; k <= n; k++) {
+            if (k != i1 && k != i2) {
+                w->nSub[j]++;
+                w->sub[j][w->nSub[j]] = k;
+            }
+        }
+    }
+}
+
+/* wachspress.F:1049-1069 */
+static double wach_edge(const wach_cell *w, int k, double x, double y) { return 1.0 - w->A[k] * x - w->B[k] * y; }
+
+/* wachspress.F:864-925 */
+static double wach_numerator(const wach_cell *w, int j, double x, double y)
+{
+    double num = 1.0;
+    for (int k = 1; k <= w->nSub[j]; k++) num = num * wach_edge(w, w->sub[j][k], x, y);
+    return num * w->kappa[j];
+}
+
+/* wachspress.F:939-1035 */
+static void wach_numerator_derivative(const wach_cell *w, int j, double x, double y, double *dU, double *dV)
+{
+    double sumU = 0.0, sumV = 0.0;
+    for (int k = 1; k <= w->nSub[j]; k++) {
+        double pU = 1.0, pV = 1.0;
+        for (int l = 1; l <= k - 1; l++) {
+            double e = wach_edge(w, w->sub[j][l], x, y);
+            pU = pU * e;
+            pV = pV * e;
+        }
+        pU = pU * (-w->A[w->sub[j][k]]);
+        pV = pV * (-w->B[w->sub[j][k]]);
+        for (int l = k + 1; l <= w->nSub[j]; l++) {
+            double e = wach_edge(w, w->sub[j][l], x, y);
+            pU = pU * e;
+            pV = pV * e;
+        }
+        sumU = sumU + pU;
+        sumV = sumV + pV;
+    }
+    *dU = sumU * w->kappa[j];
+    *dV = sumV * w->kappa[j];
+}
+
+/* wachspress.F:682-749: basis function i at (x,y) */
+static double wach_basis(const wach_cell *w, int i, double x, double y)
+{
+    double den = 0.0, numi = 0.0;
+    for (int j = 1; j <= w->n; j++) {
+        double num = wach_numerator(w, j, x, y);
+        den = den + num;
+        if (j == i) numi = num;
+    }
+    return numi / den;
+}
+
+/* wachspress.F:763-850: gradient of basis function i at (x,y) */
+static void wach_basis_derivative(const wach_cell *w, int i, double x, double y, double *dU, double *dV)
+{
+    double den = 0.0, sU = 0.0, sV = 0.0, numi = 0.0, dUi = 0.0, dVi = 0.0;
+    for (int j = 1; j <= w->n; j++) {
+        double num = wach_numerator(w, j, x, y);
+        den = den + num;
+        double du, dv;
+        wach_numerator_derivative(w, j, x, y, &du, &dv);
+        sU = sU + du;
+        sV = sV + dv;
+        if (j == i) {
+            numi = num;
+            dUi = du;
+            dVi = dv;
+        }
+    }
+    *dU = dUi / den - (numi / (den * den)) * sU;
+    *dV = dVi / den - (numi / (den * den)) * sV;
+}
+
+/* seaice_init_velocity_solver_wachspress, wachspress.F:46-161 with calculate_wachspress_derivatives
+ * (:1083-1206) and integrate_wachspress / integrate_wachspress_polygon (:179-467), Dunavant order 8. */
+void ora_wachspress_init(int nCells, int maxEdges, const int *nEdgesOnCell, const double *xLocal,
+                         const double *yLocal, double *basisGradientU, double *basisGradientV,
+                         double *basisIntegralsU, double *basisIntegralsV, double *basisIntegralsMetric)
+{
+    size_t mm = (size_t)maxEdges * (size_t)maxEdges;
+    memset(basisGradientU, 0, sizeof(double) * mm * (size_t)nCells);
+    memset(basisGradientV, 0, sizeof(double) * mm * (size_t)nCells);
+    memset(basisIntegralsU, 0, sizeof(double) * mm * (size_t)nCells);
+    memset(basisIntegralsV, 0, sizeof(double) * mm * (size_t)nCells);
+    memset(basisIntegralsMetric, 0, sizeof(double) * mm * (size_t)nCells);
+#pragma omp parallel for schedule(static)
+    for (int c = 1; c <= nCells; c++) {
+        int n = nEdgesOnCell[c - 1];
+        double x[MAXE + 1], y[MAXE + 1];
+        wach_cell w;
+        for (int i = 1; i <= n; i++) {
+            x[i] = xLocal[IX2(i, c, maxEdges)];
+            y[i] = yLocal[IX2(i, c, maxEdges)];
+        }
+        wach_setup(&w, n, x, y);
+        /* gradients at the cell's own vertices, kept only at the basis vertex and its two neighbours */
+        for (int ib = 1; ib <= n; ib++) {
+            int gs[3] = {ib, wrapped_index(ib - 1, n), wrapped_index(ib + 1, n)};
+            for (int q = 0; q < 3; q++) {
+                int ig = gs[q];
+                double du, dv;
+                wach_basis_derivative(&w, ib, x[ig], y[ig], &du, &dv);
+                basisGradientU[IX3(ib, ig, c, maxEdges)] = du;
+                basisGradientV[IX3(ib, ig, c, maxEdges)] = dv;
+            }
+        }
+        /* integrals: sub-triangles (centre, vertex t, vertex t+1) */
+        double N[MAXE + 1][MAXE + 1][NQ], dNu[MAXE + 1][MAXE + 1][NQ], dNv[MAXE + 1][MAXE + 1][NQ];
+        double jac[MAXE + 1];
+        for (int t = 1; t <= n; t++) {
+            int i1 = t, i2 = wrapped_index(t + 1, n);
+            /* get_triangle_mapping (:485-517) with (x1,y1)=(1,0), (x2,y2)=(0,1) */
+            double x1 = 1.0, y1 = 0.0, x2 = 0.0, y2 = 1.0;
+            double u1 = x[i1], v1 = y[i1], u2 = x[i2], v2 = y[i2];
+            double m11 = (u2 * y1 - u1 * y2) / (x2 * y1 - x1 * y2);
+            double m12 = (u1 * x2 - u2 * x1) / (y1 * x2 - y2 * x1);
+            double m21 = (v2 * y1 - v1 * y2) / (x2 * y1 - x1 * y2);
+            double m22 = (v1 * x2 - v2 * x1) / (y1 * x2 - y2 * x1);
+            jac[t] = m11 * m22 - m12 * m21;
+            for (int p = 0; p < NQ; p++) {
+                double px = m11 * dunU[p] + m12 * dunV[p];
+                double py = m21 * dunU[p] + m22 * dunV[p];
+                for (int i = 1; i <= n; i++) {
+                    N[t][i][p] = wach_basis(&w, i, px, py);
+                    wach_basis_derivative(&w, i, px, py, &dNu[t][i][p], &dNv[t][i][p]);
+                }
+            }
+        }
+        for (int iv = 1; iv <= n; iv++) {
+            for (int is = 1; is <= n; is++) {
+                double SU = 0.0, SV = 0.0, SM = 0.0;
+                for (int t = 1; t <= n; t++) {
+                    double sU = 0.0, sV = 0.0, sM = 0.0;
+                    for (int p = 0; p < NQ; p++) {
+                        double tmp = jac[t] * dunW[p] * N[t][is][p];
+                        sU = sU + tmp * dNu[t][iv][p];
+                        sV = sV + tmp * dNv[t][iv][p];
+                        sM = sM + tmp * N[t][iv][p];
+                    }
+                    SU = SU + sU / dunNorm;
+                    SV = SV + sV / dunNorm;
+                    SM = SM + sM / dunNorm;
+                }
+                basisIntegralsU[IX3(is, iv, c, maxEdges)] = SU;
+                basisIntegralsV[IX3(is, iv, c, maxEdges)] = SV;
+                basisIntegralsMetric[IX3(is, iv, c, maxEdges)] = SM;
+            }
+        }
+    }
+}
+
+/* variational.F:358-445 */
+void ora_variational_denominator(double *variationalDenominator, int nVertices, int vertexDegree, int maxEdges,
+                                 const int *nEdgesOnCell, const double *areaTriangle, const int *cellsOnVertex,
+                                 const int *cellVerticesAtVertex, const double *basisIntegralsMetric,
+                                 int alternate)
+{
+    for (int v = 1; v <= nVertices; v++) {
+        if (alternate) {
+            double d = 0.0;
+            for (int k = 1; k <= vertexDegree; k++) {
+                int c = cellsOnVertex[IX2(k, v, vertexDegree)];
+                int j = cellVerticesAtVertex[IX2(k, v, vertexDegree)];
+                if (j < 1) continue;
+                for (int s = 1; s <= nEdgesOnCell[c - 1]; s++) d = d + basisIntegralsMetric[IX3(s, j, c, maxEdges)];
+            }
+            variationalDenominator[v - 1] = d;
+        } else {
+            variationalDenominator[v - 1] = areaTriangle[v - 1];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ interpolation */
+
+/* mpas_seaice_mesh.F:2760-2892 (the active "cell area" branch :2835-2851).  The reference reads
+ * areaCell/variableCell at the nCells+1 sentinel slot for rim vertices; callers here pass arrays
+ * with that extra slot. */
+void ora_interpolate_cell_to_vertex(double *variableVertex, const double *variableCell, int nVerticesSolve,
+                                    int vertexDegree, const int *cellsOnVertex, const double *areaCell)
+{
+    for (int v = 1; v <= nVerticesSolve; v++) {
+        double acc = 0.0, totalArea = 0.0;
+        for (int k = 1; k <= vertexDegree; k++) {
+            int c = cellsOnVertex[IX2(k, v, vertexDegree)];
+            acc = acc + areaCell[c - 1] * variableCell[c - 1];
+            totalArea = totalArea + areaCell[c - 1];
+        }
+        variableVertex[v - 1] = acc / totalArea;
+    }
+}
+
+/* mpas_seaice_mesh.F:2906-2976 */
+void ora_interpolate_vertex_to_cell(double *variableCell, const double *variableVertex, int nCellsSolve,
+                                    int maxEdges, const int *nEdgesOnCell, const int *verticesOnCell,
+                                    const double *areaTriangle, const int *interiorVertex)
+{
+    for (int c = 1; c <= nCellsSolve; c++) {
+        double acc = 0.0, totalArea = 0.0;
+        for (int i = 1; i <= nEdgesOnCell[c - 1]; i++) {
+            int v = verticesOnCell[IX2(i, c, maxEdges)];
+            acc = acc + areaTriangle[v - 1] * variableVertex[v - 1] * (double)(float)interiorVertex[v - 1];
+            totalArea = totalArea + areaTriangle[v - 1] * (double)(float)interiorVertex[v - 1];
+        }
+        if (totalArea > 0.0) acc = acc / totalArea;
+        variableCell[c - 1] = acc;
+    }
+}
+
+/* ------------------------------------------------------------------ pre-subcycle */
+
+/* velocity_solver.F:685-752.  Category arrays are (ONE, nCategories, nCells). */
+void ora_aggregate_mass_and_area(int nCells, int nCategories, const double *iceAreaCategory,
+                                 const double *iceVolumeCategory, const double *snowVolumeCategory,
+                                 double *iceAreaCell, double *iceVolumeCell, double *snowVolumeCell,
+                                 double *totalMassCell)
+{
+    for (int c = 0; c < nCells; c++) {
+        double a = 0.0, vi = 0.0, vs = 0.0;
+        for (int k = 0; k < nCategories; k++) {
+            a = a + iceAreaCategory[(size_t)c * nCategories + k];
+            vi = vi + iceVolumeCategory[(size_t)c * nCategories + k];
+            vs = vs + snowVolumeCategory[(size_t)c * nCategories + k];
+        }
+        iceAreaCell[c] = a;
+        iceVolumeCell[c] = vi;
+        snowVolumeCell[c] = vs;
+        totalMassCell[c] = vi * seaiceDensityIce + vs * seaiceDensitySnow;
+    }
+}
+
+/* velocity_solver.F:961-1059; arrays carry the nCells+1 sentinel slot (mask there must be "no ice") */
+void ora_stress_calculation_mask(int *solveStress, int nCells, int maxEdges, const int *nEdgesOnCell,
+                                 const int *cellsOnCell, const double *iceAreaCellInitial,
+                                 const double *totalMassCell, const int *landIceMask)
+{
+    for (int c = 1; c <= nCells; c++) {
+        solveStress[c - 1] = 0;
+        if (iceAreaCellInitial[c - 1] > seaiceAreaMinimum && totalMassCell[c - 1] > seaiceMassMinimum &&
+            landIceMask[c - 1] == 0) {
+            solveStress[c - 1] = 1;
+        } else {
+            for (int i = 1; i <= nEdgesOnCell[c - 1]; i++) {
+                int nb = cellsOnCell[IX2(i, c, maxEdges)];
+                if (iceAreaCellInitial[nb - 1] > seaiceAreaMinimum && totalMassCell[nb - 1] > seaiceMassMinimum &&
+                    landIceMask[nb - 1] == 0) {
+                    solveStress[c - 1] = 1;
+                    break;
+                }
+            }
+        }
+    }
+}
+
+/* velocity_solver.F:1073-1150 */
+void ora_velocity_calculation_mask(int *solveVelocity, int nVerticesSolve, int nVertices,
+                                   const int *interiorVertex, const int *landIceMaskVertex,
+                                   const double *iceAreaVertex, const double *totalMassVertex)
+{
+    for (int v = 0; v < nVerticesSolve; v++) {
+        solveVelocity[v] = 0;
+        if (interiorVertex[v] == 1 && landIceMaskVertex[v] == 0 && iceAreaVertex[v] > seaiceAreaMinimum &&
+            totalMassVertex[v] > seaiceMassMinimum)
+            solveVelocity[v] = 1;
+    }
+    for (int v = nVerticesSolve; v < nVertices; v++) solveVelocity[v] = 0;
+}
+
+/* velocity_solver.F:1249-1277 (after the two ocean-velocity interpolations) */
+void ora_new_ice_velocities(int nVerticesSolve, int nVertices, const int *solveVelocity, int *solveVelocityPrevious,
+                            double *uVelocity, double *vVelocity, double *uVelocityInitial,
+                            double *vVelocityInitial, const double *uOceanVelocityVertex,
+                            const double *vOceanVelocityVertex, double *stressDivergenceU,
+                            double *stressDivergenceV, double *oceanStressU, double *oceanStressV)
+{
+    for (int v = 0; v < nVerticesSolve; v++) {
+        if (solveVelocity[v] == 1) {
+            if (solveVelocityPrevious[v] == 0) {
+                uVelocity[v] = uOceanVelocityVertex[v];
+                vVelocity[v] = vOceanVelocityVertex[v];
+            }
+        } else {
+            uVelocity[v] = 0.0;
+            vVelocity[v] = 0.0;
+            stressDivergenceU[v] = 0.0;
+            stressDivergenceV[v] = 0.0;
+            oceanStressU[v] = 0.0;
+            oceanStressV[v] = 0.0;
+        }
+    }
+    for (int v = 0; v < nVertices; v++) {
+        solveVelocityPrevious[v] = solveVelocity[v];
+        uVelocityInitial[v] = uVelocity[v];
+        vVelocityInitial[v] = vVelocity[v];
+    }
+}
+
+/* velocity_solver.F:1419-1435 (Hibler strength, the branch taken without the column package) */
+void ora_ice_strength_hibler(int nCellsSolve, const int *solveStress, const double *iceAreaCell,
+                             const double *iceVolumeCell, double *icePressure)
+{
+    for (int c = 0; c < nCellsSolve; c++) {
+        if (solveStress[c] == 1)
+            icePressure[c] = seaiceIceStrengthConstantHiblerP * iceVolumeCell[c] *
+                             exp(-seaiceIceStrengthConstantHiblerC * (1.0 - iceAreaCell[c]));
+        else
+            icePressure[c] = 0.0;
+    }
+}
+
+/* velocity_solver.F:1665-1728 */
+void ora_constant_air_stress(int nCellsSolve, const double *uAirVelocity, const double *vAirVelocity,
+                             const double *airDensity, const double *iceAreaCell, double *airStressCellU,
+                             double *airStressCellV)
+{
+    const double airStressCoeff = 0.0012;
+    for (int c = 0; c < nCellsSolve; c++) {
+        double windSpeed = sqrt(uAirVelocity[c] * uAirVelocity[c] + vAirVelocity[c] * vAirVelocity[c]);
+        airStressCellU[c] = airDensity[c] * windSpeed * airStressCoeff * uAirVelocity[c] * iceAreaCell[c];
+        airStressCellV[c] = airDensity[c] * windSpeed * airStressCoeff * vAirVelocity[c] * iceAreaCell[c];
+    }
+}
+
+/* velocity_solver.F:1742-1788 */
+void ora_coriolis_force_coefficient(int nVerticesSolve, const double *totalMassVertex, const double *fVertex,
+                                    double *totalMassVertexfVertex)
+{
+    for (int v = 0; v < nVerticesSolve; v++) totalMassVertexfVertex[v] = totalMassVertex[v] * fVertex[v];
+}
+
+/* velocity_solver.F:1802-1883 */
+void ora_ocean_stress(int nVerticesSolve, int nVertices, int useOceanStress, const int *solveVelocity,
+                      const double *uOceanVelocityVertex, const double *vOceanVelocityVertex,
+                      const double *fVertex, double *oceanStressU, double *oceanStressV)
+{
+    if (useOceanStress) {
+        for (int v = 0; v < nVerticesSolve; v++) {
+            if (solveVelocity[v] == 1) {
+                oceanStressU[v] = uOceanVelocityVertex[v] * cosOceanTurningAngle -
+                                  vOceanVelocityVertex[v] * sinOceanTurningAngle * sign1(fVertex[v]);
+                oceanStressV[v] = uOceanVelocityVertex[v] * sinOceanTurningAngle * sign1(fVertex[v]) +
+                                  vOceanVelocityVertex[v] * cosOceanTurningAngle;
+            } else {
+                oceanStressU[v] = 0.0;
+                oceanStressV[v] = 0.0;
+            }
+        }
+    } else {
+        for (int v = 0; v < nVertices; v++) {
+            oceanStressU[v] = 0.0;
+            oceanStressV[v] = 0.0;
+        }
+    }
+}
+
+/* velocity_solver.F:1941-2010 (geostrophic), :2149-2164 (ssh gradient, after interpolation), :2183-2213 */
+void ora_surface_tilt(int nVerticesSolve, int nVertices, int mode /*0 none,1 geostrophic,2 ssh*/,
+                      const int *solveVelocity, const double *totalMassVertex, const double *fVertex,
+                      const double *uOceanVelocityVertex, const double *vOceanVelocityVertex,
+                      const double *seaSurfaceTiltVertexU, const double *seaSurfaceTiltVertexV,
+                      double *surfaceTiltForceU, double *surfaceTiltForceV)
+{
+    if (mode == 0) {
+        for (int v = 0; v < nVertices; v++) {
+            surfaceTiltForceU[v] = 0.0;
+            surfaceTiltForceV[v] = 0.0;
+        }
+        return;
+    }
+    for (int v = 0; v < nVerticesSolve; v++) {
+        if (solveVelocity[v] == 1) {
+            if (mode == 1) {
+                surfaceTiltForceU[v] = -fVertex[v] * totalMassVertex[v] * vOceanVelocityVertex[v];
+                surfaceTiltForceV[v] = fVertex[v] * totalMassVertex[v] * uOceanVelocityVertex[v];
+            } else {
+                surfaceTiltForceU[v] = -seaiceGravity * totalMassVertex[v] * seaSurfaceTiltVertexU[v];
+                surfaceTiltForceV[v] = -seaiceGravity * totalMassVertex[v] * seaSurfaceTiltVertexV[v];
+            }
+        } else {
+            surfaceTiltForceU[v] = 0.0;
+            surfaceTiltForceV[v] = 0.0;
+        }
+    }
+}
+
+/* velocity_solver.F:2227-2386 (variational branch) */
+void ora_init_subcycle_variables(int nCells, int nVerticesSolve, int nVertices, int maxEdges,
+                                 const int *solveStress, const int *solveVelocity, double *stressDivergenceU,
+                                 double *stressDivergenceV, double *uVelocity, double *vVelocity,
+                                 double *oceanStressCoeff, double *strain11, double *strain22, double *strain12,
+                                 double *stress11, double *stress22, double *stress12)
+{
+    for (int v = 0; v < nVertices; v++) {
+        stressDivergenceU[v] = 0.0;
+        stressDivergenceV[v] = 0.0;
+    }
+    for (int v = 0; v < nVerticesSolve; v++) {
+        if (solveVelocity[v] != 1) {
+            uVelocity[v] = 0.0;
+            vVelocity[v] = 0.0;
+            oceanStressCoeff[v] = 0.0;
+        }
+    }
+    size_t n = (size_t)maxEdges * (size_t)nCells;
+    memset(strain11, 0, n * sizeof(double));
+    memset(strain22, 0, n * sizeof(double));
+    memset(strain12, 0, n * sizeof(double));
+    for (int c = 1; c <= nCells; c++) {
+        if (solveStress[c - 1] != 1) {
+            for (int i = 1; i <= maxEdges; i++) {
+                stress11[IX2(i, c, maxEdges)] = 0.0;
+                stress22[IX2(i, c, maxEdges)] = 0.0;
+                stress12[IX2(i, c, maxEdges)] = 0.0;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ subcycle kernels */
+
+/* variational.F:575-670 */
+void ora_strain_tensor_variational(int nCells, int maxEdges, const int *nEdgesOnCell, const int *verticesOnCell,
+                                   double *strain11, double *strain22, double *strain12, const double *uVelocity,
+                                   const double *vVelocity, const double *basisGradientU,
+                                   const double *basisGradientV, const double *tanLatVertexRotatedOverRadius,
+                                   const int *solveStress)
+{
+#pragma omp parallel for schedule(static)
+    for (int c = 1; c <= nCells; c++) {
+        if (solveStress[c - 1] == 1) {
+            for (int g = 1; g <= nEdgesOnCell[c - 1]; g++) {
+                double s11 = 0.0, s22 = 0.0, s12 = 0.0;
+                for (int b = 1; b <= nEdgesOnCell[c - 1]; b++) {
+                    int v = verticesOnCell[IX2(b, c, maxEdges)];
+                    s11 = s11 + uVelocity[v - 1] * basisGradientU[IX3(b, g, c, maxEdges)];
+                    s22 = s22 + vVelocity[v - 1] * basisGradientV[IX3(b, g, c, maxEdges)];
+                    s12 = s12 + 0.5 * (uVelocity[v - 1] * basisGradientV[IX3(b, g, c, maxEdges)] +
+                                       vVelocity[v - 1] * basisGradientU[IX3(b, g, c, maxEdges)]);
+                }
+                int j = verticesOnCell[IX2(g, c, maxEdges)];
+                strain11[IX2(g, c, maxEdges)] = s11 - vVelocity[j - 1] * tanLatVertexRotatedOverRadius[j - 1];
+                strain12[IX2(g, c, maxEdges)] =
+                    s12 + uVelocity[j - 1] * tanLatVertexRotatedOverRadius[j - 1] * 0.5;
+                strain22[IX2(g, c, maxEdges)] = s22;
+            }
+        }
+    }
+}
+
+/* constitutive_relation.F:178-248 */
+static void evp_constitutive_relation(double *stress11, double *stress22, double *stress12, double strain11,
+                                      double strain22, double strain12, double icePressure,
+                                      double *replacementPressure, double dtElastic, double dampingTimescale)
+{
+    double strainDivergence = strain11 + strain22;
+    double strainTension = strain11 - strain22;
+    double strainShearing = strain12 * 2.0;
+    double stress1 = *stress11 + *stress22;
+    double stress2 = *stress11 - *stress22;
+    double Delta = sqrt(strainDivergence * strainDivergence +
+                        (strainTension * strainTension + strainShearing * strainShearing) / eccentricitySquared);
+    double pressureCoefficient = icePressure / fmax(Delta, puny);
+    *replacementPressure = pressureCoefficient * Delta;
+    pressureCoefficient = (pressureCoefficient * dtElastic) / (2.0 * dampingTimescale);
+    double denominator = 1.0 + (0.5 * dtElastic) / dampingTimescale;
+    stress1 = (stress1 + pressureCoefficient * (strainDivergence - Delta)) / denominator;
+    stress2 = (stress2 + (pressureCoefficient / eccentricitySquared) * strainTension) / denominator;
+    *stress12 = (*stress12 + (pressureCoefficient / eccentricitySquared) * strainShearing * 0.5) / denominator;
+    *stress11 = 0.5 * (stress1 + stress2);
+    *stress22 = 0.5 * (stress1 - stress2);
+}
+
+/* constitutive_relation.F:262-330 */
+static void evp_constitutive_relation_revised(double *stress11, double *stress22, double *stress12,
+                                              double strain11, double strain22, double strain12,
+                                              double icePressure, double *replacementPressure)
+{
+    const double dampingRatioDenominator = 0.86, dampingRatio = 5.5e-3;
+    double strainDivergence = strain11 + strain22;
+    double strainTension = strain11 - strain22;
+    double strainShearing = strain12 * 2.0;
+    double stress1 = *stress11 + *stress22;
+    double stress2 = *stress11 - *stress22;
+    double Delta = sqrt(strainDivergence * strainDivergence +
+                        (strainTension * strainTension + strainShearing * strainShearing) / eccentricitySquared);
+    double pressureCoefficient = icePressure / fmax(Delta, puny);
+    *replacementPressure = pressureCoefficient * Delta;
+    pressureCoefficient = (pressureCoefficient * 2.0 * dampingRatio) / dampingRatioDenominator;
+    double denominator = 1.0 + (2.0 * dampingRatio) / dampingRatioDenominator;
+    stress1 = (stress1 + pressureCoefficient * (strainDivergence - Delta)) / denominator;
+    stress2 = (stress2 + (pressureCoefficient / eccentricitySquared) * strainTension) / denominator;
+    *stress12 = (*stress12 + (pressureCoefficient / eccentricitySquared) * strainShearing * 0.5) / denominator;
+    *stress11 = 0.5 * (stress1 + stress2);
+    *stress22 = 0.5 * (stress1 - stress2);
+}
+
+/* variational.F:777-975; relation: 1 evp, 2 evp_revised, 3 linear (constitutive_relation.F:344-373) */
+void ora_stress_tensor_variational(int nCells, int maxEdges, const int *nEdgesOnCell, double *stress11,
+                                   double *stress22, double *stress12, const double *strain11,
+                                   const double *strain22, const double *strain12, const double *icePressure,
+                                   double *replacementPressure, const int *solveStress, double dtElastic,
+                                   double dampingTimescale, int relation)
+{
+#pragma omp parallel for schedule(static)
+    for (int c = 1; c <= nCells; c++) {
+        if (relation == 1)
+            for (int i = 1; i <= maxEdges; i++) replacementPressure[IX2(i, c, maxEdges)] = 0.0;
+        if (solveStress[c - 1] == 1) {
+            for (int i = 1; i <= nEdgesOnCell[c - 1]; i++) {
+                size_t k = IX2(i, c, maxEdges);
+                if (relation == 1)
+                    evp_constitutive_relation(&stress11[k], &stress22[k], &stress12[k], strain11[k], strain22[k],
+                                              strain12[k], icePressure[c - 1], &replacementPressure[k], dtElastic,
+                                              dampingTimescale);
+                else if (relation == 2)
+                    evp_constitutive_relation_revised(&stress11[k], &stress22[k], &stress12[k], strain11[k],
+                                                      strain22[k], strain12[k], icePressure[c - 1],
+                                                      &replacementPressure[k]);
+                else {
+                    stress11[k] = 1.0 * strain11[k];
+                    stress22[k] = 1.0 * strain22[k];
+                    stress12[k] = 1.0 * strain12[k];
+                }
+            }
+        }
+    }
+}
+
+/* variational.F:1064-1184 */
+void ora_stress_divergence_variational(int nVerticesSolve, int vertexDegree, int maxEdges, const int *nEdgesOnCell,
+                                       const int *cellsOnVertex, const int *cellVerticesAtVertex,
+                                       double *stressDivergenceU, double *stressDivergenceV,
+                                       const double *stress11, const double *stress22, const double *stress12,
+                                       const double *basisIntegralsU, const double *basisIntegralsV,
+                                       const double *basisIntegralsMetric, const double *variationalDenominator,
+                                       const double *tanLatVertexRotatedOverRadius, const int *solveVelocity)
+{
+#pragma omp parallel for schedule(static)
+    for (int v = 1; v <= nVerticesSolve; v++) {
+        if (solveVelocity[v - 1] == 1) {
+            double divU = 0.0, divV = 0.0;
+            for (int k = 1; k <= vertexDegree; k++) {
+                int c = cellsOnVertex[IX2(k, v, vertexDegree)];
+                int j = cellVerticesAtVertex[IX2(k, v, vertexDegree)];
+                double cu = 0.0, cv = 0.0;
+                for (int s = 1; s <= nEdgesOnCell[c - 1]; s++) {
+                    size_t ks = IX2(s, c, maxEdges);
+                    size_t kb = IX3(s, j, c, maxEdges);
+                    cu = cu - stress11[ks] * basisIntegralsU[kb] - stress12[ks] * basisIntegralsV[kb] -
+                         stress12[ks] * basisIntegralsMetric[kb] * tanLatVertexRotatedOverRadius[v - 1];
+                    cv = cv - stress22[ks] * basisIntegralsV[kb] - stress12[ks] * basisIntegralsU[kb] +
+                         stress11[ks] * basisIntegralsMetric[kb] * tanLatVertexRotatedOverRadius[v - 1];
+                }
+                divU = divU + cu;
+                divV = divV + cv;
+            }
+            stressDivergenceU[v - 1] = divU / variationalDenominator[v - 1];
+            stressDivergenceV[v - 1] = divV / variationalDenominator[v - 1];
+        }
+    }
+}
+
+/* velocity_solver.F:2986-3082 (serial in the reference) */
+void ora_ocean_stress_coefficient(int nVerticesSolve, int nVertices, int useOceanStress, int quadratic,
+                                  const int *solveVelocity, double *oceanStressCoeff,
+                                  const double *uOceanVelocityVertex, const double *vOceanVelocityVertex,
+                                  const double *uVelocity, const double *vVelocity, const double *iceAreaVertex)
+{
+    if (!useOceanStress) {
+        for (int v = 0; v < nVertices; v++) oceanStressCoeff[v] = 0.0;
+        return;
+    }
+    for (int v = 0; v < nVerticesSolve; v++) {
+        if (solveVelocity[v] == 1) {
+            if (quadratic) {
+                double du = uOceanVelocityVertex[v] - uVelocity[v];
+                double dv = vOceanVelocityVertex[v] - vVelocity[v];
+                oceanStressCoeff[v] = seaiceIceOceanDragCoefficient * seaiceDensitySeaWater * iceAreaVertex[v] *
+                                      sqrt(du * du + dv * dv);
+            } else {
+                oceanStressCoeff[v] = seaiceIceOceanDragCoefficient * seaiceDensitySeaWater * iceAreaVertex[v];
+            }
+        }
+    }
+}
+
+/* velocity_solver.F:3096-3208 */
+void ora_solve_velocity(int nVerticesSolve, const int *solveVelocity, double *uVelocity, double *vVelocity,
+                        const double *totalMassVertex, const double *totalMassVertexfVertex,
+                        const double *stressDivergenceU, const double *stressDivergenceV,
+                        const double *airStressVertexU, const double *airStressVertexV,
+                        const double *surfaceTiltForceU, const double *surfaceTiltForceV,
+                        const double *oceanStressU, const double *oceanStressV, const double *oceanStressCoeff,
+                        double elasticTimeStep)
+{
+#pragma omp parallel for schedule(static)
+    for (int v = 0; v < nVerticesSolve; v++) {
+        if (solveVelocity[v] == 1) {
+            double l11 = totalMassVertex[v] / elasticTimeStep + oceanStressCoeff[v] * cosOceanTurningAngle;
+            double l12 = -totalMassVertexfVertex[v] -
+                         oceanStressCoeff[v] * sinOceanTurningAngle * sign1(totalMassVertexfVertex[v]);
+            double l21 = totalMassVertexfVertex[v] +
+                         oceanStressCoeff[v] * sinOceanTurningAngle * sign1(totalMassVertexfVertex[v]);
+            double l22 = totalMassVertex[v] / elasticTimeStep + oceanStressCoeff[v] * cosOceanTurningAngle;
+            double r1 = stressDivergenceU[v] + airStressVertexU[v] + surfaceTiltForceU[v] +
+                        oceanStressCoeff[v] * oceanStressU[v] + (totalMassVertex[v] * uVelocity[v]) / elasticTimeStep;
+            double r2 = stressDivergenceV[v] + airStressVertexV[v] + surfaceTiltForceV[v] +
+                        oceanStressCoeff[v] * oceanStressV[v] + (totalMassVertex[v] * vVelocity[v]) / elasticTimeStep;
+            double den = l11 * l22 - l12 * l21;
+            uVelocity[v] = (l22 * r1 - l12 * r2) / den;
+            vVelocity[v] = (l11 * r2 - l21 * r1) / den;
+        }
+    }
+}
+
+/* velocity_solver.F:3222-3342 */
+void ora_solve_velocity_revised(int nVerticesSolve, const int *solveVelocity, double *uVelocity, double *vVelocity,
+                                const double *uVelocityInitial, const double *vVelocityInitial,
+                                const double *totalMassVertex, const double *totalMassVertexfVertex,
+                                const double *stressDivergenceU, const double *stressDivergenceV,
+                                const double *airStressVertexU, const double *airStressVertexV,
+                                const double *surfaceTiltForceU, const double *surfaceTiltForceV,
+                                const double *oceanStressU, const double *oceanStressV,
+                                const double *oceanStressCoeff, double dynamicsTimeStep,
+                                double numericalInertiaCoefficient)
+{
+    for (int v = 0; v < nVerticesSolve; v++) {
+        if (solveVelocity[v] == 1) {
+            double l11 = (numericalInertiaCoefficient + 1.0) * (totalMassVertex[v] / dynamicsTimeStep) +
+                         oceanStressCoeff[v] * cosOceanTurningAngle;
+            double l12 = -totalMassVertexfVertex[v] -
+                         oceanStressCoeff[v] * sinOceanTurningAngle * sign1(totalMassVertexfVertex[v]);
+            double l21 = totalMassVertexfVertex[v] +
+                         oceanStressCoeff[v] * sinOceanTurningAngle * sign1(totalMassVertexfVertex[v]);
+            double l22 = (numericalInertiaCoefficient + 1.0) * (totalMassVertex[v] / dynamicsTimeStep) +
+                         oceanStressCoeff[v] * cosOceanTurningAngle;
+            double r1 = stressDivergenceU[v] + airStressVertexU[v] + surfaceTiltForceU[v] +
+                        oceanStressCoeff[v] * oceanStressU[v] +
+                        (totalMassVertex[v] * (numericalInertiaCoefficient * uVelocity[v] + uVelocityInitial[v])) /
+                            dynamicsTimeStep;
+            double r2 = stressDivergenceV[v] + airStressVertexV[v] + surfaceTiltForceV[v] +
+                        oceanStressCoeff[v] * oceanStressV[v] +
+                        (totalMassVertex[v] * (numericalInertiaCoefficient * vVelocity[v] + vVelocityInitial[v])) /
+                            dynamicsTimeStep;
+            double den = l11 * l22 - l12 * l21;
+            uVelocity[v] = (l22 * r1 - l12 * r2) / den;
+            vVelocity[v] = (l11 * r2 - l21 * r1) / den;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ post-subcycle */
+
+/* variational.F:1198-1330 */
+void ora_final_divergence_shear(int nCells, int maxEdges, const int *nEdgesOnCell, const int *solveStress,
+                                const double *strain11, const double *strain22, const double *strain12,
+                                double *divergence, double *shear, int useRidging, double *ridgeConvergence,
+                                double *ridgeShear)
+{
+    double *DeltaAverage = (double *)calloc((size_t)nCells, sizeof(double));
+    for (int c = 1; c <= nCells; c++) {
+        if (solveStress[c - 1] == 1) {
+            double dS = 0.0, tS = 0.0, sS = 0.0, dA = 0.0;
+            for (int i = 1; i <= nEdgesOnCell[c - 1]; i++) {
+                size_t k = IX2(i, c, maxEdges);
+                double sd = strain11[k] + strain22[k];
+                double st = strain11[k] - strain22[k];
+                double ss = strain12[k] * 2.0;
+                double Delta = sqrt(sd * sd + (st * st + ss * ss) / eccentricitySquared);
+                dS = dS + sd;
+                tS = tS + st;
+                sS = sS + ss;
+                dA = dA + Delta;
+            }
+            double en = (double)nEdgesOnCell[c - 1];
+            divergence[c - 1] = dS / en;
+            shear[c - 1] = sqrt(tS * tS + sS * sS) / en;
+            DeltaAverage[c - 1] = dA / en;
+        } else {
+            divergence[c - 1] = 0.0;
+            shear[c - 1] = 0.0;
+        }
+    }
+    if (useRidging) {
+        for (int c = 0; c < nCells; c++) {
+            if (solveStress[c] == 1) {
+                ridgeConvergence[c] = -fmin(divergence[c], 0.0);
+                ridgeShear[c] = 0.5 * (DeltaAverage[c] - fabs(divergence[c]));
+            } else {
+                ridgeConvergence[c] = 0.0;
+                ridgeShear[c] = 0.0;
+            }
+        }
+    }
+    for (int c = 0; c < nCells; c++) {
+        divergence[c] = divergence[c] * 100.0 * 86400.0;
+        shear[c] = shear[c] * 100.0 * 86400.0;
+    }
+    free(DeltaAverage);
+}
+
+/* velocity_solver.F:3534-3546 with principal_stresses :3567-3610 */
+void ora_principal_stresses(int nCellsSolve, int maxEdges, const int *nEdgesOnCell, const double *stress11,
+                            const double *stress22, const double *stress12, const double *replacementPressure,
+                            double *principalStress1, double *principalStress2)
+{
+    for (int c = 1; c <= nCellsSolve; c++) {
+        for (int i = 1; i <= nEdgesOnCell[c - 1]; i++) {
+            size_t k = IX2(i, c, maxEdges);
+            if (replacementPressure[k] > puny) {
+                double sq = (stress11[k] + stress22[k]) * (stress11[k] + stress22[k]) -
+                            4.0 * stress11[k] * stress22[k] + 4.0 * (stress12[k] * stress12[k]);
+                double p1 = 0.5 * (stress11[k] + stress22[k]) + 0.5 * sqrt(sq);
+                double p2 = 0.5 * (stress11[k] + stress22[k]) - 0.5 * sqrt(sq);
+                principalStress1[k] = p1 / replacementPressure[k];
+                principalStress2[k] = p2 / replacementPressure[k];
+            } else {
+                principalStress1[k] = 1.0e30;
+                principalStress2[k] = 1.0e30;
+            }
+        }
+    }
+}
+
+/* velocity_solver.F:3709-3732: vertex part of ocean_stress_final (after the coefficient update) */
+void ora_ocean_stress_final_vertex(int nVerticesSolve, int nVertices, int useOceanStress, const int *solveVelocity,
+                                   const double *oceanStressCoeff, const double *uOceanVelocityVertex,
+                                   const double *vOceanVelocityVertex, const double *uVelocity,
+                                   const double *vVelocity, const double *fVertex, const double *iceAreaVertex,
+                                   double *oceanStressU, double *oceanStressV)
+{
+    if (!useOceanStress) {
+        for (int v = 0; v < nVertices; v++) {
+            oceanStressU[v] = 0.0;
+            oceanStressV[v] = 0.0;
+        }
+        return;
+    }
+    for (int v = 0; v < nVerticesSolve; v++) {
+        if (solveVelocity[v] == 1) {
+            oceanStressU[v] = oceanStressCoeff[v] *
+                              ((uOceanVelocityVertex[v] - uVelocity[v]) * cosOceanTurningAngle -
+                               (vOceanVelocityVertex[v] - vVelocity[v]) * sinOceanTurningAngle * sign1(fVertex[v]));
+            oceanStressV[v] = oceanStressCoeff[v] *
+                              ((vOceanVelocityVertex[v] - vVelocity[v]) * cosOceanTurningAngle +
+                               (uOceanVelocityVertex[v] - uVelocity[v]) * sinOceanTurningAngle * sign1(fVertex[v]));
+            oceanStressU[v] = oceanStressU[v] / iceAreaVertex[v];
+            oceanStressV[v] = oceanStressV[v] / iceAreaVertex[v];
+        } else {
+            oceanStressU[v] = 0.0;
+            oceanStressV[v] = 0.0;
+        }
+    }
+}
+
+/* velocity_solver.F:3816-3825 */
+void ora_ocean_stress_final_rescale(int nVerticesSolve, const int *solveVelocity, const double *iceAreaVertex,
+                                    double *oceanStressU, double *oceanStressV)
+{
+    for (int v = 0; v < nVerticesSolve; v++) {
+        if (solveVelocity[v] == 1) {
+            oceanStressU[v] = oceanStressU[v] * iceAreaVertex[v];
+            oceanStressV[v] = oceanStressV[v] * iceAreaVertex[v];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ subcycle loop (single block) */
+
+/* subcycle_velocity_solver / single_subcycle_velocity_solver, velocity_solver.F:2404-2592, for one
+ * block with no halo exchange partner (a full-sphere block owns everything) and no special boundaries. */
+void ora_evp_subcycle_loop(int nSubcycles, int nCells, int nVerticesSolve, int nVertices, int maxEdges,
+                           int vertexDegree, const int *nEdgesOnCell, const int *verticesOnCell,
+                           const int *cellsOnVertex, const int *cellVerticesAtVertex, const int *solveStress,
+                           const int *solveVelocity, const double *basisGradientU, const double *basisGradientV,
+                           const double *basisIntegralsU, const double *basisIntegralsV,
+                           const double *basisIntegralsMetric, const double *variationalDenominator,
+                           const double *tanLatVertexRotatedOverRadius, const double *icePressure,
+                           const double *totalMassVertex, const double *totalMassVertexfVertex,
+                           const double *iceAreaVertex, const double *airStressVertexU,
+                           const double *airStressVertexV, const double *surfaceTiltForceU,
+                           const double *surfaceTiltForceV, const double *oceanStressU,
+                           const double *oceanStressV, const double *uOceanVelocityVertex,
+                           const double *vOceanVelocityVertex, const double *uVelocityInitial,
+                           const double *vVelocityInitial, double *uVelocity, double *vVelocity,
+                           double *strain11, double *strain22, double *strain12, double *stress11,
+                           double *stress22, double *stress12, double *replacementPressure,
+                           double *stressDivergenceU, double *stressDivergenceV, double *oceanStressCoeff,
+                           double elasticTimeStep, double dynamicsTimeStep, double dampingTimescale,
+                           double numericalInertiaCoefficient, int relation, int useOceanStress,
+                           int quadraticOceanStress)
+{
+    for (int it = 0; it < nSubcycles; it++) {
+        ora_strain_tensor_variational(nCells, maxEdges, nEdgesOnCell, verticesOnCell, strain11, strain22, strain12,
+                                      uVelocity, vVelocity, basisGradientU, basisGradientV,
+                                      tanLatVertexRotatedOverRadius, solveStress);
+        ora_stress_tensor_variational(nCells, maxEdges, nEdgesOnCell, stress11, stress22, stress12, strain11,
+                                      strain22, strain12, icePressure, replacementPressure, solveStress,
+                                      elasticTimeStep, dampingTimescale, relation);
+        ora_stress_divergence_variational(nVerticesSolve, vertexDegree, maxEdges, nEdgesOnCell, cellsOnVertex,
+                                          cellVerticesAtVertex, stressDivergenceU, stressDivergenceV, stress11,
+                                          stress22, stress12, basisIntegralsU, basisIntegralsV,
+                                          basisIntegralsMetric, variationalDenominator,
+                                          tanLatVertexRotatedOverRadius, solveVelocity);
+        ora_ocean_stress_coefficient(nVerticesSolve, nVertices, useOceanStress, quadraticOceanStress, solveVelocity,
+                                     oceanStressCoeff, uOceanVelocityVertex, vOceanVelocityVertex, uVelocity,
+                                     vVelocity, iceAreaVertex);
+        if (relation == 1)
+            ora_solve_velocity(nVerticesSolve, solveVelocity, uVelocity, vVelocity, totalMassVertex,
+                               totalMassVertexfVertex, stressDivergenceU, stressDivergenceV, airStressVertexU,
+                               airStressVertexV, surfaceTiltForceU, surfaceTiltForceV, oceanStressU, oceanStressV,
+                               oceanStressCoeff, elasticTimeStep);
+        else if (relation == 2)
+            ora_solve_velocity_revised(nVerticesSolve, solveVelocity, uVelocity, vVelocity, uVelocityInitial,
+                                       vVelocityInitial, totalMassVertex, totalMassVertexfVertex,
+                                       stressDivergenceU, stressDivergenceV, airStressVertexU, airStressVertexV,
+                                       surfaceTiltForceU, surfaceTiltForceV, oceanStressU, oceanStressV,
+                                       oceanStressCoeff, dynamicsTimeStep, numericalInertiaCoefficient);
+    }
+}
