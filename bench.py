@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""EVP subcycle benchmark: cell-subcycle-updates/s at QU60 on N MI355X GPUs.
+
+One "step" = one dynamics step's subcycle loop = 120 EVP subcycles (strain, stress, stress
+divergence, ocean stress coefficient, velocity solve [+ halo exchange when N > 1]) over the QU60
+mesh (163 842 cells) with the synthetic idealised forcing of mpas_seaice_amd.cases.  Pre- and
+post-subcycle stages are outside the timed region and reported separately (pre_ms / post_ms).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak; ~6300 GB/s is what a streaming copy reaches
+
+
+def b_alg_per_cell(M):
+    """Algorithmic (compulsory) bytes per cell per subcycle, dense basis storage, two fused kernels:
+    cell part 16 + 4M + 16M^2 + 56M + 24*(nV/nC), vertex part (nV/nC)*(148+16) + 4 + 24M + 24M^2 with
+    nV/nC = 2 (M = 6: 1000 + 1340 = 2340 B)."""
+    cell = 16 + 4 * M + 16 * M * M + 56 * M + 24 * 2
+    vert = 2 * (148 + 16) + 4 + 24 * M + 24 * M * M
+    return cell, vert
+
+
+def b_alg_cell_kernel(M):
+    """Share of those bytes moved by this library's fused cell kernel (strain + stress + the inner
+    sums of the stress divergence): both gradient matrices, the three integral matrices, stress read
+    and write, replacement pressure, connectivity, ice strength and the vertex velocities it gathers."""
+    return 16 * M * M + 24 * M * M + 48 * M + 8 * M + (4 * M + 8) + 8 + 24 * 2
+
+
+def cpu_baseline(mesh, name, max_seconds=25.0):
+    """The CPU oracle (a restatement of the reference loops, OpenMP where the reference has it) timed
+    on this host: whole-mesh subcycles until ~max_seconds of work."""
+    from mpas_seaice_amd import cases
+    from oracle import evp_flow as ora
+    dom = cases.make_domain(mesh, name)
+    ora.seaice_init_velocity_solver(dom)
+    ora.velocity_solver_pre_subcycle(dom)
+    nC = mesh.nCells
+    t0 = time.perf_counter()
+    ora.subcycle_velocity_solver(dom, 4)
+    t1 = time.perf_counter() - t0
+    n = int(max(4, min(240, (max_seconds / 2.0) / max(t1 / 4.0, 1e-6))))
+    t0 = time.perf_counter()
+    ora.subcycle_velocity_solver(dom, n)
+    dt = time.perf_counter() - t0
+    return {"value": nC * n / dt, "unit": "cell-subcycle-updates/s", "cores": ora.num_threads(), "kind": "port",
+            "sample": f"{n} subcycles of the full {name} mesh ({nC} cells), OpenMP threads = cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mesh", default="QU60")
+    ap.add_argument("--subcycles", type=int, default=120)
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("SIH_BENCH_GRAPH", "0")))
+    ap.add_argument("--sample-every", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-renumber", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from mpas_seaice_amd import cases, mesh as meshmod, velocity_solver as vs
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the solver has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    mesh = meshmod.make_named_mesh(args.mesh)
+    nsub = args.subcycles
+    M = int(mesh.maxEdges)
+
+    if world == 1:
+        dom = cases.make_domain(mesh, args.mesh, configs={"config_elastic_subcycle_number": nsub})
+        vs.seaice_mesh_pool_create(dom, device=local_rank, renumber=not args.no_renumber)
+        vs.seaice_init_velocity_solver(dom)
+        ctx = dom.blocklist[0].ctx
+        for b in dom.blocklist:
+            vs._upload(dom, b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        vs.velocity_solver_pre_subcycle(dom)
+        ctx.sync()
+        pre_ms = (time.perf_counter() - t0) * 1e3
+        for _ in range(args.warmup):
+            ctx.subcycle_timed(nsub, use_graph=args.graph, sample_every=0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cell_ms, vert_ms, nsamp = 0.0, 0.0, 0
+        for _ in range(args.steps):
+            _, tc, tv = ctx.subcycle_timed(nsub, use_graph=args.graph, sample_every=args.sample_every)
+            if tc > 0:
+                cell_ms += tc
+                vert_ms += tv
+                nsamp += 1
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        ctx.subcycle(1, last=True)
+        vs.velocity_solver_post_subcycle(dom)
+        ctx.sync()
+        post_ms = (time.perf_counter() - t0) * 1e3
+        if nsamp == 0:  # graph replay has no per-kernel events: sample the kernels once afterwards
+            _, cell_ms, vert_ms = ctx.subcycle_timed(nsub, use_graph=False, sample_every=4)
+            nsamp = 1
+        cell_ms /= nsamp
+        vert_ms /= nsamp
+        u = np.zeros(mesh.nVertices + 1)
+        ctx.get("uVelocity", u)
+        if not np.isfinite(u).all():
+            raise SystemExit("non-finite velocities after the benchmark loop")
+        n_cells_total = mesh.nCells
+        vs.seaice_mesh_pool_destroy(dom)
+        parallelism = "1 block"
+    else:
+        from mpas_seaice_amd import parallel
+        res = parallel.bench_multi_gpu(mesh, args.mesh, nsub, args.steps, args.warmup, local_rank,
+                                       renumber=not args.no_renumber)
+        wall, pre_ms, post_ms, cell_ms, vert_ms, n_cells_total = (res[k] for k in (
+            "wall", "pre_ms", "post_ms", "cell_ms", "vert_ms", "n_cells_total"))
+        parallelism = f"{world} MPAS blocks, one per GPU, halo exchange of uVelocity/vVelocity every subcycle"
+        if rank != 0:
+            return
+
+    ms_per_step = wall / args.steps * 1e3
+    value = n_cells_total * nsub * args.steps / wall
+    b_cell, b_vert = b_alg_per_cell(M)
+    cells_per_launch = n_cells_total / world
+    roof_bytes = b_alg_cell_kernel(M) * cells_per_launch
+    achieved = roof_bytes / (cell_ms * 1e-3) / 1e9 if cell_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if world == 1 and os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("cell_kernel_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "EVP cell-subcycle-updates/sec at QU60", "value": value, "unit": "cell-subcycle-updates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.mesh} full-sphere mesh ({n_cells_total} cells, maxEdges {M}), "
+                               f"{nsub} EVP subcycles per step, variational Wachspress operators, idealised forcing",
+                   "parallelism": parallelism, "hip_graph": bool(args.graph)},
+        "roofline": {"bound": "hbm", "kernel": "k_sub_cells (fused strain + EVP stress + stress-divergence partial sums)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "algorithmic_bytes_per_launch": roof_bytes,
+                     "kernel_ms": cell_ms, "vertex_kernel_ms": vert_ms},
+        "subcycle_hbm": {"algorithmic_bytes_per_cell_subcycle": b_cell + b_vert,
+                         "achieved_GBps": (b_cell + b_vert) * value / 1e9,
+                         "frac_of_peak": (b_cell + b_vert) * value / 1e9 / HBM_PEAK_GBS},
+        "pre_ms": pre_ms, "post_ms": post_ms,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(mesh, args.mesh)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
