@@ -170,11 +170,15 @@ int sih_evp_subcycle_timed(sih_ctx *ctx, int n, int useGraph, int sampleEvery, d
 
 /* ---- halo exchange (pack / unpack only) -------------------------------------------------------
  * location: 0 cells, 1 vertices.  sendIdx / recvIdx are 1-based local indices, all neighbours
- * concatenated in the order the host will lay the message buffers out. */
+ * concatenated; sendCounts / recvCounts (nPeers entries each, may be NULL with nPeers = 0 for a single
+ * segment) give the number of entries per neighbour in that order. */
 int sih_halo_set_lists(sih_ctx *ctx, int location, int nSend, const int32_t *sendIdx, int nRecv,
-                       const int32_t *recvIdx);
-/* gather the listed entries of `nFields` fields (all of one location and type) into a DEVICE buffer:
- * buf[f * nSend + i] = field_f(sendIdx[i]);  unpack scatters buf[f * nRecv + i] -> field_f(recvIdx[i]).
+                       const int32_t *recvIdx, int nPeers, const int32_t *sendCounts,
+                       const int32_t *recvCounts);
+/* gather the listed entries of `nFields` fields (all of one location and type) into a DEVICE buffer laid
+ * out neighbour-major, so that each neighbour's message is contiguous:
+ *   buf[off_p * nFields + f * cnt_p + i] = field_f(sendIdx[off_p + i]),  off_p = sum of counts before p;
+ * unpack scatters the same layout (with the recv counts) into field_f(recvIdx[...]).
  * Both are asynchronous on the context's stream. */
 int sih_halo_pack(sih_ctx *ctx, int location, int nFields, const char *const *names, void *deviceBuf);
 int sih_halo_unpack(sih_ctx *ctx, int location, int nFields, const char *const *names, const void *deviceBuf);

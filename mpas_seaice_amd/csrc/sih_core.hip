@@ -49,17 +49,25 @@ __global__ void k_get(T *__restrict__ dst, const T *__restrict__ src, const int 
 }
 
 template <typename T>
-__global__ void k_pack(T *__restrict__ buf, const T *__restrict__ f, const int *__restrict__ idx, int n)
+__global__ void k_pack(T *__restrict__ buf, const T *__restrict__ f, const int *__restrict__ idx,
+                       const int *__restrict__ segStart, const int *__restrict__ segCnt, int n, int nf, int fi)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) buf[t] = f[idx[t]];
+    if (t < n) {
+        int s0 = segStart[t], sc = segCnt[t];
+        buf[(size_t)s0 * nf + (size_t)fi * sc + (t - s0)] = f[idx[t]];
+    }
 }
 
 template <typename T>
-__global__ void k_unpack(const T *__restrict__ buf, T *__restrict__ f, const int *__restrict__ idx, int n)
+__global__ void k_unpack(const T *__restrict__ buf, T *__restrict__ f, const int *__restrict__ idx,
+                         const int *__restrict__ segStart, const int *__restrict__ segCnt, int n, int nf, int fi)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) f[idx[t]] = buf[t];
+    if (t < n) {
+        int s0 = segStart[t], sc = segCnt[t];
+        f[idx[t]] = buf[(size_t)s0 * nf + (size_t)fi * sc + (t - s0)];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -368,6 +376,10 @@ extern "C" int sih_block_destroy(sih_ctx *c)
     for (int k = 0; k < 2; k++) {
         if (c->d_send[k]) hipFree(c->d_send[k]);
         if (c->d_recv[k]) hipFree(c->d_recv[k]);
+        for (int j = 0; j < 2; j++) {
+            if (c->d_segStart[k][j]) hipFree(c->d_segStart[k][j]);
+            if (c->d_segCnt[k][j]) hipFree(c->d_segCnt[k][j]);
+        }
     }
     if (c->d_stage) hipFree(c->d_stage);
     if (c->ownStream) hipStreamDestroy(c->ownStream);
@@ -468,10 +480,25 @@ extern "C" int sih_field_get(sih_ctx *c, const char *name, void *host, size_t co
 }
 
 // ------------------------------------------------------------------------------------------ halo
-extern "C" int sih_halo_set_lists(sih_ctx *c, int location, int nSend, const int32_t *sendIdx, int nRecv,
-                                  const int32_t *recvIdx)
+static int uploadInts(int **dst, const std::vector<int> &v)
 {
-    if (!c || location < 0 || location > 1 || nSend < 0 || nRecv < 0 || (nSend && !sendIdx) || (nRecv && !recvIdx)) {
+    if (*dst) {
+        HIPCHK(hipFree(*dst));
+        *dst = nullptr;
+    }
+    if (!v.empty()) {
+        HIPCHK(hipMalloc((void **)dst, sizeof(int) * v.size()));
+        HIPCHK(hipMemcpy(*dst, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice));
+    }
+    return SIH_OK;
+}
+
+extern "C" int sih_halo_set_lists(sih_ctx *c, int location, int nSend, const int32_t *sendIdx, int nRecv,
+                                  const int32_t *recvIdx, int nPeers, const int32_t *sendCounts,
+                                  const int32_t *recvCounts)
+{
+    if (!c || location < 0 || location > 1 || nSend < 0 || nRecv < 0 || (nSend && !sendIdx) || (nRecv && !recvIdx) ||
+        nPeers < 0 || (nPeers && (!sendCounts || !recvCounts))) {
         sih_set_error("sih_halo_set_lists: bad argument");
         return SIH_ERR_ARG;
     }
@@ -493,18 +520,46 @@ extern "C" int sih_halo_set_lists(sih_ctx *c, int location, int nSend, const int
         }
         r[i] = inv[recvIdx[i] - 1];
     }
+    std::vector<int> ss(nSend, 0), sc(nSend, nSend), rs(nRecv, 0), rcn(nRecv, nRecv);
+    if (nPeers > 0) {
+        long ts = 0, tr = 0;
+        for (int p = 0; p < nPeers; p++) {
+            if (sendCounts[p] < 0 || recvCounts[p] < 0) {
+                sih_set_error("sih_halo_set_lists: negative count");
+                return SIH_ERR_ARG;
+            }
+            ts += sendCounts[p];
+            tr += recvCounts[p];
+        }
+        if (ts != nSend || tr != nRecv) {
+            sih_set_error("sih_halo_set_lists: counts do not add up to the list lengths");
+            return SIH_ERR_ARG;
+        }
+        int o = 0;
+        for (int p = 0; p < nPeers; p++) {
+            for (int i = 0; i < sendCounts[p]; i++) {
+                ss[o + i] = o;
+                sc[o + i] = sendCounts[p];
+            }
+            o += sendCounts[p];
+        }
+        o = 0;
+        for (int p = 0; p < nPeers; p++) {
+            for (int i = 0; i < recvCounts[p]; i++) {
+                rs[o + i] = o;
+                rcn[o + i] = recvCounts[p];
+            }
+            o += recvCounts[p];
+        }
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->d_send[location]) HIPCHK(hipFree(c->d_send[location]));
-    if (c->d_recv[location]) HIPCHK(hipFree(c->d_recv[location]));
-    c->d_send[location] = c->d_recv[location] = nullptr;
-    if (nSend) {
-        HIPCHK(hipMalloc((void **)&c->d_send[location], sizeof(int) * nSend));
-        HIPCHK(hipMemcpy(c->d_send[location], s.data(), sizeof(int) * nSend, hipMemcpyHostToDevice));
-    }
-    if (nRecv) {
-        HIPCHK(hipMalloc((void **)&c->d_recv[location], sizeof(int) * nRecv));
-        HIPCHK(hipMemcpy(c->d_recv[location], r.data(), sizeof(int) * nRecv, hipMemcpyHostToDevice));
-    }
+    int rc;
+    if ((rc = uploadInts(&c->d_send[location], s))) return rc;
+    if ((rc = uploadInts(&c->d_recv[location], r))) return rc;
+    if ((rc = uploadInts(&c->d_segStart[location][0], ss))) return rc;
+    if ((rc = uploadInts(&c->d_segCnt[location][0], sc))) return rc;
+    if ((rc = uploadInts(&c->d_segStart[location][1], rs))) return rc;
+    if ((rc = uploadInts(&c->d_segCnt[location][1], rcn))) return rc;
     c->nSend[location] = nSend;
     c->nRecv[location] = nRecv;
     return SIH_OK;
@@ -518,6 +573,7 @@ static int haloPackUnpack(sih_ctx *c, int location, int nFields, const char *con
     }
     int n = pack ? c->nSend[location] : c->nRecv[location];
     const int *idx = pack ? c->d_send[location] : c->d_recv[location];
+    const int *sg0 = c->d_segStart[location][pack ? 0 : 1], *sgc = c->d_segCnt[location][pack ? 0 : 1];
     if (n == 0 || nFields == 0) return SIH_OK;
     if (!buf) {
         sih_set_error("sih_halo_pack/unpack: null buffer");
@@ -530,19 +586,25 @@ static int haloPackUnpack(sih_ctx *c, int location, int nFields, const char *con
             sih_set_error(std::string("sih_halo_pack/unpack: not a scalar field of this location: ") + names[f]);
             return SIH_ERR_ARG;
         }
+        if (f > 0 && fl->isInt != sih_find_field(c, names[0])->isInt) {
+            sih_set_error("sih_halo_pack/unpack: fields of one call must share a type");
+            return SIH_ERR_ARG;
+        }
         dim3 grid((n + 255) / 256), block(256);
         if (fl->isInt) {
-            int *b = (int *)buf + (size_t)f * n;
             if (pack)
-                hipLaunchKernelGGL(k_pack<int>, grid, block, 0, c->stream, b, (const int *)fl->d, idx, n);
+                hipLaunchKernelGGL(k_pack<int>, grid, block, 0, c->stream, (int *)buf, (const int *)fl->d, idx, sg0, sgc, n,
+                                   nFields, f);
             else
-                hipLaunchKernelGGL(k_unpack<int>, grid, block, 0, c->stream, (const int *)b, (int *)fl->d, idx, n);
+                hipLaunchKernelGGL(k_unpack<int>, grid, block, 0, c->stream, (const int *)buf, (int *)fl->d, idx, sg0, sgc,
+                                   n, nFields, f);
         } else {
-            double *b = (double *)buf + (size_t)f * n;
             if (pack)
-                hipLaunchKernelGGL(k_pack<double>, grid, block, 0, c->stream, b, (const double *)fl->d, idx, n);
+                hipLaunchKernelGGL(k_pack<double>, grid, block, 0, c->stream, (double *)buf, (const double *)fl->d, idx, sg0,
+                                   sgc, n, nFields, f);
             else
-                hipLaunchKernelGGL(k_unpack<double>, grid, block, 0, c->stream, (const double *)b, (double *)fl->d, idx, n);
+                hipLaunchKernelGGL(k_unpack<double>, grid, block, 0, c->stream, (const double *)buf, (double *)fl->d, idx,
+                                   sg0, sgc, n, nFields, f);
         }
     }
     HIPCHK(hipGetLastError());

@@ -71,6 +71,8 @@ struct sih_ctx {
     size_t stageBytes = 0;
     int nSend[2] = {0, 0}, nRecv[2] = {0, 0};
     int *d_send[2] = {nullptr, nullptr}, *d_recv[2] = {nullptr, nullptr};
+    // per entry: start offset and length of the neighbour segment it belongs to (send: [0], recv: [1])
+    int *d_segStart[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *d_segCnt[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipGraphExec_t graphExec = nullptr;
     int graphN = 0;
     int *d_flag = nullptr;

@@ -69,6 +69,14 @@ def load():
         raise SeaiceHipError(
             f"{LIB_PATH} is missing: build it with `python -m mpas_seaice_amd.build` "
             "(there is no CPU fallback for the solver)")
+    # PyTorch wheels bundle their own HIP runtime under the same SONAME (libamdhip64.so.7) but load it by
+    # another file name.  Two HIP runtimes in one process cannot both own the GPU, so when torch is
+    # part of the process (device buffers, torch.distributed) it must be loaded first: this library
+    # then binds to the runtime that is already there.  A host without torch uses /opt/rocm's.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     lib.sih_last_error.restype = ctypes.c_char_p
     lib.sih_field_count.restype = ctypes.c_size_t
@@ -89,7 +97,7 @@ def load():
                                            ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                            ctypes.POINTER(ctypes.c_double)]
     lib.sih_halo_set_lists.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-                                       ctypes.c_int, ctypes.c_void_p]
+                                       ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     lib.sih_halo_pack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                   ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
     lib.sih_halo_unpack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
@@ -210,11 +218,19 @@ class BlockContext:
         check(self._lib.sih_set_stream(self.handle, ctypes.c_void_p(stream_ptr) if stream_ptr else None),
               "sih_set_stream")
 
-    def halo_set_lists(self, location, send_idx, recv_idx):
+    def halo_set_lists(self, location, send_idx, recv_idx, send_counts=None, recv_counts=None):
         s = np.ascontiguousarray(send_idx, dtype=np.int32)
         r = np.ascontiguousarray(recv_idx, dtype=np.int32)
+        npeers = 0
+        sc = rc = None
+        if send_counts is not None:
+            sc = np.ascontiguousarray(send_counts, dtype=np.int32)
+            rc = np.ascontiguousarray(recv_counts, dtype=np.int32)
+            npeers = sc.size
         check(self._lib.sih_halo_set_lists(self.handle, int(location), s.size, _ptr(s) if s.size else None,
-                                           r.size, _ptr(r) if r.size else None), "sih_halo_set_lists")
+                                           r.size, _ptr(r) if r.size else None, npeers,
+                                           _ptr(sc) if npeers else None, _ptr(rc) if npeers else None),
+              "sih_halo_set_lists")
 
     def _names(self, names):
         arr = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])

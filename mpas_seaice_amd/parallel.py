@@ -1,0 +1,302 @@
+"""Halo exchange between MPAS blocks: the transport the reference gets from ``mpas_dmpar_*halo_exch``
+(/root/reference/src/shared/mpas_seaice_velocity_solver.F:2543-2584 and the once-per-step exchanges).
+
+Two transports share the same exchange lists (partition.BlockHalo):
+  * LocalComm  - all blocks live in this process (several blocks on one GPU, or host arrays);
+  * DistComm   - one block per process, ``torch.distributed`` all_to_all_single: RCCL on GPUs
+                 (backend "nccl"), gloo on host tensors.
+Device blocks pack / unpack through the C ABI (sih_halo_pack / sih_halo_unpack) into torch device
+buffers; host blocks (``HostFields``) index numpy pool arrays, which is what the CPU-side tests use.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import cases
+from .partition import partition_mesh
+
+LOC_ID = {"cell": 0, "vertex": 1}
+
+# location and integer-ness of the fields the velocity solver exchanges
+FIELD_LOC = {
+    "iceAreaCellInitial": "cell", "totalMassCell": "cell", "icePressure": "cell", "airStressCellU": "cell",
+    "airStressCellV": "cell", "seaSurfaceTiltU": "cell", "seaSurfaceTiltV": "cell",
+    "solveVelocity": "vertex", "interiorVertex": "vertex", "uVelocity": "vertex", "vVelocity": "vertex",
+    "oceanStressU": "vertex", "oceanStressV": "vertex",
+}
+INT_FIELDS = {"solveVelocity", "interiorVertex"}
+FIELD_POOL = {
+    "iceAreaCellInitial": "icestate", "totalMassCell": "icestate", "icePressure": "velocity_solver",
+    "airStressCellU": "velocity_solver", "airStressCellV": "velocity_solver", "seaSurfaceTiltU": "ocean_coupling",
+    "seaSurfaceTiltV": "ocean_coupling", "solveVelocity": "velocity_solver", "interiorVertex": "boundary",
+    "uVelocity": "velocity_solver", "vVelocity": "velocity_solver", "oceanStressU": "velocity_solver",
+    "oceanStressV": "velocity_solver",
+}
+
+
+def _group(names):
+    groups = {}
+    for n in names:
+        groups.setdefault((FIELD_LOC[n], n in INT_FIELDS), []).append(n)
+    return groups
+
+
+class _Lists:
+    """Concatenated send / recv lists of one block for one location, neighbours in ascending order."""
+
+    def __init__(self, halo, loc, nblocks):
+        self.peers = list(range(nblocks))
+        self.send_counts = [len(halo.send[loc].get(p, ())) for p in self.peers]
+        self.recv_counts = [len(halo.recv[loc].get(p, ())) for p in self.peers]
+        cat = lambda d: (np.concatenate([d[p] for p in self.peers if p in d]).astype(np.int32)  # noqa: E731
+                         if any(p in d for p in self.peers) else np.zeros(0, dtype=np.int32))
+        self.send_idx = cat(halo.send[loc])
+        self.recv_idx = cat(halo.recv[loc])
+        self.send_off = np.concatenate([[0], np.cumsum(self.send_counts)]).astype(np.int64)
+        self.recv_off = np.concatenate([[0], np.cumsum(self.recv_counts)]).astype(np.int64)
+
+
+class HostFields:
+    """pack / unpack on numpy pool arrays (used with the CPU oracle flow in tests); same neighbour-major
+    message layout as sih_halo_pack: [peer][field][entry]."""
+
+    def __init__(self, block):
+        self.block = block
+
+    def pack(self, lists, names, is_int):
+        nf = len(names)
+        out = np.empty(nf * lists.send_idx.size, dtype=np.int32 if is_int else np.float64)
+        for p in lists.peers:
+            o, c = int(lists.send_off[p]), lists.send_counts[p]
+            for f, n in enumerate(names):
+                out[o * nf + f * c:o * nf + (f + 1) * c] = \
+                    self.block.structs[FIELD_POOL[n]][n][lists.send_idx[o:o + c] - 1]
+        return out
+
+    def unpack(self, lists, names, buf):
+        nf = len(names)
+        for p in lists.peers:
+            o, c = int(lists.recv_off[p]), lists.recv_counts[p]
+            for f, n in enumerate(names):
+                self.block.structs[FIELD_POOL[n]][n][lists.recv_idx[o:o + c] - 1] = \
+                    buf[o * nf + f * c:o * nf + (f + 1) * c]
+
+
+class CommBase:
+    def __init__(self, domain, halos, nblocks):
+        self.nblocks = nblocks
+        self.lists = []
+        for b, h in zip(domain.blocklist, halos):
+            self.lists.append({loc: _Lists(h, loc, nblocks) for loc in ("cell", "vertex")})
+            b.halo = h
+        self.device = all(getattr(b, "ctx", None) is not None for b in domain.blocklist)
+        if self.device:
+            for b, L in zip(domain.blocklist, self.lists):
+                for loc in ("cell", "vertex"):
+                    b.ctx.halo_set_lists(LOC_ID[loc], L[loc].send_idx, L[loc].recv_idx, L[loc].send_counts,
+                                         L[loc].recv_counts)
+        self._bufs = {}
+
+    def _torch_buf(self, key, n, is_int, device):
+        import torch
+        k = (key, is_int)
+        t = self._bufs.get(k)
+        if t is None or t.numel() < max(n, 1):
+            t = torch.empty(max(n, 1), dtype=torch.int32 if is_int else torch.float64, device=device)
+            self._bufs[k] = t
+        return t
+
+
+class LocalComm(CommBase):
+    """All blocks in this process; block i of the partition is domain.blocklist[i]."""
+
+    def allreduce_min(self, x):
+        return x
+
+    def halo_exchange(self, domain, names):
+        for (loc, is_int), ns in _group(names).items():
+            nf = len(ns)
+            if self.device:
+                import torch
+                dev = torch.device("cuda", torch.cuda.current_device())
+                sends, recvs = [], []
+                for i, b in enumerate(domain.blocklist):
+                    L = self.lists[i][loc]
+                    s = self._torch_buf(("s", i, loc), nf * L.send_idx.size, is_int, dev)
+                    r = self._torch_buf(("r", i, loc), nf * L.recv_idx.size, is_int, dev)
+                    b.ctx.halo_pack(LOC_ID[loc], ns, s.data_ptr())
+                    sends.append(s)
+                    recvs.append(r)
+                for b in domain.blocklist:
+                    b.ctx.sync()
+                for i in range(self.nblocks):
+                    Li = self.lists[i][loc]
+                    for p in range(self.nblocks):
+                        cnt = Li.recv_counts[p] * nf
+                        if cnt:
+                            Lp = self.lists[p][loc]
+                            ro, so = int(Li.recv_off[p]) * nf, int(Lp.send_off[i]) * nf
+                            recvs[i][ro:ro + cnt].copy_(sends[p][so:so + cnt])
+                torch.cuda.synchronize()
+                for i, b in enumerate(domain.blocklist):
+                    b.ctx.halo_unpack(LOC_ID[loc], ns, recvs[i].data_ptr())
+            else:
+                hf = [HostFields(b) for b in domain.blocklist]
+                sends = [hf[i].pack(self.lists[i][loc], ns, is_int) for i in range(self.nblocks)]
+                for i in range(self.nblocks):
+                    Li = self.lists[i][loc]
+                    r = np.empty(nf * Li.recv_idx.size, dtype=sends[i].dtype)
+                    for p in range(self.nblocks):
+                        cnt = Li.recv_counts[p] * nf
+                        if cnt:
+                            Lp = self.lists[p][loc]
+                            ro, so = int(Li.recv_off[p]) * nf, int(Lp.send_off[i]) * nf
+                            r[ro:ro + cnt] = sends[p][so:so + cnt]
+                    hf[i].unpack(Li, ns, r)
+
+
+class DistComm(CommBase):
+    """One block per process; neighbour exchange as a single all_to_all_single per field group."""
+
+    def __init__(self, domain, halo, nblocks, rank):
+        import torch.distributed as dist
+        assert len(domain.blocklist) == 1
+        self.rank = rank
+        self.dist = dist
+        super().__init__(domain, [halo], nblocks)
+
+    def allreduce_min(self, x):
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        if self.dist.get_backend() == "nccl":
+            t = t.cuda()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return float(t.item())
+
+    def halo_exchange(self, domain, names):
+        import torch
+        b = domain.blocklist[0]
+        for (loc, is_int), ns in _group(names).items():
+            L = self.lists[0][loc]
+            nf = len(ns)
+            send_split = [c * nf for c in L.send_counts]
+            recv_split = [c * nf for c in L.recv_counts]
+            ns_tot, nr_tot = nf * L.send_idx.size, nf * L.recv_idx.size
+            if self.device:
+                dev = torch.device("cuda", torch.cuda.current_device())
+                s = self._torch_buf(("s", loc), ns_tot, is_int, dev)
+                r = self._torch_buf(("r", loc), nr_tot, is_int, dev)
+                b.ctx.halo_pack(LOC_ID[loc], ns, s.data_ptr())
+                if self.dist.get_backend() == "gloo":
+                    # gloo moves host memory only: stage through the host with synchronous copies
+                    b.ctx.sync()
+                    sh = s[:ns_tot].cpu()
+                    rh = torch.empty(nr_tot, dtype=sh.dtype)
+                    self.dist.all_to_all_single(rh, sh, recv_split, send_split)
+                    r[:nr_tot].copy_(rh)
+                    torch.cuda.synchronize()
+                else:
+                    self.dist.all_to_all_single(r[:nr_tot], s[:ns_tot], recv_split, send_split)
+                b.ctx.halo_unpack(LOC_ID[loc], ns, r.data_ptr())
+            else:
+                hf = HostFields(b)
+                st = torch.from_numpy(hf.pack(L, ns, is_int))
+                rt = torch.empty(nr_tot, dtype=st.dtype)
+                self.dist.all_to_all_single(rt, st, recv_split, send_split)
+                hf.unpack(L, ns, rt.numpy())
+
+
+# ----------------------------------------------------------------------------------------------
+def make_partitioned_domain(mesh, name, nblocks, configs=None, only_block=None, **case_kw):
+    """Domain holding all blocks of the partition (only_block=None) or just one of them."""
+    meshes, halos = partition_mesh(mesh, nblocks)
+    if only_block is not None:
+        dom = cases.make_domain([meshes[only_block]], name, configs=configs, **case_kw)
+        return dom, halos[only_block], halos
+    dom = cases.make_domain(meshes, name, configs=configs, **case_kw)
+    return dom, halos, halos
+
+
+def gather_global(domains_blocks, halos, pool, name, n_global, loc):
+    """Assemble a global field from the owned parts of block fields (for comparisons)."""
+    first = domains_blocks[0].structs[pool][name]
+    lead = first.shape[:-1]
+    out = np.zeros(lead + (n_global,), dtype=first.dtype)
+    for b, h in zip(domains_blocks, halos):
+        nown = h.nOwned[loc]
+        out[..., h.globalID[loc][:nown]] = b.structs[pool][name][..., :nown]
+    return out
+
+
+def oracle_halo_callback(comm):
+    """Adapter: the oracle flow calls halo(domain, pool, names)."""
+    def halo(domain, pool, names):
+        comm.halo_exchange(domain, names)
+    return halo
+
+
+def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True):
+    """One block per rank over RCCL: K steps of nsub subcycles with a halo exchange each subcycle."""
+    import os
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    from . import velocity_solver as vs
+    if not dist.is_initialized():
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dom, halo, _ = make_partitioned_domain(mesh, name, world, configs={"config_elastic_subcycle_number": nsub},
+                                           only_block=rank)
+    vs.seaice_mesh_pool_create(dom, device=local_rank, renumber=renumber)
+    ctx = dom.blocklist[0].ctx
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    dom.comm = DistComm(dom, halo, world, rank)
+    vs.seaice_init_velocity_solver(dom)
+    for b in dom.blocklist:
+        vs._upload(dom, b)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    vs.velocity_solver_pre_subcycle(dom)
+    torch.cuda.synchronize()
+    pre_ms = (time.perf_counter() - t0) * 1e3
+
+    def step():
+        for _ in range(nsub):
+            ctx.subcycle(1, last=False)
+            dom.comm.halo_exchange(dom, ["uVelocity", "vVelocity"])
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+    t0 = time.perf_counter()
+    ctx.subcycle(1, last=True)
+    dom.comm.halo_exchange(dom, ["uVelocity", "vVelocity"])
+    vs.velocity_solver_post_subcycle(dom)
+    torch.cuda.synchronize()
+    post_ms = (time.perf_counter() - t0) * 1e3
+    _, cell_ms, vert_ms = ctx.subcycle_timed(8, use_graph=False, sample_every=1)
+    u = np.zeros(dom.blocklist[0].dimensions["nVertices"] + 1)
+    ctx.get("uVelocity", u)
+    ok = torch.tensor([1.0 if np.isfinite(u).all() else 0.0], device="cuda")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if ok.item() < 1.0:
+        raise SystemExit("non-finite velocities after the benchmark loop")
+    vs.seaice_mesh_pool_destroy(dom)
+    dist.barrier()
+    dist.destroy_process_group()
+    return {"wall": wall, "pre_ms": pre_ms, "post_ms": post_ms, "cell_ms": cell_ms, "vert_ms": vert_ms,
+            "n_cells_total": int(mesh.nCells)}

@@ -1,0 +1,80 @@
+"""Worker for the multi-process halo-exchange tests (launched by torch.distributed.run).
+
+mode cpu : every rank runs the CPU oracle flow on its own block, exchanging halos over gloo.
+mode gpu : every rank drives the HIP library on its own block (all ranks share GPU 0), exchanging
+           halos over gloo through host staging.
+Each rank also computes the single-block oracle answer and checks its owned entities against it.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from mpas_seaice_amd import cases, parallel  # noqa: E402
+from oracle import evp_flow as ora  # noqa: E402
+from util import get_mesh  # noqa: E402
+
+
+def main():
+    mode = sys.argv[1]
+    meshname = sys.argv[2] if len(sys.argv) > 2 else "geo8"
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ora.set_num_threads(2)
+    mesh = get_mesh(meshname)
+    cfg = {"config_elastic_subcycle_number": 12, "config_dt": 7200.0}
+    ref = cases.make_domain(mesh, None, configs=cfg, open_water_band=(-0.2, 0.3))
+    ora.seaice_init_velocity_solver(ref)
+    ora.seaice_run_velocity_solver(ref)
+    dom, halo, _ = parallel.make_partitioned_domain(mesh, None, world, configs=cfg, only_block=rank,
+                                                    open_water_band=(-0.2, 0.3))
+    if mode == "cpu":
+        comm = parallel.DistComm(dom, halo, world, rank)
+        dom.halo = parallel.oracle_halo_callback(comm)
+        dom.allreduce_min = comm.allreduce_min
+        ora.seaice_init_velocity_solver(dom)
+        ora.seaice_run_velocity_solver(dom)
+        tol = 0.0
+    else:
+        from mpas_seaice_amd import velocity_solver as vs
+        torch.cuda.set_device(0)
+        vs.seaice_mesh_pool_create(dom, device=0)
+        dom.comm = parallel.DistComm(dom, halo, world, rank)
+        vs.seaice_init_velocity_solver(dom)
+        vs.seaice_run_velocity_solver(dom)
+        vs.seaice_mesh_pool_destroy(dom)
+        tol = 1e-10
+    b = dom.blocklist[0]
+    rb = ref.blocklist[0]
+    worst = 0.0
+    for pool, name, loc in (("velocity_solver", "uVelocity", "vertex"), ("velocity_solver", "vVelocity", "vertex"),
+                            ("velocity_variational", "stress11", "cell"), ("velocity_variational", "stress12", "cell"),
+                            ("velocity_solver", "oceanStressCellU", "cell"), ("velocity_solver", "divergence", "cell"),
+                            ("velocity_solver", "solveVelocity", "vertex")):
+        nown = halo.nOwned[loc]
+        g = halo.globalID[loc][:nown]
+        mine = b.structs[pool][name][..., :nown]
+        theirs = rb.structs[pool][name][..., g]
+        den = max(np.abs(theirs).max(), 1e-300)
+        err = float(np.abs(mine.astype(np.float64) - theirs).max() / den)
+        worst = max(worst, err)
+        assert err <= tol, (rank, name, err)
+    # halo copies of the velocities must equal the owners' values too
+    gv = halo.globalID["vertex"]
+    u = b.structs["velocity_solver"]["uVelocity"][:len(gv)]
+    err = float(np.abs(u - rb.structs["velocity_solver"]["uVelocity"][gv]).max())
+    assert err <= tol * max(np.abs(u).max(), 1e-300) + 0.0, (rank, "halo u", err)
+    print(f"rank {rank}/{world} mode {mode}: ok, worst rel err {worst:.2e}", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

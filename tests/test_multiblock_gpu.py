@@ -1,0 +1,58 @@
+"""Several MPAS blocks driven through the HIP library: halo pack/unpack and the staged pre/post-cycle."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from mpas_seaice_amd import cases, parallel, velocity_solver as vs
+from util import get_mesh
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-10
+
+
+@pytest.mark.parametrize("nblocks", [2, 4])
+def test_blocks_on_one_gpu_match_single_block_oracle(oracle, nblocks):
+    mesh = get_mesh("QU480")
+    cfg = {"config_elastic_subcycle_number": 40}
+    ref = cases.make_domain(mesh, "QU480", configs=cfg, open_water_band=(-0.2, 0.3))
+    oracle.seaice_init_velocity_solver(ref)
+    oracle.seaice_run_velocity_solver(ref)
+    dom, halos, _ = parallel.make_partitioned_domain(mesh, "QU480", nblocks, configs=cfg,
+                                                     open_water_band=(-0.2, 0.3))
+    vs.seaice_mesh_pool_create(dom, device=0)
+    try:
+        dom.comm = parallel.LocalComm(dom, halos, nblocks)
+        vs.seaice_init_velocity_solver(dom)
+        vs.seaice_run_velocity_solver(dom)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+    for pool, name, loc, n in (("velocity_solver", "uVelocity", "vertex", mesh.nVertices),
+                               ("velocity_solver", "vVelocity", "vertex", mesh.nVertices),
+                               ("velocity_variational", "stress11", "cell", mesh.nCells),
+                               ("velocity_variational", "stress12", "cell", mesh.nCells),
+                               ("velocity_solver", "divergence", "cell", mesh.nCells),
+                               ("velocity_solver", "oceanStressCellU", "cell", mesh.nCells),
+                               ("velocity_solver", "solveVelocity", "vertex", mesh.nVertices)):
+        g = parallel.gather_global(dom.blocklist, halos, pool, name, n, loc).astype(np.float64)
+        r = ref.blocklist[0].structs[pool][name][..., :n].astype(np.float64)
+        err = np.abs(g - r).max() / max(np.abs(r).max(), 1e-300)
+        assert err <= TOL, (name, err)
+
+
+def test_two_ranks_sharing_the_gpu_over_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "dist_worker.py"), "gpu", "geo8"]
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.count(": ok") == 2, out.stdout

@@ -1,0 +1,128 @@
+"""The CPU oracle against the analytic known answers of the reference's idealised test cases
+and against invariants of the variational scheme (no golden vectors exist in the reference)."""
+import numpy as np
+import pytest
+
+import analytic
+from mpas_seaice_amd import cases, mesh as meshmod
+from mpas_seaice_amd.cases import rotated_lonlat
+from util import get_mesh
+
+
+def test_analytic_restatements_match_reference_samples():
+    s = analytic.SPHERE_SAMPLE
+    got = analytic.velocities_strains_analytical(s["lat"], s["lon"])
+    for g, k in zip(got, ("u", "v", "e11", "e22", "e12")):
+        assert abs(g - s[k]) < 5e-11 * max(1.0, abs(s[k])), k
+    p = analytic.PLANE_SAMPLE
+    got = analytic.planar_fields(p["x"], p["y"])
+    for g, k in zip(got, ("u", "v", "e11", "e22", "e12", "divu", "divv")):
+        assert abs(g - p[k]) < 5e-11 * max(1.0, abs(p[k])), k
+
+
+def _init(oracle, mesh, configs=None):
+    dom = cases.make_domain(mesh, None, configs=configs)
+    oracle.seaice_init_velocity_solver(dom)
+    return dom
+
+
+def _strain(oracle, dom, u, v):
+    b = dom.blocklist[0]
+    d, m, vv = b.dimensions, b.structs["mesh"], b.structs["velocity_variational"]
+    nC, nV, M = d["nCells"], d["nVertices"], d["maxEdges"]
+    uu = np.zeros(nV + 1)
+    vw = np.zeros(nV + 1)
+    uu[:nV], vw[:nV] = u, v
+    ss = np.ones(nC + 1, dtype=np.int32)
+    e11, e22, e12 = (np.zeros((M, nC + 1), order="F") for _ in range(3))
+    oracle.call("ora_strain_tensor_variational", nC, M, m["nEdgesOnCell"], m["verticesOnCell"], e11, e22, e12, uu, vw,
+                vv["basisGradientU"], vv["basisGradientV"], vv["tanLatVertexRotatedOverRadius"], ss)
+    return e11, e22, e12
+
+
+def sphere_strain_error(oracle, n):
+    mesh = meshmod.make_sphere_mesh(n, radius=1.0)
+    dom = _init(oracle, mesh)
+    b = dom.blocklist[0]
+    m = b.structs["mesh"]
+    nC, nV = mesh.nCells, mesh.nVertices
+    lon, lat = rotated_lonlat(m["xVertex"][:nV], m["yVertex"][:nV], m["zVertex"][:nV], 1.0)
+    u, v, a11, a22, a12 = analytic.velocities_strains_analytical(lat, lon)
+    e11, e22, e12 = _strain(oracle, dom, u, v)
+    voc = m["verticesOnCell"].astype(np.int64) - 1
+    err2, nrm2 = 0.0, 0.0
+    for i in range(mesh.maxEdges):
+        act = (m["nEdgesOnCell"][:nC] > i)
+        vi = voc[i, :nC][act]
+        keep = np.abs(lat[vi]) < np.deg2rad(70.0)  # the reference's norm also stays away from the grid poles
+        for e, a in ((e11, a11), (e22, a22), (e12, a12)):
+            err2 += ((e[i, :nC][act][keep] - a[vi][keep]) ** 2).sum()
+            nrm2 += (a[vi][keep] ** 2).sum()
+    return np.sqrt(err2 / nrm2)
+
+
+def test_sphere_strain_converges_to_spherical_harmonic_answer(oracle):
+    e8, e16, e32 = (sphere_strain_error(oracle, n) for n in (8, 16, 32))
+    assert e32 < e16 < e8
+    assert e32 < 0.08
+    # at least first-order convergence of the L2 norm under mesh refinement
+    assert np.log2(e16 / e32) > 0.9, (e8, e16, e32)
+
+
+def test_planar_operators_linear_exact_and_sinusoid_converges(oracle):
+    errs = []
+    for nx in (16, 32):
+        mesh = meshmod.make_planar_hex_mesh(nx, nx, 1.0 / nx)
+        dom = _init(oracle, mesh, {"config_include_metric_terms": False})
+        b = dom.blocklist[0]
+        m = b.structs["mesh"]
+        nC, nV = mesh.nCells, mesh.nVertices
+        x, y = m["xVertex"][:nV], m["yVertex"][:nV]
+        # linear field: the Wachspress gradient is exact
+        u, v, a11, a22, a12, _, _ = analytic.planar_fields(x, y, "linear")
+        e11, e22, e12 = _strain(oracle, dom, u, v)
+        assert np.abs(e11[:, :nC] - 1.0).max() < 1e-11
+        assert np.abs(e22[:, :nC] - 1.0).max() < 1e-11
+        assert np.abs(e12[:, :nC]).max() < 1e-11
+        u, v, a11, a22, a12, du, dv = analytic.planar_fields(x, y, "sinusoid", A=1.0)
+        e11, e22, e12 = _strain(oracle, dom, u, v)
+        voc = m["verticesOnCell"].astype(np.int64) - 1
+        err = max(np.abs(e11[i, :nC] - a11[voc[i, :nC]]).max() for i in range(6)) / np.abs(a11).max()
+        errs.append(err)
+    assert errs[1] < 0.6 * errs[0]
+
+
+def test_basis_invariants(oracle):
+    mesh = get_mesh("QU480")
+    dom = _init(oracle, mesh)
+    b = dom.blocklist[0]
+    vv = b.structs["velocity_variational"]
+    nC = mesh.nCells
+    gU, gV = vv["basisGradientU"][:, :, :nC], vv["basisGradientV"][:, :, :nC]
+    scale = np.abs(gU).max()
+    # partition of unity: the basis gradients sum to zero at every corner
+    assert np.abs(gU.sum(axis=0)).max() < 1e-12 * scale
+    assert np.abs(gV.sum(axis=0)).max() < 1e-12 * scale
+    # only the basis vertex and its two neighbours carry a gradient (wachspress.F:1178-1191)
+    nz = (gU != 0).sum(axis=0)
+    assert nz.max() == 3
+    SU, SM = vv["basisIntegralsU"][:, :, :nC], vv["basisIntegralsMetric"][:, :, :nC]
+    # sum_j dN_j/dx = 0 under the integral, and sum_sj int N_s N_j = planar cell area ~ areaCell
+    assert np.abs(SU.sum(axis=1)).max() < 1e-9 * np.abs(SU).max()
+    rel = np.abs(SM.sum(axis=(0, 1)) / mesh["areaCell"] - 1.0).max()
+    assert rel < 5e-3
+    # metric integrals are symmetric up to rounding
+    assert np.abs(SM - SM.transpose(1, 0, 2)).max() < 1e-12 * np.abs(SM).max()
+
+
+def test_full_step_is_finite_and_deterministic(oracle):
+    mesh = get_mesh("geo8")
+    out = []
+    for threads in (1, 4):
+        oracle.set_num_threads(threads)
+        dom = cases.make_domain(mesh, None, configs={"config_dt": 7200.0})
+        oracle.seaice_init_velocity_solver(dom)
+        oracle.seaice_run_velocity_solver(dom)
+        out.append(dom.blocklist[0].structs["velocity_solver"]["uVelocity"].copy())
+    assert np.isfinite(out[0]).all() and np.abs(out[0]).max() > 1e-3
+    assert np.array_equal(out[0], out[1])

@@ -1,0 +1,75 @@
+"""Block decomposition + halo exchange, on the CPU: bit-identical to the single-block answer."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from mpas_seaice_amd import cases, parallel, partition
+from util import get_mesh
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_partition_structure():
+    mesh = get_mesh("geo8")
+    meshes, halos = partition.partition_mesh(mesh, 3)
+    assert sum(m.nCellsSolve for m in meshes) == mesh.nCells
+    assert sum(m.nVerticesSolve for m in meshes) == mesh.nVertices
+    assert sum(m.nEdgesSolve for m in meshes) == mesh.nEdges
+    for r, (m, h) in enumerate(zip(meshes, halos)):
+        # every owned vertex sees its three cells inside the block
+        cov = m["cellsOnVertex"][:, :m.nVerticesSolve]
+        assert (cov <= m.nCells).all()
+        # send / recv lists pair up
+        for loc in ("cell", "vertex", "edge"):
+            for p, idx in h.recv[loc].items():
+                other = halos[p].send[loc][r]
+                assert len(other) == len(idx)
+                assert np.array_equal(h.globalID[loc][idx - 1], halos[p].globalID[loc][other - 1])
+                assert (idx > h.nOwned[loc]).all() and (other <= halos[p].nOwned[loc]).all()
+
+
+@pytest.mark.parametrize("nblocks", [2, 5])
+def test_multiblock_oracle_flow_is_bit_identical(oracle, nblocks):
+    mesh = get_mesh("geo8")
+    cfg = {"config_elastic_subcycle_number": 15, "config_dt": 7200.0}
+    ref = cases.make_domain(mesh, None, configs=cfg, open_water_band=(-0.2, 0.3))
+    oracle.seaice_init_velocity_solver(ref)
+    oracle.seaice_run_velocity_solver(ref)
+    dom, halos, _ = parallel.make_partitioned_domain(mesh, None, nblocks, configs=cfg, open_water_band=(-0.2, 0.3))
+    comm = parallel.LocalComm(dom, halos, nblocks)
+    dom.halo = parallel.oracle_halo_callback(comm)
+    dom.allreduce_min = comm.allreduce_min
+    oracle.seaice_init_velocity_solver(dom)
+    oracle.seaice_run_velocity_solver(dom)
+    for pool, name, loc, n in (("velocity_solver", "uVelocity", "vertex", mesh.nVertices),
+                               ("velocity_solver", "vVelocity", "vertex", mesh.nVertices),
+                               ("velocity_variational", "stress22", "cell", mesh.nCells),
+                               ("velocity_solver", "shear", "cell", mesh.nCells),
+                               ("velocity_solver", "oceanStressCellV", "cell", mesh.nCells)):
+        g = parallel.gather_global(dom.blocklist, halos, pool, name, n, loc)
+        r = ref.blocklist[0].structs[pool][name][..., :n]
+        assert np.array_equal(g, r), name
+
+
+def test_two_process_gloo_halo_exchange():
+    """world_size 2 over gloo: each rank owns one block and runs the oracle flow on it."""
+    port = free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "dist_worker.py"), "cpu", "geo8"]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.count(": ok") == 2, out.stdout
