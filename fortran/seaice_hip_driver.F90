@@ -1,0 +1,200 @@
+!> Stand-alone Fortran host for one MPAS block: the orchestration that, inside MPAS-Seaice, lives in the
+!> ISO_C_BINDING shim modules replacing seaice_init_velocity_solver / seaice_run_velocity_solver
+!> (src/shared/mpas_seaice_velocity_solver.F:85, 562 of the reference).  Pool arrays are plain Fortran
+!> arrays with the Registry dimensions (src/Registry.xml:2251-2367, 2439-2524, 3691-3765); they are handed
+!> to the C ABI with c_loc, exactly as the shim hands the framework's pool arrays.
+!>
+!> usage: seaice_hip_driver <case file> <result file>
+!> The case file is a raw little-endian stream written by mpas_seaice_amd/fortran_case.py.
+program seaice_hip_driver
+
+  use iso_c_binding
+  use seaice_hip_interface
+
+  implicit none
+
+  integer, parameter :: RKIND = c_double
+
+  character(len=1024) :: caseFile, resultFile
+  integer :: iu, ou, ierr
+  integer(c_int32_t) :: nCells, nVertices, nEdges, maxEdges, nCategories, nSubcycles, onASphere, vertexDegree
+  real(kind=RKIND) :: sphereRadius, config_dt
+
+  ! mesh pool
+  integer(c_int32_t), dimension(:), allocatable, target :: nEdgesOnCell
+  integer(c_int32_t), dimension(:,:), allocatable, target :: verticesOnCell, cellsOnCell, edgesOnCell, &
+       cellsOnVertex, cellsOnEdge, verticesOnEdge
+  real(kind=RKIND), dimension(:), allocatable, target :: xCell, yCell, zCell, xVertex, yVertex, zVertex, &
+       areaCell, areaTriangle, fVertex, dvEdge, dcEdge
+  ! tracers, forcing
+  real(kind=RKIND), dimension(:,:,:), allocatable, target :: iceAreaCategory, iceVolumeCategory, snowVolumeCategory
+  real(kind=RKIND), dimension(:), allocatable, target :: uOceanVelocity, vOceanVelocity, uAirVelocity, &
+       vAirVelocity, airDensity
+  ! velocity_solver / velocity_variational pools
+  real(kind=RKIND), dimension(:), allocatable, target :: uVelocity, vVelocity, divergence, shear
+  real(kind=RKIND), dimension(:,:), allocatable, target :: stress11, stress22, stress12
+  integer(c_int32_t), dimension(:), allocatable, target :: solveVelocityPrevious
+
+  type(sih_mesh_desc) :: mesh
+  type(sih_evp_config) :: cfg
+  type(c_ptr) :: ctx
+
+  if (command_argument_count() < 2) then
+     write(*,*) "usage: seaice_hip_driver <case file> <result file>"
+     stop 2
+  endif
+  call get_command_argument(1, caseFile)
+  call get_command_argument(2, resultFile)
+
+  open(newunit=iu, file=trim(caseFile), access="stream", form="unformatted", status="old")
+  read(iu) nCells, nVertices, nEdges, maxEdges, nCategories, nSubcycles, onASphere
+  read(iu) sphereRadius, config_dt
+  vertexDegree = 3
+
+  allocate(nEdgesOnCell(nCells))
+  allocate(verticesOnCell(maxEdges,nCells), cellsOnCell(maxEdges,nCells), edgesOnCell(maxEdges,nCells))
+  allocate(cellsOnVertex(vertexDegree,nVertices), cellsOnEdge(2,nEdges), verticesOnEdge(2,nEdges))
+  allocate(xCell(nCells), yCell(nCells), zCell(nCells), areaCell(nCells))
+  allocate(xVertex(nVertices), yVertex(nVertices), zVertex(nVertices), areaTriangle(nVertices), fVertex(nVertices))
+  allocate(dvEdge(nEdges), dcEdge(nEdges))
+  allocate(iceAreaCategory(1,nCategories,nCells), iceVolumeCategory(1,nCategories,nCells), &
+           snowVolumeCategory(1,nCategories,nCells))
+  allocate(uOceanVelocity(nCells), vOceanVelocity(nCells), uAirVelocity(nCells), vAirVelocity(nCells), &
+           airDensity(nCells))
+  allocate(uVelocity(nVertices), vVelocity(nVertices), solveVelocityPrevious(nVertices))
+  allocate(stress11(maxEdges,nCells), stress22(maxEdges,nCells), stress12(maxEdges,nCells))
+  allocate(divergence(nCells), shear(nCells))
+
+  read(iu) nEdgesOnCell, verticesOnCell, cellsOnCell, edgesOnCell, cellsOnVertex, cellsOnEdge, verticesOnEdge
+  read(iu) xCell, yCell, zCell, xVertex, yVertex, zVertex, areaCell, areaTriangle, fVertex, dvEdge, dcEdge
+  read(iu) iceAreaCategory, iceVolumeCategory, snowVolumeCategory
+  read(iu) uOceanVelocity, vOceanVelocity, uAirVelocity, vAirVelocity, airDensity
+  close(iu)
+
+  uVelocity = 0.0_RKIND
+  vVelocity = 0.0_RKIND
+  solveVelocityPrevious = 0
+  stress11 = 0.0_RKIND
+  stress22 = 0.0_RKIND
+  stress12 = 0.0_RKIND
+
+  ! ---- seaice_mesh_pool_create ---------------------------------------------------------------
+  mesh % nCells = nCells;       mesh % nCellsSolve = nCells
+  mesh % nVertices = nVertices; mesh % nVerticesSolve = nVertices
+  mesh % nEdges = nEdges;       mesh % nEdgesSolve = nEdges
+  mesh % maxEdges = maxEdges;   mesh % vertexDegree = vertexDegree
+  mesh % onASphere = onASphere; mesh % sphereRadius = sphereRadius
+  mesh % nEdgesOnCell = c_loc(nEdgesOnCell);     mesh % verticesOnCell = c_loc(verticesOnCell)
+  mesh % cellsOnCell = c_loc(cellsOnCell);       mesh % edgesOnCell = c_loc(edgesOnCell)
+  mesh % cellsOnVertex = c_loc(cellsOnVertex);   mesh % cellsOnEdge = c_loc(cellsOnEdge)
+  mesh % verticesOnEdge = c_loc(verticesOnEdge)
+  mesh % xCell = c_loc(xCell); mesh % yCell = c_loc(yCell); mesh % zCell = c_loc(zCell)
+  mesh % xVertex = c_loc(xVertex); mesh % yVertex = c_loc(yVertex); mesh % zVertex = c_loc(zVertex)
+  mesh % areaCell = c_loc(areaCell); mesh % areaTriangle = c_loc(areaTriangle); mesh % fVertex = c_loc(fVertex)
+  mesh % dvEdge = c_loc(dvEdge); mesh % dcEdge = c_loc(dcEdge)
+  mesh % renumber = 1
+  call check(sih_block_create(mesh, 0_c_int, ctx), "sih_block_create")
+
+  ! ---- seaice_init_velocity_solver ------------------------------------------------------------
+  cfg % dt = config_dt
+  cfg % dynamicsSubcycleNumber = 1
+  cfg % elasticSubcycleNumber = nSubcycles
+  cfg % constitutiveRelation = 1        ! config_constitutive_relation_type = 'evp'
+  cfg % variationalBasis = 1            ! config_variational_basis = 'wachspress'
+  cfg % variationalDenominator = 0      ! 'original'
+  cfg % wachspressIntegrationOrder = 8
+  cfg % rotateCartesianGrid = 1
+  cfg % includeMetricTerms = 1
+  cfg % useAirStress = 1
+  cfg % useOceanStress = 1
+  cfg % oceanStressType = 1             ! 'quadratic'
+  cfg % surfaceTilt = 1                 ! geostrophic
+  cfg % calcVelocityMasks = 1
+  cfg % useColumnPackage = 0
+  cfg % nCategories = nCategories
+  cfg % minEdgeLengthGlobal = 0.0_RKIND
+  call check(sih_evp_init(ctx, cfg), "sih_evp_init")
+
+  ! ---- seaice_run_velocity_solver -------------------------------------------------------------
+  call put_r3("iceAreaCategory", iceAreaCategory)
+  call put_r3("iceVolumeCategory", iceVolumeCategory)
+  call put_r3("snowVolumeCategory", snowVolumeCategory)
+  call put_r1("uOceanVelocity", uOceanVelocity)
+  call put_r1("vOceanVelocity", vOceanVelocity)
+  call put_r1("uAirVelocity", uAirVelocity)
+  call put_r1("vAirVelocity", vAirVelocity)
+  call put_r1("airDensity", airDensity)
+  call put_r1("uVelocity", uVelocity)
+  call put_r1("vVelocity", vVelocity)
+  call put_i1("solveVelocityPrevious", solveVelocityPrevious)
+  call put_r2("stress11", stress11)
+  call put_r2("stress22", stress22)
+  call put_r2("stress12", stress12)
+
+  call check(sih_evp_run(ctx), "sih_evp_run")
+
+  call get_r1("uVelocity", uVelocity)
+  call get_r1("vVelocity", vVelocity)
+  call get_r2("stress11", stress11)
+  call get_r2("stress22", stress22)
+  call get_r2("stress12", stress12)
+  call get_r1("divergence", divergence)
+  call get_r1("shear", shear)
+
+  open(newunit=ou, file=trim(resultFile), access="stream", form="unformatted", status="replace")
+  write(ou) uVelocity, vVelocity, stress11, stress22, stress12, divergence, shear
+  close(ou)
+
+  ! ---- seaice_mesh_pool_destroy ---------------------------------------------------------------
+  call check(sih_block_destroy(ctx), "sih_block_destroy")
+  write(*,'(a,es23.15)') "seaice_hip_driver ok, max|uVelocity| = ", maxval(abs(uVelocity))
+
+contains
+
+  subroutine check(ierr, what)
+    integer(c_int), intent(in) :: ierr
+    character(len=*), intent(in) :: what
+    if (ierr /= SIH_OK) then
+       ! the reference would issue MPAS_LOG_CRIT here
+       write(*,*) "CRITICAL ERROR in ", what, ": ", sih_error_message()
+       stop 1
+    endif
+  end subroutine check
+
+  subroutine put_r1(name, a)
+    character(len=*), intent(in) :: name
+    real(kind=RKIND), dimension(:), intent(in), target, contiguous :: a
+    call check(sih_field_put(ctx, name//c_null_char, c_loc(a), int(size(a), c_size_t)), "put "//name)
+  end subroutine put_r1
+
+  subroutine put_r2(name, a)
+    character(len=*), intent(in) :: name
+    real(kind=RKIND), dimension(:,:), intent(in), target, contiguous :: a
+    call check(sih_field_put(ctx, name//c_null_char, c_loc(a), int(size(a), c_size_t)), "put "//name)
+  end subroutine put_r2
+
+  subroutine put_r3(name, a)
+    character(len=*), intent(in) :: name
+    real(kind=RKIND), dimension(:,:,:), intent(in), target, contiguous :: a
+    call check(sih_field_put(ctx, name//c_null_char, c_loc(a), int(size(a), c_size_t)), "put "//name)
+  end subroutine put_r3
+
+  subroutine put_i1(name, a)
+    character(len=*), intent(in) :: name
+    integer(c_int32_t), dimension(:), intent(in), target, contiguous :: a
+    call check(sih_field_put(ctx, name//c_null_char, c_loc(a), int(size(a), c_size_t)), "put "//name)
+  end subroutine put_i1
+
+  subroutine get_r1(name, a)
+    character(len=*), intent(in) :: name
+    real(kind=RKIND), dimension(:), intent(inout), target, contiguous :: a
+    call check(sih_field_get(ctx, name//c_null_char, c_loc(a), int(size(a), c_size_t)), "get "//name)
+  end subroutine get_r1
+
+  subroutine get_r2(name, a)
+    character(len=*), intent(in) :: name
+    real(kind=RKIND), dimension(:,:), intent(inout), target, contiguous :: a
+    call check(sih_field_get(ctx, name//c_null_char, c_loc(a), int(size(a), c_size_t)), "get "//name)
+  end subroutine get_r2
+
+end program seaice_hip_driver

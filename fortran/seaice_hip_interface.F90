@@ -1,0 +1,211 @@
+!> ISO_C_BINDING view of include/seaice_hip.h: the interface a Fortran host (the MPAS-Seaice shim) uses
+!> to drive libseaice_hip.  Names, argument order and struct layouts mirror the C header one to one.
+module seaice_hip_interface
+
+  use iso_c_binding
+
+  implicit none
+
+  public
+
+  integer(c_int), parameter :: SIH_OK = 0, SIH_ERR_ARG = 1, SIH_ERR_HIP = 2, SIH_ERR_STATE = 3, &
+                               SIH_ERR_UNSUPPORTED = 4
+
+  !> struct sih_mesh_desc
+  type, bind(C) :: sih_mesh_desc
+     integer(c_int32_t) :: nCells, nCellsSolve
+     integer(c_int32_t) :: nVertices, nVerticesSolve
+     integer(c_int32_t) :: nEdges, nEdgesSolve
+     integer(c_int32_t) :: maxEdges, vertexDegree
+     integer(c_int32_t) :: onASphere
+     real(c_double)     :: sphereRadius
+     type(c_ptr) :: nEdgesOnCell, verticesOnCell, cellsOnCell, edgesOnCell
+     type(c_ptr) :: cellsOnVertex, cellsOnEdge, verticesOnEdge
+     type(c_ptr) :: xCell, yCell, zCell
+     type(c_ptr) :: xVertex, yVertex, zVertex
+     type(c_ptr) :: areaCell, areaTriangle, fVertex
+     type(c_ptr) :: dvEdge, dcEdge
+     integer(c_int32_t) :: renumber
+  end type sih_mesh_desc
+
+  !> struct sih_evp_config
+  type, bind(C) :: sih_evp_config
+     real(c_double)     :: dt
+     integer(c_int32_t) :: dynamicsSubcycleNumber, elasticSubcycleNumber
+     integer(c_int32_t) :: constitutiveRelation, variationalBasis, variationalDenominator
+     integer(c_int32_t) :: wachspressIntegrationOrder
+     integer(c_int32_t) :: rotateCartesianGrid, includeMetricTerms
+     integer(c_int32_t) :: useAirStress, useOceanStress, oceanStressType, surfaceTilt
+     integer(c_int32_t) :: calcVelocityMasks, useColumnPackage, nCategories
+     real(c_double)     :: minEdgeLengthGlobal
+  end type sih_evp_config
+
+  interface
+
+     function sih_block_create(mesh, device, ctx) bind(C, name="sih_block_create") result(ierr)
+       import :: sih_mesh_desc, c_int, c_ptr
+       type(sih_mesh_desc), intent(in) :: mesh
+       integer(c_int), value :: device
+       type(c_ptr), intent(out) :: ctx
+       integer(c_int) :: ierr
+     end function sih_block_create
+
+     function sih_block_destroy(ctx) bind(C, name="sih_block_destroy") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int) :: ierr
+     end function sih_block_destroy
+
+     function sih_last_error() bind(C, name="sih_last_error") result(msg)
+       import :: c_ptr
+       type(c_ptr) :: msg
+     end function sih_last_error
+
+     function sih_set_stream(ctx, hipStream) bind(C, name="sih_set_stream") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, hipStream
+       integer(c_int) :: ierr
+     end function sih_set_stream
+
+     function sih_sync(ctx) bind(C, name="sih_sync") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int) :: ierr
+     end function sih_sync
+
+     function sih_evp_init(ctx, cfg) bind(C, name="sih_evp_init") result(ierr)
+       import :: sih_evp_config, c_int, c_ptr
+       type(c_ptr), value :: ctx
+       type(sih_evp_config), intent(in) :: cfg
+       integer(c_int) :: ierr
+     end function sih_evp_init
+
+     function sih_evp_static_changed(ctx) bind(C, name="sih_evp_static_changed") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int) :: ierr
+     end function sih_evp_static_changed
+
+     function sih_field_put(ctx, name, host, count) bind(C, name="sih_field_put") result(ierr)
+       import :: c_int, c_ptr, c_char, c_size_t
+       type(c_ptr), value :: ctx
+       character(kind=c_char), dimension(*), intent(in) :: name
+       type(c_ptr), value :: host
+       integer(c_size_t), value :: count
+       integer(c_int) :: ierr
+     end function sih_field_put
+
+     function sih_field_get(ctx, name, host, count) bind(C, name="sih_field_get") result(ierr)
+       import :: c_int, c_ptr, c_char, c_size_t
+       type(c_ptr), value :: ctx
+       character(kind=c_char), dimension(*), intent(in) :: name
+       type(c_ptr), value :: host
+       integer(c_size_t), value :: count
+       integer(c_int) :: ierr
+     end function sih_field_get
+
+     function sih_field_count(ctx, name, elemSize) bind(C, name="sih_field_count") result(n)
+       import :: c_int, c_ptr, c_char, c_size_t
+       type(c_ptr), value :: ctx
+       character(kind=c_char), dimension(*), intent(in) :: name
+       integer(c_int), intent(out) :: elemSize
+       integer(c_size_t) :: n
+     end function sih_field_count
+
+     function sih_evp_pre_subcycle(ctx, stage) bind(C, name="sih_evp_pre_subcycle") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: stage
+       integer(c_int) :: ierr
+     end function sih_evp_pre_subcycle
+
+     function sih_evp_subcycle(ctx, n, last) bind(C, name="sih_evp_subcycle") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n, last
+       integer(c_int) :: ierr
+     end function sih_evp_subcycle
+
+     function sih_evp_post_subcycle(ctx, stage) bind(C, name="sih_evp_post_subcycle") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: stage
+       integer(c_int) :: ierr
+     end function sih_evp_post_subcycle
+
+     function sih_evp_run(ctx) bind(C, name="sih_evp_run") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int) :: ierr
+     end function sih_evp_run
+
+     function sih_evp_subcycle_timed(ctx, n, useGraph, sampleEvery, totalMs, cellMs, vertexMs) &
+          bind(C, name="sih_evp_subcycle_timed") result(ierr)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n, useGraph, sampleEvery
+       real(c_double), intent(out) :: totalMs, cellMs, vertexMs
+       integer(c_int) :: ierr
+     end function sih_evp_subcycle_timed
+
+     function sih_halo_set_lists(ctx, location, nSend, sendIdx, nRecv, recvIdx, nPeers, sendCounts, recvCounts) &
+          bind(C, name="sih_halo_set_lists") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: location, nSend, nRecv, nPeers
+       type(c_ptr), value :: sendIdx, recvIdx, sendCounts, recvCounts
+       integer(c_int) :: ierr
+     end function sih_halo_set_lists
+
+     function sih_halo_pack(ctx, location, nFields, names, deviceBuf) bind(C, name="sih_halo_pack") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: location, nFields
+       type(c_ptr), dimension(*), intent(in) :: names
+       type(c_ptr), value :: deviceBuf
+       integer(c_int) :: ierr
+     end function sih_halo_pack
+
+     function sih_halo_unpack(ctx, location, nFields, names, deviceBuf) bind(C, name="sih_halo_unpack") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: location, nFields
+       type(c_ptr), dimension(*), intent(in) :: names
+       type(c_ptr), value :: deviceBuf
+       integer(c_int) :: ierr
+     end function sih_halo_unpack
+
+     function sih_get_info(ctx, key, value) bind(C, name="sih_get_info") result(ierr)
+       import :: c_int, c_ptr, c_char, c_double
+       type(c_ptr), value :: ctx
+       character(kind=c_char), dimension(*), intent(in) :: key
+       real(c_double), intent(out) :: value
+       integer(c_int) :: ierr
+     end function sih_get_info
+
+  end interface
+
+contains
+
+  !> sih_last_error() as a Fortran string
+  function sih_error_message() result(msg)
+    character(len=:), allocatable :: msg
+    type(c_ptr) :: p
+    character(kind=c_char), dimension(:), pointer :: s
+    integer :: n, i
+    p = sih_last_error()
+    msg = ""
+    if (.not. c_associated(p)) return
+    call c_f_pointer(p, s, [1024])
+    n = 0
+    do while (n < 1024)
+       if (s(n+1) == c_null_char) exit
+       n = n + 1
+    enddo
+    allocate(character(len=n) :: msg)
+    do i = 1, n
+       msg(i:i) = s(i)
+    enddo
+  end function sih_error_message
+
+end module seaice_hip_interface

@@ -1,0 +1,41 @@
+"""The Fortran host (ISO_C_BINDING interface module + driver, built with amdflang) drives the C ABI."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from mpas_seaice_amd import cases, fortran_case
+from util import get_mesh
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "fortran", "seaice_hip_driver")
+
+
+def test_fortran_driver_matches_oracle(oracle, tmp_path):
+    if not os.path.exists(EXE):
+        pytest.fail("fortran/seaice_hip_driver is not built (run __graft_entry__.build())")
+    mesh = get_mesh("QU480")
+    cfg = {"config_elastic_subcycle_number": 60}
+    ref = cases.make_domain(mesh, "QU480", configs=cfg)
+    case = str(tmp_path / "case.bin")
+    res = str(tmp_path / "result.bin")
+    fortran_case.write_case(case, ref.blocklist[0], ref.configs)
+    oracle.seaice_init_velocity_solver(ref)
+    oracle.seaice_run_velocity_solver(ref)
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib/llvm/lib:/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    out = subprocess.run([EXE, case, res], capture_output=True, text=True, timeout=200, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "seaice_hip_driver ok" in out.stdout
+    got = fortran_case.read_result(res, ref.blocklist[0])
+    b = ref.blocklist[0]
+    nC, nV = mesh.nCells, mesh.nVertices
+    for name, pool, n in (("uVelocity", "velocity_solver", nV), ("vVelocity", "velocity_solver", nV),
+                          ("stress11", "velocity_variational", nC), ("stress22", "velocity_variational", nC),
+                          ("stress12", "velocity_variational", nC), ("divergence", "velocity_solver", nC),
+                          ("shear", "velocity_solver", nC)):
+        r = b.structs[pool][name][..., :n]
+        err = np.abs(got[name] - r).max() / np.abs(r).max()
+        assert err <= 1e-10, (name, err)
