@@ -140,14 +140,16 @@ def main():
                                        renumber=not args.no_renumber)
         wall, pre_ms, post_ms, cell_ms, vert_ms, n_cells_total = (res[k] for k in (
             "wall", "pre_ms", "post_ms", "cell_ms", "vert_ms", "n_cells_total"))
-        parallelism = f"{world} MPAS blocks, one per GPU, halo exchange of uVelocity/vVelocity every subcycle"
+        parallelism = (f"{world} MPAS blocks, one per GPU, {res['interval']} halo layers, RCCL exchange of "
+                       f"uVelocity/vVelocity/stress every {res['interval']} subcycles")
+        block_cells = res["n_block_cells"]
         if rank != 0:
             return
 
     ms_per_step = wall / args.steps * 1e3
     value = n_cells_total * nsub * args.steps / wall
     b_cell, b_vert = b_alg_per_cell(M)
-    cells_per_launch = n_cells_total / world
+    cells_per_launch = n_cells_total if world == 1 else block_cells
     roof_bytes = b_alg_cell_kernel(M) * cells_per_launch
     achieved = roof_bytes / (cell_ms * 1e-3) / 1e9 if cell_ms > 0 else 0.0
     traffic = None

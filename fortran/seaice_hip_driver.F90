@@ -113,6 +113,7 @@ program seaice_hip_driver
   cfg % useColumnPackage = 0
   cfg % nCategories = nCategories
   cfg % minEdgeLengthGlobal = 0.0_RKIND
+  cfg % computeHaloVertices = 0
   call check(sih_evp_init(ctx, cfg), "sih_evp_init")
 
   ! ---- seaice_run_velocity_solver -------------------------------------------------------------

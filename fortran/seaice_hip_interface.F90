@@ -38,6 +38,7 @@ module seaice_hip_interface
      integer(c_int32_t) :: useAirStress, useOceanStress, oceanStressType, surfaceTilt
      integer(c_int32_t) :: calcVelocityMasks, useColumnPackage, nCategories
      real(c_double)     :: minEdgeLengthGlobal
+     integer(c_int32_t) :: computeHaloVertices
   end type sih_evp_config
 
   interface

@@ -89,6 +89,11 @@ typedef struct sih_evp_config {
     int32_t nCategories;
     double minEdgeLengthGlobal;       /* global min of dvEdge (mpas_dmpar_min_real in seaice_init_evp);
                                          <= 0: use this block's own minimum */
+    int32_t computeHaloVertices;      /* 0: vertex loops cover the owned vertices only, as in the reference
+                                         (halo values arrive by exchange).  1: they also cover every halo
+                                         vertex whose three cells are inside the block; the values equal the
+                                         owner's bit for bit and let a block with H halo layers run H
+                                         subcycles between exchanges of uVelocity, vVelocity and stress11/22/12 */
 } sih_evp_config;
 
 /* ---- life cycle ----------------------------------------------------------------------------- */

@@ -28,10 +28,11 @@ __constant__ double c_dunW[16] = {0.14431560767779, 0.09509163426728, 0.09509163
 
 struct InitArgs {
     int nCells, nVertices, nVerticesSolve, M, padC, padV, rotate, onASphere, includeMetric, alternateDenominator;
+    int computeHalo;
     double R;
     const int *nEdgesOnCell, *voc, *cov;
     const double *xCell, *yCell, *zCell, *xVertex, *yVertex, *zVertex, *areaTriangle;
-    int *cvav, *gidx, *interiorVertex;
+    int *cvav, *gidx, *interiorVertex, *vActive;
     double *tanLat, *varDenom;
     double *gradU, *gradV, *SU, *SV, *SM, *gradU3, *gradV3;
     int *flag;
@@ -78,7 +79,11 @@ __global__ void k_init_vertices(InitArgs a)
         // where the divergence partial sum of this (cell, corner) lives; the zero slot otherwise
         a.gidx[k * a.padV + v] = (j >= 0) ? j * a.padC + c : a.nCells;
     }
-    if (v < a.nVerticesSolve) a.interiorVertex[v] = (nInterior == 3) ? 1 : 0;
+    // vertices the vertex loops cover: the owned ones (the reference's 1..nVerticesSolve) and, on request,
+    // halo vertices that see all three of their cells inside the block
+    const int active = (v < a.nVerticesSolve) || (a.computeHalo && nInterior == 3);
+    a.vActive[v] = active ? 1 : 0;
+    if (active) a.interiorVertex[v] = (nInterior == 3) ? 1 : 0;
 }
 
 // ---- Wachspress basis on one polygon (wachspress.F:535-1069) --------------------------------
@@ -401,6 +406,8 @@ static InitArgs makeInitArgs(sih_ctx *c)
     a.cvav = fi("cellVerticesAtVertex");
     a.gidx = fi("_gidx");
     a.interiorVertex = fi("interiorVertex");
+    a.vActive = fi("_vertexActive");
+    a.computeHalo = c->cfg.computeHaloVertices ? 1 : 0;
     a.tanLat = fd("tanLatVertexRotatedOverRadius");
     a.varDenom = fd("variationalDenominator");
     a.gradU = fd("basisGradientU");

@@ -50,6 +50,7 @@ void sih_bind_dev(sih_ctx *c)
     d.cvav = fi("cellVerticesAtVertex");
     d.gidx = fi("_gidx");
     d.interiorVertex = fi("interiorVertex");
+    d.vActive = fi("_vertexActive");
     d.landIceMask = fi("landIceMask");
     d.landIceMaskVertex = fi("landIceMaskVertex");
     d.solveStress = fi("solveStress");
@@ -170,7 +171,7 @@ __global__ void k_pre1_vertices(SihDev d, int calcMasks)
 {
     int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= d.nVertices) return;
-    if (v < d.nVerticesSolve) {
+    if (d.vActive[v]) {
         double av = interpC2V(d, v, d.iceAreaCellInitial);
         double mv = interpC2V(d, v, d.totalMassCell);
         d.iceAreaVertex[v] = av;
@@ -211,7 +212,7 @@ __global__ void k_pre2_vertices(SihDev d)
 {
     int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= d.nVertices) return;
-    if (v < d.nVerticesSolve) {
+    if (d.vActive[v]) {
         double uo = interpC2V(d, v, d.uOcn);
         double vo = interpC2V(d, v, d.vOcn);
         d.uOcnVert[v] = uo;
@@ -263,7 +264,7 @@ __global__ void k_pre4_vertices(SihDev d)
     if (v >= d.nVertices) return;
     d.divU[v] = 0.0;
     d.divV[v] = 0.0;
-    if (v >= d.nVerticesSolve) {
+    if (!d.vActive[v]) {
         if (!d.useOcean) {
             d.ocnStressU[v] = 0.0;
             d.ocnStressV[v] = 0.0;
@@ -498,7 +499,8 @@ template <bool LAST>
 __global__ void __launch_bounds__(256) k_sub_vertices(SihDev d)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= d.nVerticesSolve) return;
+    if (v >= d.nVertices) return;
+    if (!d.vActive[v]) return;
     if (d.solveVelocity[v] != 1) {
         if (LAST && !d.useOcean) d.ocnCoeff[v] = 0.0;
         return;
@@ -624,7 +626,7 @@ __global__ void k_post0_vertices(SihDev d)
         d.ocnStressV[v] = 0.0;
         return;
     }
-    if (v >= d.nVerticesSolve) return;
+    if (!d.vActive[v]) return;
     if (d.solveVelocity[v] == 1) {
         double uo = d.uOcnVert[v], vo = d.vOcnVert[v], uu = d.u[v], vv = d.v[v], f = d.fVertex[v];
         double coeff;
@@ -677,7 +679,7 @@ __global__ void k_post1_cells(SihDev d)
 __global__ void k_post1_vertices(SihDev d)
 {
     int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= d.nVerticesSolve || !d.useOcean) return;
+    if (v >= d.nVertices || !d.useOcean || !d.vActive[v]) return;
     if (d.solveVelocity[v] == 1) {
         d.ocnStressU[v] = d.ocnStressU[v] * d.iceAreaVertex[v];
         d.ocnStressV[v] = d.ocnStressV[v] * d.iceAreaVertex[v];
@@ -762,7 +764,7 @@ static void launchCellKernel(sih_ctx *c, bool last)
 
 static void launchVertexKernel(sih_ctx *c, bool last)
 {
-    dim3 b(256), g = gridFor(c->nVerticesSolve);
+    dim3 b(256), g = gridFor(c->cfg.computeHaloVertices ? c->nVertices : c->nVerticesSolve);
     if (last)
         hipLaunchKernelGGL(k_sub_vertices<true>, g, b, 0, c->stream, c->dev);
     else

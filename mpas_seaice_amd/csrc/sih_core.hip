@@ -272,7 +272,8 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
     const Spec specs[] = {
         // connectivity in internal numbering
         {"_nEdgesOnCell", LOC_CELL, 1, true}, {"_voc", LOC_CELL, M, true}, {"_coc", LOC_CELL, M, true},
-        {"_cov", LOC_VERTEX, 3, true}, {"_cvav", LOC_VERTEX, 3, true}, {"_gidx", LOC_VERTEX, 3, true},
+        {"_cov", LOC_VERTEX, 3, true}, {"_gidx", LOC_VERTEX, 3, true},
+        {"_vertexActive", LOC_VERTEX, 1, true},
         // geometry
         {"xCell", LOC_CELL, 1, false}, {"yCell", LOC_CELL, 1, false}, {"zCell", LOC_CELL, 1, false},
         {"xVertex", LOC_VERTEX, 1, false}, {"yVertex", LOC_VERTEX, 1, false}, {"zVertex", LOC_VERTEX, 1, false},
@@ -580,31 +581,42 @@ static int haloPackUnpack(sih_ctx *c, int location, int nFields, const char *con
         return SIH_ERR_ARG;
     }
     HIPCHK(hipSetDevice(c->device));
+    int nPlanes = 0;
     for (int f = 0; f < nFields; f++) {
         SihField *fl = sih_find_field(c, names[f]);
-        if (!fl || (int)fl->loc != location || fl->lead != 1) {
-            sih_set_error(std::string("sih_halo_pack/unpack: not a scalar field of this location: ") + names[f]);
+        if (!fl || (int)fl->loc != location) {
+            sih_set_error(std::string("sih_halo_pack/unpack: not a field of this location: ") + names[f]);
             return SIH_ERR_ARG;
         }
         if (f > 0 && fl->isInt != sih_find_field(c, names[0])->isInt) {
             sih_set_error("sih_halo_pack/unpack: fields of one call must share a type");
             return SIH_ERR_ARG;
         }
+        nPlanes += fl->lead;
+    }
+    const int pad = location == 0 ? c->padC : c->padV;
+    int plane = 0;
+    for (int f = 0; f < nFields; f++) {
+        SihField *fl = sih_find_field(c, names[f]);
         dim3 grid((n + 255) / 256), block(256);
-        if (fl->isInt) {
-            if (pack)
-                hipLaunchKernelGGL(k_pack<int>, grid, block, 0, c->stream, (int *)buf, (const int *)fl->d, idx, sg0, sgc, n,
-                                   nFields, f);
-            else
-                hipLaunchKernelGGL(k_unpack<int>, grid, block, 0, c->stream, (const int *)buf, (int *)fl->d, idx, sg0, sgc,
-                                   n, nFields, f);
-        } else {
-            if (pack)
-                hipLaunchKernelGGL(k_pack<double>, grid, block, 0, c->stream, (double *)buf, (const double *)fl->d, idx, sg0,
-                                   sgc, n, nFields, f);
-            else
-                hipLaunchKernelGGL(k_unpack<double>, grid, block, 0, c->stream, (const double *)buf, (double *)fl->d, idx,
-                                   sg0, sgc, n, nFields, f);
+        for (int l = 0; l < fl->lead; l++, plane++) {
+            if (fl->isInt) {
+                int *fp = (int *)fl->d + (size_t)l * pad;
+                if (pack)
+                    hipLaunchKernelGGL(k_pack<int>, grid, block, 0, c->stream, (int *)buf, (const int *)fp, idx, sg0, sgc,
+                                       n, nPlanes, plane);
+                else
+                    hipLaunchKernelGGL(k_unpack<int>, grid, block, 0, c->stream, (const int *)buf, fp, idx, sg0, sgc, n,
+                                       nPlanes, plane);
+            } else {
+                double *fp = (double *)fl->d + (size_t)l * pad;
+                if (pack)
+                    hipLaunchKernelGGL(k_pack<double>, grid, block, 0, c->stream, (double *)buf, (const double *)fp, idx,
+                                       sg0, sgc, n, nPlanes, plane);
+                else
+                    hipLaunchKernelGGL(k_unpack<double>, grid, block, 0, c->stream, (const double *)buf, fp, idx, sg0,
+                                       sgc, n, nPlanes, plane);
+            }
         }
     }
     HIPCHK(hipGetLastError());

@@ -28,7 +28,7 @@ struct SihDev {
     int padC, padV;
     // connectivity (internal numbering, 0-based; "none" = nCells / nVertices, a zero-filled slot)
     const int *nEdgesOnCell, *voc, *coc, *cov, *cvav, *gidx;
-    const int *interiorVertex, *landIceMask, *landIceMaskVertex;
+    const int *interiorVertex, *landIceMask, *landIceMaskVertex, *vActive;
     int *solveStress, *solveVelocity, *solveVelocityPrevious;
     // geometry
     const double *areaCell, *areaTriangle, *fVertex, *tanLat, *varDenom;

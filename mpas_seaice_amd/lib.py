@@ -49,6 +49,7 @@ class EvpConfig(ctypes.Structure):
         ("oceanStressType", ctypes.c_int32), ("surfaceTilt", ctypes.c_int32),
         ("calcVelocityMasks", ctypes.c_int32), ("useColumnPackage", ctypes.c_int32),
         ("nCategories", ctypes.c_int32), ("minEdgeLengthGlobal", ctypes.c_double),
+        ("computeHaloVertices", ctypes.c_int32),
     ]
 
 

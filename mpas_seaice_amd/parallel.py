@@ -23,14 +23,16 @@ FIELD_LOC = {
     "airStressCellV": "cell", "seaSurfaceTiltU": "cell", "seaSurfaceTiltV": "cell",
     "solveVelocity": "vertex", "interiorVertex": "vertex", "uVelocity": "vertex", "vVelocity": "vertex",
     "oceanStressU": "vertex", "oceanStressV": "vertex",
+    "stress11": "cell", "stress22": "cell", "stress12": "cell", "solveStress": "cell",
 }
-INT_FIELDS = {"solveVelocity", "interiorVertex"}
+INT_FIELDS = {"solveVelocity", "interiorVertex", "solveStress"}
 FIELD_POOL = {
     "iceAreaCellInitial": "icestate", "totalMassCell": "icestate", "icePressure": "velocity_solver",
     "airStressCellU": "velocity_solver", "airStressCellV": "velocity_solver", "seaSurfaceTiltU": "ocean_coupling",
     "seaSurfaceTiltV": "ocean_coupling", "solveVelocity": "velocity_solver", "interiorVertex": "boundary",
     "uVelocity": "velocity_solver", "vVelocity": "velocity_solver", "oceanStressU": "velocity_solver",
-    "oceanStressV": "velocity_solver",
+    "oceanStressV": "velocity_solver", "stress11": "velocity_variational", "stress22": "velocity_variational",
+    "stress12": "velocity_variational", "solveStress": "velocity_solver",
 }
 
 
@@ -58,28 +60,39 @@ class _Lists:
 
 class HostFields:
     """pack / unpack on numpy pool arrays (used with the CPU oracle flow in tests); same neighbour-major
-    message layout as sih_halo_pack: [peer][field][entry]."""
+    message layout as sih_halo_pack: [peer][plane][entry], a field with several entries per entity
+    (stress11: maxEdges per cell) contributing one plane per entry."""
 
     def __init__(self, block):
         self.block = block
 
+    def planes(self, names):
+        out = []
+        for n in names:
+            a = self.block.structs[FIELD_POOL[n]][n]
+            if a.ndim == 1:
+                out.append(a)
+            else:
+                out.extend(a[l] for l in range(a.shape[0]))
+        return out
+
     def pack(self, lists, names, is_int):
-        nf = len(names)
+        pl = self.planes(names)
+        nf = len(pl)
         out = np.empty(nf * lists.send_idx.size, dtype=np.int32 if is_int else np.float64)
         for p in lists.peers:
             o, c = int(lists.send_off[p]), lists.send_counts[p]
-            for f, n in enumerate(names):
-                out[o * nf + f * c:o * nf + (f + 1) * c] = \
-                    self.block.structs[FIELD_POOL[n]][n][lists.send_idx[o:o + c] - 1]
+            for f, a in enumerate(pl):
+                out[o * nf + f * c:o * nf + (f + 1) * c] = a[lists.send_idx[o:o + c] - 1]
         return out
 
     def unpack(self, lists, names, buf):
-        nf = len(names)
+        pl = self.planes(names)
+        nf = len(pl)
         for p in lists.peers:
             o, c = int(lists.recv_off[p]), lists.recv_counts[p]
-            for f, n in enumerate(names):
-                self.block.structs[FIELD_POOL[n]][n][lists.recv_idx[o:o + c] - 1] = \
-                    buf[o * nf + f * c:o * nf + (f + 1) * c]
+            for f, a in enumerate(pl):
+                a[lists.recv_idx[o:o + c] - 1] = buf[o * nf + f * c:o * nf + (f + 1) * c]
 
 
 class CommBase:
@@ -96,6 +109,13 @@ class CommBase:
                     b.ctx.halo_set_lists(LOC_ID[loc], L[loc].send_idx, L[loc].recv_idx, L[loc].send_counts,
                                          L[loc].recv_counts)
         self._bufs = {}
+
+    def n_planes(self, domain, names):
+        tot = 0
+        for n in names:
+            a = domain.blocklist[0].structs[FIELD_POOL[n]][n]
+            tot += 1 if a.ndim == 1 else a.shape[0]
+        return tot
 
     def _torch_buf(self, key, n, is_int, device):
         import torch
@@ -115,7 +135,7 @@ class LocalComm(CommBase):
 
     def halo_exchange(self, domain, names):
         for (loc, is_int), ns in _group(names).items():
-            nf = len(ns)
+            nf = self.n_planes(domain, ns)
             if self.device:
                 import torch
                 dev = torch.device("cuda", torch.cuda.current_device())
@@ -178,7 +198,7 @@ class DistComm(CommBase):
         b = domain.blocklist[0]
         for (loc, is_int), ns in _group(names).items():
             L = self.lists[0][loc]
-            nf = len(ns)
+            nf = self.n_planes(domain, ns)
             send_split = [c * nf for c in L.send_counts]
             recv_split = [c * nf for c in L.recv_counts]
             ns_tot, nr_tot = nf * L.send_idx.size, nf * L.recv_idx.size
@@ -209,7 +229,8 @@ class DistComm(CommBase):
 # ----------------------------------------------------------------------------------------------
 def make_partitioned_domain(mesh, name, nblocks, configs=None, only_block=None, **case_kw):
     """Domain holding all blocks of the partition (only_block=None) or just one of them."""
-    meshes, halos = partition_mesh(mesh, nblocks)
+    num_halos = int((configs or {}).get("config_num_halos", 2))
+    meshes, halos = partition_mesh(mesh, nblocks, num_halos=num_halos)
     if only_block is not None:
         dom = cases.make_domain([meshes[only_block]], name, configs=configs, **case_kw)
         return dom, halos[only_block], halos
@@ -235,8 +256,9 @@ def oracle_halo_callback(comm):
     return halo
 
 
-def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True):
-    """One block per rank over RCCL: K steps of nsub subcycles with a halo exchange each subcycle."""
+def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, interval=None):
+    """One block per rank over RCCL: K steps of nsub subcycles; halos are `interval` layers deep and are
+    exchanged every `interval` subcycles (uVelocity, vVelocity, stress11/22/12)."""
     import os
     import time
 
@@ -244,11 +266,14 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True):
     import torch.distributed as dist
 
     from . import velocity_solver as vs
+    if interval is None:
+        interval = int(os.environ.get("SIH_HALO_INTERVAL", "4"))
     if not dist.is_initialized():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     rank, world = dist.get_rank(), dist.get_world_size()
-    dom, halo, _ = make_partitioned_domain(mesh, name, world, configs={"config_elastic_subcycle_number": nsub},
-                                           only_block=rank)
+    cfg = {"config_elastic_subcycle_number": nsub, "config_num_halos": max(2, interval),
+           "config_halo_exchange_interval": interval}
+    dom, halo, _ = make_partitioned_domain(mesh, name, world, configs=cfg, only_block=rank)
     vs.seaice_mesh_pool_create(dom, device=local_rank, renumber=renumber)
     ctx = dom.blocklist[0].ctx
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -262,11 +287,16 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True):
     vs.velocity_solver_pre_subcycle(dom)
     torch.cuda.synchronize()
     pre_ms = (time.perf_counter() - t0) * 1e3
+    names = ["uVelocity", "vVelocity"] if interval == 1 else ["uVelocity", "vVelocity", "stress11", "stress22",
+                                                               "stress12"]
 
     def step():
-        for _ in range(nsub):
-            ctx.subcycle(1, last=False)
-            dom.comm.halo_exchange(dom, ["uVelocity", "vVelocity"])
+        done = 0
+        while done < nsub:
+            m = min(interval, nsub - done)
+            ctx.subcycle(m, last=False)
+            done += m
+            dom.comm.halo_exchange(dom, names)
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -284,7 +314,7 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True):
     wall = float(t.item())
     t0 = time.perf_counter()
     ctx.subcycle(1, last=True)
-    dom.comm.halo_exchange(dom, ["uVelocity", "vVelocity"])
+    dom.comm.halo_exchange(dom, names)
     vs.velocity_solver_post_subcycle(dom)
     torch.cuda.synchronize()
     post_ms = (time.perf_counter() - t0) * 1e3
@@ -295,8 +325,9 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True):
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if ok.item() < 1.0:
         raise SystemExit("non-finite velocities after the benchmark loop")
+    n_block_cells = dom.blocklist[0].dimensions["nCells"]
     vs.seaice_mesh_pool_destroy(dom)
     dist.barrier()
     dist.destroy_process_group()
     return {"wall": wall, "pre_ms": pre_ms, "post_ms": post_ms, "cell_ms": cell_ms, "vert_ms": vert_ms,
-            "n_cells_total": int(mesh.nCells)}
+            "n_cells_total": int(mesh.nCells), "n_block_cells": int(n_block_cells), "interval": interval}

@@ -47,6 +47,10 @@ DEFAULT_CONFIGS = {
     "config_aggregate_halo_exch": False,
     "config_reuse_halo_exch": False,
     "config_num_halos": 2,
+    # not a reference option: number of subcycles between halo exchanges of the velocity solver.  k > 1 needs
+    # config_num_halos >= k halo layers; the solver then also updates halo vertices/cells redundantly and
+    # exchanges uVelocity, vVelocity and stress11/22/12 every k subcycles (results identical to k = 1)
+    "config_halo_exchange_interval": 1,
     "config_advection_type": "incremental_remap",
     "config_earth_radius": 6371229.0,
 }

@@ -101,6 +101,10 @@ def _evp_config(domain, block):
     c.useColumnPackage = int(bool(cfg["config_use_column_package"]))
     c.nCategories = int(block.dimensions["nCategories"])
     c.minEdgeLengthGlobal = float(domain.solver_state.get("dvEdgeMinGlobal", 0.0))
+    k = int(cfg.get("config_halo_exchange_interval", 1))
+    if k < 1 or (k > 1 and k > int(cfg["config_num_halos"])):
+        raise _lib.SeaiceHipError("config_halo_exchange_interval must be between 1 and config_num_halos")
+    c.computeHaloVertices = int(k > 1)
     return c
 
 
@@ -176,6 +180,10 @@ def velocity_solver_pre_subcycle(domain):
         for b in domain.blocklist:
             b.ctx.pre_subcycle(-1)
         return
+    if int(domain.configs.get("config_halo_exchange_interval", 1)) > 1:
+        # with several subcycles between exchanges the stress mask of the outer halo cells, which the
+        # reference leaves to local (possibly incomplete) neighbour information, must be the owner's
+        after[1] = ["solveVelocity", "solveStress"]
     for stage in range(5):
         for b in domain.blocklist:
             b.ctx.pre_subcycle(stage)
@@ -191,10 +199,15 @@ def subcycle_velocity_solver(domain, clock=None):
         for b in domain.blocklist:
             b.ctx.subcycle(n, last=True)
         return
-    for it in range(n):
+    k = int(domain.configs.get("config_halo_exchange_interval", 1))
+    names = ["uVelocity", "vVelocity"] if k == 1 else ["uVelocity", "vVelocity", "stress11", "stress22", "stress12"]
+    done = 0
+    while done < n:
+        m = min(k, n - done)
         for b in domain.blocklist:
-            b.ctx.subcycle(1, last=(it == n - 1))
-        comm.halo_exchange(domain, ["uVelocity", "vVelocity"])
+            b.ctx.subcycle(m, last=(done + m == n))
+        done += m
+        comm.halo_exchange(domain, names)
 
 
 def velocity_solver_post_subcycle(domain):

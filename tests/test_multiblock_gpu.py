@@ -15,14 +15,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = 1e-10
 
 
-@pytest.mark.parametrize("nblocks", [2, 4])
-def test_blocks_on_one_gpu_match_single_block_oracle(oracle, nblocks):
+@pytest.mark.parametrize("nblocks,interval", [(2, 1), (4, 1), (3, 3), (4, 4)])
+def test_blocks_on_one_gpu_match_single_block_oracle(oracle, nblocks, interval):
+    """interval k > 1: k halo layers, redundant halo updates, one exchange per k subcycles."""
     mesh = get_mesh("QU480")
     cfg = {"config_elastic_subcycle_number": 40}
     ref = cases.make_domain(mesh, "QU480", configs=cfg, open_water_band=(-0.2, 0.3))
     oracle.seaice_init_velocity_solver(ref)
     oracle.seaice_run_velocity_solver(ref)
-    dom, halos, _ = parallel.make_partitioned_domain(mesh, "QU480", nblocks, configs=cfg,
+    pcfg = dict(cfg, config_num_halos=max(2, interval), config_halo_exchange_interval=interval)
+    dom, halos, _ = parallel.make_partitioned_domain(mesh, "QU480", nblocks, configs=pcfg,
                                                      open_water_band=(-0.2, 0.3))
     vs.seaice_mesh_pool_create(dom, device=0)
     try:
