@@ -10,6 +10,10 @@
  *     velocity_solver_pre_subcycle       :613     subcycle_velocity_solver  :2404
  *     velocity_solver_post_subcycle      :3360
  *   mpas_dmpar_field_halo_exch (pack / unpack halves only; the transport stays with the host)
+ * and the incremental-remap advection entry points:
+ *   seaice_init_advection / seaice_run_advection   src/shared/mpas_seaice_advection.F:40, :90
+ *     seaice_init_advection_incremental_remap      src/shared/mpas_seaice_advection_incremental_remap.F:165
+ *     seaice_run_advection_incremental_remap       :2338      incremental_remap_block  :2740
  *
  * Conventions
  *   - Plain pointers and sizes only.  Host arrays use the reference's layout: Fortran order, float64
@@ -40,7 +44,8 @@ enum {
     SIH_ERR_ARG = 1,        /* bad argument / unknown option (reference: "... unknown", MPAS_LOG_CRIT) */
     SIH_ERR_HIP = 2,        /* HIP runtime failure */
     SIH_ERR_STATE = 3,      /* call out of order (e.g. run before init) */
-    SIH_ERR_UNSUPPORTED = 4 /* option of the reference that is outside this library's scope */
+    SIH_ERR_UNSUPPORTED = 4, /* option of the reference that is outside this library's scope */
+    SIH_ERR_IR = 5          /* a run-time abort of the advection (negative mass / area, degenerate geometry) */
 };
 
 /* Mesh description of one block: the `mesh` pool fields the dynamics read
@@ -187,6 +192,50 @@ int sih_halo_set_lists(sih_ctx *ctx, int location, int nSend, const int32_t *sen
  * Both are asynchronous on the context's stream. */
 int sih_halo_pack(sih_ctx *ctx, int location, int nFields, const char *const *names, void *deviceBuf);
 int sih_halo_unpack(sih_ctx *ctx, int location, int nFields, const char *const *names, const void *deviceBuf);
+
+/* ---- incremental-remap advection ---------------------------------------------------------------
+ * Replaces, for one block, seaice_init_advection_incremental_remap and the per-block part of
+ * seaice_run_advection_incremental_remap (src/shared/mpas_seaice_advection_incremental_remap.F:165,
+ * :2338) with incremental_remap_block (:2740).  Hexagonal meshes (vertexDegree 3) only. */
+
+/* mesh-pool fields the advection reads beyond sih_mesh_desc, and the options it reads
+ * (incremental_remap.F:257-340, :2899-2901).  Pointers are borrowed for the duration of the call. */
+typedef struct sih_ir_desc {
+    const int32_t *edgesOnCell;    /* (maxEdges, nCells) */
+    const int32_t *cellsOnEdge;    /* (2, nEdges) */
+    const int32_t *verticesOnEdge; /* (2, nEdges) */
+    const int32_t *edgesOnVertex;  /* (vertexDegree, nVertices) */
+    const double *xEdge, *yEdge, *zEdge; /* (nEdges) */
+    const double *dcEdge, *dvEdge;       /* (nEdges) */
+    const double *coeffsReconstruct;     /* (3, maxEdges, nCells): mesh-pool field coeffs_reconstruct, the
+                                            output of the framework's mpas_init_reconstruct (:744-746) */
+    int32_t nCategories;
+    int32_t rotateCartesianGrid;         /* config_rotate_cartesian_grid */
+} sih_ir_desc;
+
+/* seaice_init_advection_incremental_remap (:165-816): local frames, vertex coordinates relative to
+ * cells and edges, remap connectivity, geometric cell averages.  Fails with SIH_ERR_ARG where the
+ * reference aborts (cells not convex / not counter-clockwise, cell 1 of an edge not in its left
+ * half-plane, non-positive cell area). */
+int sih_ir_init(sih_ctx *ctx, const sih_ir_desc *desc);
+/* The ordered tracer list (seaice_add_tracers_to_linked_list / set_tracer_order,
+ * incremental_remap_tracers.F:158-526, :860-922): names[0] is the mass-like field (parents[0] = "None"),
+ * every parent precedes its children, nLayers[i] is the size of the leading dimension of tracer i
+ * (1 for the (ONE, nCategories, nCells) fields).  Each tracer becomes a field of that name with
+ * nLayers*nCategories values per cell for sih_field_put / sih_field_get. */
+int sih_ir_set_tracers(sih_ctx *ctx, int nTracers, const char *const *names, const char *const *parents,
+                       const int32_t *nLayers);
+/* One call of the block part of seaice_run_advection_incremental_remap (:2489-2650): volume ->
+ * thickness, incremental_remap_block with time step dt (uVelocity / vVelocity and the tracer fields are
+ * read on the device; halos must be current), thickness -> volume.  Returns SIH_ERR_IR where the
+ * reference aborts ("IR negative reconstructed ice area", "IR: Negative mass in IR", parallel basis
+ * vectors).  checkConservation != 0 also evaluates sum_tracers (:7998) before and after the update. */
+int sih_ir_run(sih_ctx *ctx, double dt, int checkConservation);
+/* sum_tracers results of the last sih_ir_run(…, 1): nLayers*nCategories values each */
+int sih_ir_get_sums(sih_ctx *ctx, const char *tracer, double *initSums, double *finalSums);
+/* sih_ir_run bracketed by HIP events on the context's stream: total and per-phase durations in ms
+ * (phases: 0 conversion+masks, 1 reconstruction, 2 departure triangles, 3 fluxes, 4 update+zap) */
+int sih_ir_run_timed(sih_ctx *ctx, double dt, double *totalMs, double *phaseMs5);
 
 /* introspection for tests and reports */
 int sih_get_info(sih_ctx *ctx, const char *key, double *value);

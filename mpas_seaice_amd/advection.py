@@ -1,0 +1,98 @@
+"""Host mirror of the reference's advection driver for the device library.
+
+``seaice_init_advection`` / ``seaice_run_advection`` follow
+/root/reference/src/shared/mpas_seaice_advection.F:40-140 and, for ``config_advection_type =
+'incremental_remap'``, /root/reference/src/shared/mpas_seaice_advection_incremental_remap.F
+(seaice_init_advection_incremental_remap :165, seaice_run_advection_incremental_remap :2338).  The
+per-block arithmetic runs in libseaice_hip.so (sih_ir_*); this module keeps the reference's call
+sequence: halo updates of velocity and tracers, the block loop, the conservation check with its global
+sums, the optional final halo update.  There is no CPU path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import tracers as trc
+from .lib import SeaiceHipError
+
+
+def seaice_init_advection(domain):
+    """mpas_seaice_advection.F:40-76"""
+    cfg = domain.configs
+    if not cfg.get("config_use_advection", True):
+        return
+    if cfg["config_advection_type"] != "incremental_remap":
+        raise SeaiceHipError("config_advection_type: only 'incremental_remap' is implemented on the device")
+    # check_halo_layer_number, incremental_remap.F:829-874
+    if getattr(domain, "comm", None) is not None and int(cfg.get("config_num_halos", 2)) < 2:
+        raise SeaiceHipError("IR requires at least two halo layers (config_num_halos)")
+    tracersHead = trc.seaice_add_tracers_to_linked_list(domain)
+    for b in domain.blocklist:
+        if getattr(b, "ctx", None) is None:
+            raise SeaiceHipError("seaice_init_advection: seaice_mesh_pool_create must run first")
+        m = b.structs["mesh"]
+        if "coeffs_reconstruct" not in m:
+            raise SeaiceHipError("mesh pool lacks coeffs_reconstruct (the output of mpas_init_reconstruct)")
+        b.ctx.ir_init(m, b.dimensions["nCategories"],
+                      bool(cfg["config_rotate_cartesian_grid"]) and bool(m["on_a_sphere"]))
+        b.ctx.ir_set_tracers([t.tracerName for t in tracersHead], [t.parentName for t in tracersHead],
+                             [t.nLayers for t in tracersHead])
+
+
+def _n(b, loc):
+    return b.dimensions[{"cell": "nCells", "vertex": "nVertices"}[loc]]
+
+
+def seaice_run_advection(domain, updateHaloInit=True, updateHaloFinal=False, upload=True, download=True):
+    """mpas_seaice_advection.F:90-136 -> seaice_run_advection_incremental_remap (:2338-2667).
+
+    ``upload`` / ``download`` move uVelocity, vVelocity and the tracers between the host pools and the
+    device around the call; a host that keeps its state on the device between the velocity solver and
+    the advection passes ``upload=False``.
+    """
+    cfg = domain.configs
+    if not cfg.get("config_use_advection", True):
+        return
+    tracersHead = domain.solver_state["tracersHead"]
+    names = [t.tracerName for t in tracersHead]
+    comm = getattr(domain, "comm", None)
+    if upload:
+        for b in domain.blocklist:
+            vs, tp = b.structs["velocity_solver"], b.structs["tracers"]
+            b.ctx.put("uVelocity", vs["uVelocity"])
+            b.ctx.put("vVelocity", vs["vVelocity"])
+            for n in names:
+                b.ctx.put(n, tp[n])
+    # initial halo updates of velocity, mass and tracers, :2436-2487
+    if updateHaloInit and comm is not None and cfg["config_use_halo_exch"]:
+        comm.halo_exchange(domain, ["uVelocity", "vVelocity"])
+        comm.halo_exchange(domain, names)
+    check = bool(cfg["config_conservation_check"])
+    for b in domain.blocklist:
+        dt = float(b.structs["velocity_solver"]["dynamicsTimeStep"][0])
+        b.ctx.ir_run(dt, check)
+    if check:  # check_tracer_conservation, :8126-8253 (global sums over blocks and ranks)
+        nCat = domain.blocklist[0].dimensions["nCategories"]
+        for t in tracersHead:
+            init = np.zeros(t.nLayers * nCat)
+            fin = np.zeros(t.nLayers * nCat)
+            for b in domain.blocklist:
+                a0, a1 = b.ctx.ir_get_sums(t.tracerName, t.nLayers * nCat)
+                init += a0
+                fin += a1
+            if comm is not None and hasattr(comm, "allreduce_sum"):
+                init, fin = comm.allreduce_sum(init), comm.allreduce_sum(fin)
+            big = np.abs(init) > 1.0e-11
+            ratio = np.where(big, (fin - init) / np.where(big, init, 1.0), 0.0)
+            if (np.abs(ratio) > 1.0e-11).any():
+                raise SeaiceHipError("IR: Tracer conservation error: tracer = " + t.tracerName)
+            domain.solver_state.setdefault("ir_sums", {})[t.tracerName] = (init, fin)
+    if cfg["config_monotonicity_check"]:
+        raise SeaiceHipError("config_monotonicity_check is not implemented on the device")
+    if updateHaloFinal and comm is not None:
+        comm.halo_exchange(domain, names)
+    if download:
+        for b in domain.blocklist:
+            tp = b.structs["tracers"]
+            for n in names:
+                b.ctx.get(n, tp[n])

@@ -58,6 +58,17 @@ def fill_idealised_state(block, time=0.0, open_water_band=None, rotate=True):
         tr["iceAreaCategory"][0, k, :nC] = area * frac[k]
         tr["iceVolumeCategory"][0, k, :nC] = area * frac[k] * thick * hfac[k]
         tr["snowVolumeCategory"][0, k, :nC] = area * frac[k] * 0.2
+    # smooth analytic fields for the other advected tracers (values only matter where ice exists)
+    if "surfaceTemperature" in tr:
+        for k in range(nCat):
+            tr["surfaceTemperature"][0, k, :nC] = -5.0 - 10.0 * np.sin(lat) ** 2 - 0.5 * k + 2.0 * np.cos(2.0 * lon)
+    for name, base, amp in (("iceEnthalpy", -2.0e8, 0.5e8), ("iceSalinity", 4.0, 2.0), ("snowEnthalpy", -1.1e8, 0.1e8)):
+        if name in tr:
+            nL = tr[name].shape[0]
+            for l in range(nL):
+                for k in range(nCat):
+                    tr[name][l, k, :nC] = base + amp * ((l + 1.0) / nL) * np.cos(lon + 0.3 * k) * np.cos(lat) \
+                        + 0.1 * amp * np.sin(2.0 * lat + l)
     a, b, theta = 5.0, 3.0, 4.0 * 24.0 * 3600.0
     amp = np.sin((2.0 * np.pi * time) / theta) - b
     at = block.structs["atmos_coupling"]

@@ -1,0 +1,1346 @@
+// Incremental-remap (IR) tracer advection on the device.
+//
+// Follows src/shared/mpas_seaice_advection_incremental_remap.F of the reference (routine : line cited
+// at each kernel) for hexagonal meshes (vertexDegree = 3).  Arithmetic is written statement by statement
+// in the reference's evaluation order and compiled with -ffp-contract=off.
+//
+// Data layout: structure-of-arrays like the rest of the library.  A tracer with L layers and nCat
+// categories is L*nCat planes of padC doubles, plane index = category * L + layer (the reference's
+// (layer, category, cell) array with the cell index made fastest).  Per-edge quantities are planes of
+// padE values.  Cells, vertices and edges use the library's internal numbering ("none" = nCells /
+// nVertices / nEdges, a zero-filled slot).
+//
+// Differences of organisation (not of arithmetic) from the reference:
+//  * tracer masks (make_masks :3404) are not stored: mask(tracer, cell) is recomputed where it is used as
+//    "parent value > 1e-11" (1 for the mass-like field);
+//  * the values of mass*tracer products at the quadrature points (triangleValue, :6826) are not
+//    stored either: a child recomputes the product along its chain of ancestors in the same order of
+//    multiplications, which gives the same bits;
+//  * the quadrature points are recomputed from the stored triangle vertices inside the flux kernel;
+//  * a departure triangle is transformed to its source cell's frame (shift_vertices :6270) as soon as it
+//    is found; nothing it depends on changes in between in the reference.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "sih_internal.h"
+
+#define NTRI 6          // nTriPerEdgeRemap, Registry.xml:63
+#define EPS11 1.0e-11   // :60
+#define W1QP 1.09951743655321885e-01  // :63-70
+#define W2QP 2.23381589678011389e-01
+#define Q1QP 9.15762135097710761e-02
+#define Q2QP 8.16847572980458514e-01
+#define Q3QP 1.08103018168070275e-01
+#define Q4QP 4.45948490915965612e-01
+#define HUGE_R 1.79769313486231571e308
+
+#define FLAG_CCW 1
+#define FLAG_HALFPLANE 2
+#define FLAG_AREA 4
+#define FLAG_PARALLEL 8
+#define FLAG_NEGAREA 16
+#define FLAG_NEGMASS 32
+
+struct IrDev {
+    int nCells, nCellsSolve, nVertices, nEdges, M, nCat, padC, padV, padE, onSphere, rotate;
+    const int *nEdgesOnCell, *voc, *coc;
+    int *eoc, *coe, *voe, *eov, *remapEdge, *eoer, *coer;
+    double *g2c, *xVOC, *yVOC, *xVOE, *yVOE, *geom, *minLen;
+    const double *dcEdge, *dvEdge, *coeffs, *areaCell;
+    const double *u, *v;
+    double *dp;
+    int *triCount, *triCell;
+    double *xTri, *yTri, *triArea;
+    int *maskCell, *flag;
+};
+
+struct IrLevel {
+    const double *val, *center, *gx, *gy;
+    int L;
+};
+
+struct IrArgs {
+    int L, Lp, nLev, isMass;
+    IrLevel lev[4];  // chain from the mass-like field to this tracer (lev[nLev-1])
+    double *val, *center, *gx, *gy, *xB, *yB, *prod, *flux;
+    const double *parentVal, *parentXB, *parentYB, *parentProd;
+};
+
+struct IrTracer {
+    std::string name;
+    int parent = -1, L = 1, nParents = 0;
+    bool hasChild = false;
+    double *val = nullptr, *center = nullptr, *gx = nullptr, *gy = nullptr, *xB = nullptr, *yB = nullptr,
+           *prod = nullptr, *flux = nullptr;
+    std::vector<double> sumInit, sumFinal;
+};
+
+struct IrZapEntry {
+    double *val;
+    int L;
+};
+
+struct sih_ir_state {
+    IrDev d{};
+    std::vector<IrTracer> tracers;
+    int nCat = 0;
+    bool inited = false;
+    IrZapEntry *d_zap = nullptr;
+    double *d_sums = nullptr;
+    int iVol = -1, iSnow = -1;
+    int cflWarnings = 0;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+void sih_ir_destroy(sih_ctx *c)
+{
+    if (!c->ir) return;
+    if (c->ir->d_zap) hipFree(c->ir->d_zap);
+    if (c->ir->d_sums) hipFree(c->ir->d_sums);
+    for (hipEvent_t e : c->ir->ev)
+        if (e) hipEventDestroy(e);
+    delete c->ir;
+    c->ir = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------ helpers
+__device__ inline void unitVector3(double v[3])
+{  // :8900-8918
+    double mag = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (mag > 0.0) {
+        v[0] = v[0] / mag;
+        v[1] = v[1] / mag;
+        v[2] = v[2] / mag;
+    } else {
+        v[0] = v[1] = v[2] = 0.0;
+    }
+}
+
+__device__ inline double cross2(double ax, double ay, double bx, double by) { return ax * by - ay * bx; }  // :9083
+
+// point_in_half_plane :9201-9234 with its dummy arguments (point, lineStart, lineEnd)
+__device__ inline bool inHalfPlane(double px, double py, double sx, double sy, double ex, double ey)
+{
+    return cross2(ex - sx, ey - sy, px - sx, py - sy) >= 0.0;
+}
+
+__device__ inline double triArea2(double ax, double ay, double bx, double by, double cx, double cy)
+{  // :9172-9185
+    return fabs(0.5 * ((bx - ax) * (cy - ay) - (by - ay) * (cx - ax)));
+}
+
+// find_line_intersection :8934-9016
+__device__ inline bool lineIntersect(double x1, double y1, double x2, double y2, double x3, double y3, double x4,
+                                     double y4, double &ix, double &iy)
+{
+    double rx = x2 - x1, ry = y2 - y1, sx = x4 - x3, sy = y4 - y3;
+    double rsCross = rx * sy - ry * sx;
+    double rsCrossMin = EPS11 * sqrt((rx * rx + ry * ry) * (sx * sx + sy * sy));
+    bool hit = false;
+    if (fabs(rsCross) > rsCrossMin) {
+        double t1 = (sy * (x3 - x1) - sx * (y3 - y1)) / rsCross;
+        double t2 = (ry * (x3 - x1) - rx * (y3 - y1)) / rsCross;
+        ix = x1 + t1 * rx;
+        iy = y1 + t1 * ry;
+        if (t1 > 0.0 && t1 < 1.0 && t2 > 0.0 && t2 < 1.0) hit = true;
+    } else {
+        ix = HUGE_R;
+        iy = HUGE_R;
+    }
+    return hit;
+}
+
+// rows 1 and 2 of transGlobalToLocal, define_local_to_global_transformations :990-1084
+__device__ inline void localFrame(double x, double y, double z, double r1[3], double r2[3])
+{
+    double up[3] = {x, y, z};
+    unitVector3(up);
+    if (fabs(x * x + y * y) > EPS11) {
+        r1[0] = -y;
+        r1[1] = x;
+        r1[2] = 0.0;
+        unitVector3(r1);
+        r2[0] = up[1] * r1[2] - up[2] * r1[1];  // cross_product_3d(vertical, east) :9109-9123
+        r2[1] = up[2] * r1[0] - up[0] * r1[2];
+        r2[2] = up[0] * r1[1] - up[1] * r1[0];
+    } else if (z > 0.0) {
+        r1[0] = 1.0; r1[1] = 0.0; r1[2] = 0.0;
+        r2[0] = 0.0; r2[1] = 1.0; r2[2] = 0.0;
+    } else {
+        r1[0] = 0.0; r1[1] = 1.0; r1[2] = 0.0;
+        r2[0] = 1.0; r2[1] = 0.0; r2[2] = 0.0;
+    }
+}
+
+__device__ inline void rotated(const double *x, const double *y, const double *z, int i, int rot, double p[3])
+{  // rotate_global_vectors :948-975
+    if (rot) {
+        p[0] = -z[i];
+        p[1] = y[i];
+        p[2] = x[i];
+    } else {
+        p[0] = x[i];
+        p[1] = y[i];
+        p[2] = z[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ init kernels
+struct IrInitArgs {
+    const double *xC, *yC, *zC, *xV, *yV, *zV, *xE, *yE, *zE;
+};
+
+// per cell: local frame, get_vertex_on_cell_coordinates :1823-2036 (with its two orientation checks)
+__global__ void k_ir_init_cells(IrDev d, IrInitArgs a)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nCells) return;
+    const int rot = d.rotate && d.onSphere;
+    double pc[3], r1[3] = {0, 0, 0}, r2[3] = {0, 0, 0};
+    rotated(a.xC, a.yC, a.zC, c, rot, pc);
+    if (d.onSphere) {
+        localFrame(pc[0], pc[1], pc[2], r1, r2);
+        for (int j = 0; j < 3; j++) {
+            d.g2c[(size_t)j * d.padC + c] = r1[j];
+            d.g2c[(size_t)(3 + j) * d.padC + c] = r2[j];
+        }
+    }
+    const int n = d.nEdgesOnCell[c];
+    for (int i = 0; i < n; i++) {
+        int v = d.voc[(size_t)i * d.padC + c];
+        double pv[3];
+        rotated(a.xV, a.yV, a.zV, v, rot, pv);
+        double w0 = pv[0] - pc[0], w1 = pv[1] - pc[1], w2 = pv[2] - pc[2];
+        if (d.onSphere) {
+            d.xVOC[(size_t)i * d.padC + c] = r1[0] * w0 + r1[1] * w1 + r1[2] * w2;
+            d.yVOC[(size_t)i * d.padC + c] = r2[0] * w0 + r2[1] * w1 + r2[2] * w2;
+        } else {
+            d.xVOC[(size_t)i * d.padC + c] = w0;
+            d.yVOC[(size_t)i * d.padC + c] = w1;
+        }
+    }
+    int bad = 0;
+    for (int i = 0; i < n; i++) {
+        int ip1 = i + 1 >= n ? 0 : i + 1;
+        if (d.onSphere) {
+            double p1[3], p2[3];
+            rotated(a.xV, a.yV, a.zV, d.voc[(size_t)i * d.padC + c], rot, p1);
+            rotated(a.xV, a.yV, a.zV, d.voc[(size_t)ip1 * d.padC + c], rot, p2);
+            double a0 = p1[0] - pc[0], a1 = p1[1] - pc[1], a2 = p1[2] - pc[2];
+            double b0 = p2[0] - pc[0], b1 = p2[1] - pc[1], b2 = p2[2] - pc[2];
+            double w0 = a1 * b2 - a2 * b1, w1 = a2 * b0 - a0 * b2, w2 = a0 * b1 - a1 * b0;
+            if (!(w0 * pc[0] + w1 * pc[1] + w2 * pc[2] >= 0.0)) bad = 1;
+        }
+        if (!(cross2(d.xVOC[(size_t)i * d.padC + c], d.yVOC[(size_t)i * d.padC + c], d.xVOC[(size_t)ip1 * d.padC + c],
+                     d.yVOC[(size_t)ip1 * d.padC + c]) >= 0.0))
+            bad = 1;
+    }
+    if (bad) atomicOr(d.flag, FLAG_CCW);
+    if (c < d.nCellsSolve && !(d.areaCell[c] > 0.0)) atomicOr(d.flag, FLAG_AREA);  // :789-797
+}
+
+// per edge: get_geometry_incremental_remap :1255-1583 and the first loop of :1604-1635
+__global__ void k_ir_init_edges(IrDev d, IrInitArgs a)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= d.nEdges) return;
+    const int rot = d.rotate && d.onSphere;
+    const int nC = d.nCells, nE = d.nEdges;
+    int c1 = d.coe[e], c2 = d.coe[(size_t)d.padE + e];
+    int remap = (c1 < d.nCellsSolve || c2 < d.nCellsSolve) ? 1 : 0;
+    if (c1 >= nC || c2 >= nC) remap = 0;
+    d.remapEdge[e] = remap;
+    int v1 = d.voe[e], v2 = d.voe[(size_t)d.padE + e];
+    double pe[3], p1[3], p2[3], r1[3] = {0, 0, 0}, r2[3] = {0, 0, 0};
+    rotated(a.xE, a.yE, a.zE, e, rot, pe);
+    rotated(a.xV, a.yV, a.zV, v1, rot, p1);
+    rotated(a.xV, a.yV, a.zV, v2, rot, p2);
+    if (d.onSphere) {
+        localFrame(pe[0], pe[1], pe[2], r1, r2);
+        double w0 = p2[0] - p1[0], w1 = p2[1] - p1[1], w2 = p2[2] - p1[2];
+        double xv = r1[0] * w0 + r1[1] * w1 + r1[2] * w2;
+        double yv = r2[0] * w0 + r2[1] * w1 + r2[2] * w2;
+        d.xVOE[e] = -0.5 * xv;
+        d.yVOE[e] = -0.5 * yv;
+        d.xVOE[(size_t)d.padE + e] = 0.5 * xv;
+        d.yVOE[(size_t)d.padE + e] = 0.5 * yv;
+    } else if (remap) {
+        d.xVOE[e] = p1[0] - pe[0];
+        d.yVOE[e] = p1[1] - pe[1];
+        d.xVOE[(size_t)d.padE + e] = p2[0] - pe[0];
+        d.yVOE[(size_t)d.padE + e] = p2[1] - pe[1];
+    }
+    for (int k = 0; k < 4; k++) {
+        d.eoer[(size_t)k * d.padE + e] = nE;
+        d.coer[(size_t)k * d.padE + e] = nC;
+    }
+    if (!remap) return;
+    {  // cell 1 must lie in the left half-plane of V1 -> V2, :1296-1395
+        double ev[2][2], cc[2], pc[3];
+        const double *pp[2] = {p1, p2};
+        for (int k = 0; k < 2; k++) {
+            double w0 = pp[k][0] - pe[0], w1 = pp[k][1] - pe[1], w2 = pp[k][2] - pe[2];
+            if (d.onSphere) {
+                ev[k][0] = r1[0] * w0 + r1[1] * w1 + r1[2] * w2;
+                ev[k][1] = r2[0] * w0 + r2[1] * w1 + r2[2] * w2;
+            } else {
+                ev[k][0] = w0;
+                ev[k][1] = w1;
+            }
+        }
+        rotated(a.xC, a.yC, a.zC, c1, rot, pc);
+        double w0 = pc[0] - pe[0], w1 = pc[1] - pe[1], w2 = pc[2] - pe[2];
+        if (d.onSphere) {
+            cc[0] = r1[0] * w0 + r1[1] * w1 + r1[2] * w2;
+            cc[1] = r2[0] * w0 + r2[1] * w1 + r2[2] * w2;
+        } else {
+            cc[0] = w0;
+            cc[1] = w1;
+        }
+        if (!inHalfPlane(ev[0][0], ev[0][1], ev[1][0], ev[1][1], cc[0], cc[1])) atomicOr(d.flag, FLAG_HALFPLANE);
+    }
+    d.coer[e] = c1;
+    d.coer[(size_t)d.padE + e] = c2;
+    int eo[4] = {nE, nE, nE, nE};
+    for (int k = 0; k < 2; k++) {
+        int c = k == 0 ? c1 : c2;
+        int n = d.nEdgesOnCell[c], iMain = 0;
+        for (int i = 0; i < n; i++)
+            if (d.eoc[(size_t)i * d.padC + c] == e) {
+                iMain = i;
+                break;
+            }
+        int im = iMain - 1 < 0 ? iMain - 1 + n : iMain - 1;
+        int ip = iMain + 1 >= n ? iMain + 1 - n : iMain + 1;
+        if (k == 0) {
+            eo[0] = d.eoc[(size_t)im * d.padC + c];
+            eo[1] = d.eoc[(size_t)ip * d.padC + c];
+        } else {
+            eo[2] = d.eoc[(size_t)ip * d.padC + c];
+            eo[3] = d.eoc[(size_t)im * d.padC + c];
+        }
+    }
+    for (int k = 0; k < 4; k++) d.eoer[(size_t)k * d.padE + e] = eo[k];
+    for (int k = 0; k < 2; k++) {  // C3 and C4, :1513-1539
+        int en = eo[k];
+        if (en >= nE) en = eo[k + 2];
+        int found = nC;
+        for (int j = 0; j < 2; j++) {
+            int cn = d.coe[(size_t)j * d.padE + en];
+            if (cn < nC && cn != c1 && cn != c2) found = cn;
+        }
+        d.coer[(size_t)(k + 2) * d.padE + e] = found;
+    }
+}
+
+// per remap edge: coordinates of the distant vertices V3..V6, second loop of :1650-1699 / planar :1703-1760
+__global__ void k_ir_init_edge_vertices(IrDev d, IrInitArgs a)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= d.nEdges || d.remapEdge[e] != 1) return;
+    const int nE = d.nEdges;
+    int count = 2;
+    for (int k = 0; k < 4; k++) {
+        int en = d.eoer[(size_t)k * d.padE + e];
+        if (en >= nE) continue;
+        int n1 = 0, m1 = 0, m2 = 0;
+        for (int n = 0; n < 2; n++)
+            for (int m = 0; m < 2; m++)
+                if (d.voe[(size_t)m * d.padE + en] == d.voe[(size_t)n * d.padE + e]) {
+                    n1 = n;
+                    m1 = m;
+                    m2 = 1 - m;
+                    count = count + 1;
+                    break;
+                }
+        if (d.onSphere) {
+            d.xVOE[(size_t)(2 + k) * d.padE + e] =
+                d.xVOE[(size_t)n1 * d.padE + e] + (d.xVOE[(size_t)m2 * d.padE + en] - d.xVOE[(size_t)m1 * d.padE + en]);
+            d.yVOE[(size_t)(2 + k) * d.padE + e] =
+                d.yVOE[(size_t)n1 * d.padE + e] + (d.yVOE[(size_t)m2 * d.padE + en] - d.yVOE[(size_t)m1 * d.padE + en]);
+        } else {
+            int v = d.voe[(size_t)m2 * d.padE + en];
+            d.xVOE[(size_t)(count - 1) * d.padE + e] = a.xV[v] - a.xE[e];
+            d.yVOE[(size_t)(count - 1) * d.padE + e] = a.yV[v] - a.yE[e];
+        }
+    }
+}
+
+// per vertex: minLengthEdgesOnVertex :1764-1806
+__global__ void k_ir_init_vertices(IrDev d, IrInitArgs a)
+{
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= d.nVertices) return;
+    double mn = HUGE_R;
+    for (int k = 0; k < 3; k++) {
+        int e = d.eov[(size_t)k * d.padV + v];
+        if (e < d.nEdges) {
+            int v1 = d.voe[e], v2 = d.voe[(size_t)d.padE + e];
+            // the rotation of the frame permutes the components, so the squared length is summed in the
+            // rotated order like the reference does
+            double p1[3], p2[3];
+            rotated(a.xV, a.yV, a.zV, v1, d.rotate && d.onSphere, p1);
+            rotated(a.xV, a.yV, a.zV, v2, d.rotate && d.onSphere, p2);
+            double w0 = p2[0] - p1[0], w1 = p2[1] - p1[1], w2 = p2[2] - p1[2];
+            double len = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+            if (len < mn) mn = len;
+        }
+    }
+    d.minLen[v] = mn;
+}
+
+// per cell: compute_geometric_cell_averages :2097-2323
+__global__ void k_ir_init_geom(IrDev d)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nCells) return;
+    const int n = d.nEdgesOnCell[c];
+    double sumArea = 0.0;
+    for (int i = 0; i < n; i++) {
+        int e = d.eoc[(size_t)i * d.padC + c];
+        double fr = 0.25 * d.dcEdge[e] * d.dvEdge[e];
+        sumArea = sumArea + fr;
+    }
+    double acc[14];
+    for (int k = 0; k < 14; k++) acc[k] = 0.0;
+    for (int i = 0; i < n; i++) {
+        int e = d.eoc[(size_t)i * d.padC + c];
+        double frac = (0.25 * d.dcEdge[e] * d.dvEdge[e]) / sumArea;
+        int ip1 = i + 1 >= n ? 0 : i + 1;
+        const double x1 = 0.0, y1 = 0.0;
+        double x2 = d.xVOC[(size_t)i * d.padC + c], y2 = d.yVOC[(size_t)i * d.padC + c];
+        double x3 = d.xVOC[(size_t)ip1 * d.padC + c], y3 = d.yVOC[(size_t)ip1 * d.padC + c];
+        double xq[6], yq[6];
+        xq[0] = Q1QP * x1 + Q1QP * x2 + Q2QP * x3;  yq[0] = Q1QP * y1 + Q1QP * y2 + Q2QP * y3;
+        xq[1] = Q1QP * x1 + Q2QP * x2 + Q1QP * x3;  yq[1] = Q1QP * y1 + Q2QP * y2 + Q1QP * y3;
+        xq[2] = Q2QP * x1 + Q1QP * x2 + Q1QP * x3;  yq[2] = Q2QP * y1 + Q1QP * y2 + Q1QP * y3;
+        xq[3] = Q3QP * x1 + Q4QP * x2 + Q4QP * x3;  yq[3] = Q3QP * y1 + Q4QP * y2 + Q4QP * y3;
+        xq[4] = Q4QP * x1 + Q3QP * x2 + Q4QP * x3;  yq[4] = Q4QP * y1 + Q3QP * y2 + Q4QP * y3;
+        xq[5] = Q4QP * x1 + Q4QP * x2 + Q3QP * x3;  yq[5] = Q4QP * y1 + Q4QP * y2 + Q3QP * y3;
+        double av[14];
+        for (int k = 0; k < 14; k++) av[k] = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            double x = xq[q], y = yq[q], w = q < 3 ? W1QP : W2QP;
+            double xx = x * x, yy = y * y, xxx = xx * x, yyy = yy * y, xxxx = xx * xx, yyyy = yy * yy;
+            av[0] = av[0] + w * x;
+            av[1] = av[1] + w * y;
+            av[2] = av[2] + w * xx;
+            av[3] = av[3] + w * x * y;
+            av[4] = av[4] + w * yy;
+            av[5] = av[5] + w * xxx;
+            av[6] = av[6] + w * xx * y;
+            av[7] = av[7] + w * x * yy;
+            av[8] = av[8] + w * yyy;
+            av[9] = av[9] + w * xxxx;
+            av[10] = av[10] + w * xxx * y;
+            av[11] = av[11] + w * xx * yy;
+            av[12] = av[12] + w * x * yyy;
+            av[13] = av[13] + w * yyyy;
+        }
+        for (int k = 0; k < 14; k++) acc[k] = acc[k] + frac * av[k];
+    }
+    for (int k = 0; k < 14; k++) d.geom[(size_t)k * d.padC + c] = acc[k];
+}
+
+// ------------------------------------------------------------------------------------------ step kernels
+
+// volume_to_thickness :9248-9281 (toThickness) / thickness_to_volume :9295-9324, every block cell
+__global__ void k_ir_convert(IrDev d, const double *area, double *vol, int toThickness)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nCells) return;
+    size_t k = (size_t)blockIdx.y * d.padC + c;
+    double a = area[k];
+    if (toThickness)
+        vol[k] = a > 0.0 ? vol[k] / a : 0.0;
+    else
+        vol[k] = a * vol[k];
+}
+
+// maskCell of make_masks :3486-3492
+__global__ void k_ir_mask_cell(IrDev d, const double *mass)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nCells) return;
+    double s = 0.0;
+    for (int cat = 0; cat < d.nCat; cat++) s = s + mass[(size_t)cat * d.padC + c];
+    d.maskCell[c] = s > 0.0 ? 1 : 0;
+}
+
+// One tracer plane per blockIdx.y: compute_gradient :4204/:4429, limit_tracer_gradient :4802/:4999,
+// centre value :3785-3791, compute_barycenter_coordinates :4658-4787 (if the tracer has children) and
+// this tracer's mass*tracer product (compute_mass_tracer_products :6982-7109).
+__global__ void __launch_bounds__(256) k_ir_reconstruct(IrDev d, IrArgs a)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nCells) return;
+    const int l = blockIdx.y, cat = l / a.L, layer = l - cat * a.L;
+    const size_t pc = d.padC;
+    const size_t k = (size_t)l * pc + c;
+    const size_t lp = (size_t)(a.Lp == 1 ? cat : l) * pc;
+    const double f = a.val[k];
+    a.prod[k] = (a.parentProd ? a.parentProd[lp + c] : 1.0) * f;
+    double xb, yb;
+    if (a.parentXB) {
+        xb = a.parentXB[lp + c];
+        yb = a.parentYB[lp + c];
+    } else {
+        xb = d.geom[c];
+        yb = d.geom[pc + c];
+    }
+    double gxv = 0.0, gyv = 0.0;
+    const bool ice = d.maskCell[c] == 1;
+    if (ice) {
+        const int n = d.nEdgesOnCell[c];
+        const bool mc = a.parentVal ? (a.parentVal[lp + c] > EPS11) : true;
+        double g0 = 0.0, g1 = 0.0, g2 = 0.0, mx = f, mn = f;
+        for (int ie = 0; ie < n; ie++) {
+            int nb = d.coc[(size_t)ie * pc + c];
+            double ng = 0.0;
+            if (nb < d.nCells) {
+                bool mnb = a.parentVal ? (a.parentVal[lp + nb] > EPS11) : true;
+                double fnb = a.val[(size_t)l * pc + nb];
+                if (mc && mnb) {
+                    int e = d.eoc[(size_t)ie * pc + c];
+                    double sg = (c == d.coe[e]) ? 1.0 : -1.0;
+                    ng = sg * (fnb - f) / d.dcEdge[e];
+                }
+                if (mnb) {
+                    mx = fmax(mx, fnb);
+                    mn = fmin(mn, fnb);
+                }
+            }
+            g0 = g0 + d.coeffs[(size_t)(ie * 3 + 0) * pc + c] * ng;
+            g1 = g1 + d.coeffs[(size_t)(ie * 3 + 1) * pc + c] * ng;
+            g2 = g2 + d.coeffs[(size_t)(ie * 3 + 2) * pc + c] * ng;
+        }
+        if (d.rotate && d.onSphere) {  // :4353-4359
+            double t = g0;
+            g0 = -g2;
+            g2 = t;
+        }
+        if (d.onSphere) {
+            gxv = d.g2c[c] * g0 + d.g2c[pc + c] * g1 + d.g2c[2 * pc + c] * g2;
+            gyv = d.g2c[3 * pc + c] * g0 + d.g2c[4 * pc + c] * g1 + d.g2c[5 * pc + c] * g2;
+        } else {
+            gxv = g0;
+            gyv = g1;
+        }
+        // limiter
+        mx = mx - f;
+        mn = mn - f;
+        double lmx = 0.0, lmn = 0.0;
+        for (int iv = 0; iv < n; iv++) {
+            double dev = gxv * (d.xVOC[(size_t)iv * pc + c] - xb) + gyv * (d.yVOC[(size_t)iv * pc + c] - yb);
+            lmx = fmax(lmx, dev);
+            lmn = fmin(lmn, dev);
+        }
+        double f1 = fabs(lmx) > fabs(mx) ? fmax(0.0, mx / lmx) : 1.0;
+        double f2 = fabs(lmn) > fabs(mn) ? fmax(0.0, mn / lmn) : 1.0;
+        double fac = fmin(f1, f2);
+        fac = fmax(0.0, fac - EPS11);
+        gxv = gxv * fac;
+        gyv = gyv * fac;
+    }
+    const double cen = f - gxv * xb - gyv * yb;
+    a.gx[k] = gxv;
+    a.gy[k] = gyv;
+    a.center[k] = cen;
+    if (a.xB) {
+        double bx = 0.0, by = 0.0;
+        if (ice) {
+#define G(j) d.geom[(size_t)(j) * pc + c]
+            double mean[3], ce[3], gx[3], gy[3];
+            for (int j = 0; j < a.nLev - 1; j++) {
+                size_t kj = (size_t)(a.lev[j].L == 1 ? cat : cat * a.lev[j].L + layer) * pc + c;
+                mean[j] = a.lev[j].val[kj];
+                ce[j] = a.lev[j].center[kj];
+                gx[j] = a.lev[j].gx[kj];
+                gy[j] = a.lev[j].gy[kj];
+            }
+            mean[a.nLev - 1] = f;
+            ce[a.nLev - 1] = cen;
+            gx[a.nLev - 1] = gxv;
+            gy[a.nLev - 1] = gyv;
+            if (a.nLev == 1) {
+                double c0 = ce[0], cx = gx[0], cy = gy[0];
+                double rcp = fabs(mean[0]) > 0.0 ? 1.0 / mean[0] : 0.0;
+                bx = (c0 * G(0) + cx * G(2) + cy * G(3)) * rcp;
+                by = (c0 * G(1) + cx * G(3) + cy * G(4)) * rcp;
+            } else if (a.nLev == 2) {
+                double c0 = ce[0] * ce[1];
+                double cx = ce[0] * gx[1] + gx[0] * ce[1];
+                double cy = ce[0] * gy[1] + gy[0] * ce[1];
+                double cxx = gx[0] * gx[1];
+                double cxy = gx[0] * gy[1] + gy[0] * gx[1];
+                double cyy = gy[0] * gy[1];
+                double pr = mean[0] * mean[1];
+                double rcp = fabs(pr) > 0.0 ? 1.0 / pr : 0.0;
+                bx = (c0 * G(0) + cx * G(2) + cy * G(3) + cxx * G(5) + cxy * G(6) + cyy * G(7)) * rcp;
+                by = (c0 * G(1) + cx * G(3) + cy * G(4) + cxx * G(6) + cxy * G(7) + cyy * G(8)) * rcp;
+            } else {
+                double c0 = ce[0] * ce[1] * ce[2];
+                double cx = ce[0] * ce[1] * gx[2] + ce[0] * gx[1] * ce[2] + gx[0] * ce[1] * ce[2];
+                double cy = ce[0] * ce[1] * gy[2] + ce[0] * gy[1] * ce[2] + gy[0] * ce[1] * ce[2];
+                double cxx = ce[0] * gx[1] * gx[2] + gx[0] * ce[1] * gx[2] + gx[0] * gx[1] * ce[2];
+                double cxy = ce[0] * gx[1] * gy[2] + gx[0] * gy[1] * ce[2] + gy[0] * ce[1] * gx[2] +
+                             ce[0] * gy[1] * gx[2] + gx[0] * ce[1] * gy[2] + gy[0] * gx[1] * ce[2];
+                double cyy = ce[0] * gy[1] * gy[2] + gy[0] * ce[1] * gy[2] + gy[0] * gy[1] * ce[2];
+                double cxxx = gx[0] * gx[1] * gx[2];
+                double cxxy = gx[0] * gx[1] * gy[2] + gx[0] * gy[1] * gx[2] + gy[0] * gx[1] * gx[2];
+                double cxyy = gy[0] * gy[1] * gx[2] + gy[0] * gx[1] * gy[2] + gx[0] * gy[1] * gy[2];
+                double cyyy = gy[0] * gy[1] * gy[2];
+                double pr = mean[0] * mean[1] * mean[2];
+                double rcp = fabs(pr) > 0.0 ? 1.0 / pr : 0.0;
+                bx = (c0 * G(0) + cx * G(2) + cy * G(3) + cxx * G(5) + cxy * G(6) + cyy * G(7) + cxxx * G(9) +
+                      cxxy * G(10) + cxyy * G(11) + cyyy * G(12)) *
+                     rcp;
+                by = (c0 * G(1) + cx * G(3) + cy * G(4) + cxx * G(6) + cxy * G(7) + cyy * G(8) + cxxx * G(10) +
+                      cxxy * G(11) + cxyy * G(12) + cyyy * G(13)) *
+                     rcp;
+            }
+#undef G
+        }
+        a.xB[k] = bx;
+        a.yB[k] = by;
+    }
+}
+
+// find_departure_points :5255-5349
+__global__ void k_ir_departure_points(IrDev d, double dt)
+{
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= d.nVertices) return;
+    double dx = -d.u[v] * dt, dy = -d.v[v] * dt;
+    d.dp[v] = dx;
+    d.dp[(size_t)d.padV + v] = dy;
+    if (sqrt(dx * dx + dy * dy) > d.minLen[v]) atomicAdd(d.flag + 1, 1);
+}
+
+// shift_vertices_of_departure_triangle :6270-6500 followed by the signed area (:6231), then stored
+__device__ inline void emitTriangle(const IrDev &d, int e, int t, double xt[3], double yt[3], int tvoe, int cell,
+                                    double e1x, double e1y, double e2x, double e2y, int sign)
+{
+    const size_t pe = d.padE, pc = d.padC;
+    d.triCell[(size_t)t * pe + e] = cell;
+    double area = 0.0;
+    if (cell < d.nCells) {
+        const int n = d.nEdgesOnCell[cell];
+        int tvoc = 0;
+        const int vShared = d.voe[(size_t)tvoe * pe + e];
+        for (int iv = 0; iv < n; iv++)
+            if (d.voc[(size_t)iv * pc + cell] == vShared) tvoc = iv;
+        const double xe = d.xVOE[(size_t)tvoe * pe + e], ye = d.yVOE[(size_t)tvoe * pe + e];
+        const double xc = d.xVOC[(size_t)tvoc * pc + cell], yc = d.yVOC[(size_t)tvoc * pc + cell];
+        if (d.onSphere) {
+            double cp = cross2(e1x, e1y, e2x, e2y);
+            if (fabs(cp) < EPS11) atomicOr(d.flag, FLAG_PARALLEL);
+            if (cp > 0.0) {
+                double tx = e1x, ty = e1y;
+                e1x = e2x;
+                e1y = e2y;
+                e2x = tx;
+                e2y = ty;
+            }
+            int im1 = tvoc - 1 < 0 ? tvoc - 1 + n : tvoc - 1;
+            int ip1 = tvoc + 1 >= n ? tvoc + 1 - n : tvoc + 1;
+            double c1x = d.xVOC[(size_t)im1 * pc + cell] - xc, c1y = d.yVOC[(size_t)im1 * pc + cell] - yc;
+            double c2x = d.xVOC[(size_t)ip1 * pc + cell] - xc, c2y = d.yVOC[(size_t)ip1 * pc + cell] - yc;
+            double denom = e1x * e2y - e2x * e1y;
+            for (int k = 0; k < 3; k++) {
+                xt[k] = xt[k] - xe;
+                yt[k] = yt[k] - ye;
+                double ca = (xt[k] * e2y - yt[k] * e2x) / denom;
+                double cb = (yt[k] * e1x - xt[k] * e1y) / denom;
+                xt[k] = xc + ca * c1x + cb * c2x;
+                yt[k] = yc + ca * c1y + cb * c2y;
+            }
+        } else {
+            for (int k = 0; k < 3; k++) {
+                xt[k] = xt[k] - xe + xc;
+                yt[k] = yt[k] - ye + yc;
+            }
+        }
+        area = fabs(0.5 * ((xt[1] - xt[0]) * (yt[2] - yt[0]) - (yt[1] - yt[0]) * (xt[2] - xt[0])));
+        area = area * sign;
+    }
+    for (int k = 0; k < 3; k++) {
+        d.xTri[(size_t)(t * 3 + k) * pe + e] = xt[k];
+        d.yTri[(size_t)(t * 3 + k) * pe + e] = yt[k];
+    }
+    d.triArea[(size_t)t * pe + e] = area;
+}
+
+// find_departure_triangles :5365-6254, one edge per thread
+__global__ void __launch_bounds__(128) k_ir_triangles(IrDev d)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= d.nEdges) return;
+    const size_t pe = d.padE, pv = d.padV;
+    int masked = 0;
+    const int v1 = d.voe[e], v2 = d.voe[pe + e];
+    const double d1x = d.dp[v1], d1y = d.dp[pv + v1], d2x = d.dp[v2], d2y = d.dp[pv + v2];
+    if (d.remapEdge[e] == 1) {
+        if (d1x * d1x + d1y * d1y > 0.0) masked = 1;
+        if (d2x * d2x + d2y * d2y > 0.0) masked = 1;
+    }
+    if (!masked) {
+        d.triCount[e] = 0;
+        return;
+    }
+    double ev[2][2], dp[2][2];
+    ev[0][0] = d.xVOE[e];
+    ev[0][1] = d.yVOE[e];
+    ev[1][0] = d.xVOE[pe + e];
+    ev[1][1] = d.yVOE[pe + e];
+    dp[0][0] = ev[0][0] + d1x;
+    dp[0][1] = ev[0][1] + d1y;
+    dp[1][0] = ev[1][0] + d2x;
+    dp[1][1] = ev[1][1] + d2y;
+    int tc = 0;
+    // side triangles :5711-5968
+    for (int k = 0; k < 2; k++) {
+        for (int side = 0; side < 2; side++) {
+            int ieoe = k + 2 * side;  // 0-based E index: E1,E3 at V1; E2,E4 at V2
+            int en = d.eoer[(size_t)ieoe * pe + e];
+            bool hit = false;
+            double ix = 0.0, iy = 0.0, nx = 0.0, ny = 0.0;
+            if (en < d.nEdges) {
+                nx = d.xVOE[(size_t)(ieoe + 2) * pe + e];
+                ny = d.yVOE[(size_t)(ieoe + 2) * pe + e];
+                hit = lineIntersect(dp[0][0], dp[0][1], dp[1][0], dp[1][1], ev[k][0], ev[k][1], nx, ny, ix, iy);
+            }
+            if (hit) {
+                double xt[3] = {ev[k][0], dp[k][0], ix}, yt[3] = {ev[k][1], dp[k][1], iy};
+                int cell = d.coer[(size_t)(k + 2) * pe + e];
+                int other = ieoe + 2;
+                if (other > 3) other = other - 4;
+                double ox = d.xVOE[(size_t)(other + 2) * pe + e], oy = d.yVOE[(size_t)(other + 2) * pe + e];
+                if (tc < NTRI)
+                    emitTriangle(d, e, tc, xt, yt, k, cell, nx - ev[k][0], ny - ev[k][1], ox - ev[k][0], oy - ev[k][1],
+                                 side == 0 ? 1 : -1);
+                tc = tc + 1;
+                dp[k][0] = ix;
+                dp[k][1] = iy;
+            }
+        }
+    }
+    // central triangles :5970-6183
+    double mx, my;
+    bool hitMain = lineIntersect(dp[0][0], dp[0][1], dp[1][0], dp[1][1], ev[0][0], ev[0][1], ev[1][0], ev[1][1], mx, my);
+    bool doCentral = hitMain;
+    if (!hitMain) {
+        // quadrilateral_area(V1, V2, D2, D1) :9137-9158
+        double t1 = triArea2(ev[0][0], ev[0][1], ev[1][0], ev[1][1], dp[1][0], dp[1][1]);
+        double t2 = triArea2(ev[0][0], ev[0][1], dp[1][0], dp[1][1], dp[0][0], dp[0][1]);
+        doCentral = (t1 + t2) > 0.0;
+    }
+    if (doCentral) {
+        for (int k = 0; k < 2; k++) {
+            const int o = 1 - k;
+            double xt[3], yt[3];
+            if (hitMain) {  // V, D, IP0
+                xt[0] = ev[k][0];  yt[0] = ev[k][1];
+                xt[1] = dp[k][0];  yt[1] = dp[k][1];
+                xt[2] = mx;        yt[2] = my;
+            } else if (k == 0) {  // V1, V2, D1
+                xt[0] = ev[0][0];  yt[0] = ev[0][1];
+                xt[1] = ev[1][0];  yt[1] = ev[1][1];
+                xt[2] = dp[0][0];  yt[2] = dp[0][1];
+            } else {  // V2, D1, D2
+                xt[0] = ev[1][0];  yt[0] = ev[1][1];
+                xt[1] = dp[0][0];  yt[1] = dp[0][1];
+                xt[2] = dp[1][0];  yt[2] = dp[1][1];
+            }
+            bool inHP = inHalfPlane(ev[0][0], ev[0][1], ev[1][0], ev[1][1], dp[k][0], dp[k][1]);
+            int cell = d.coer[(size_t)(inHP ? 0 : 1) * pe + e];
+            int other = inHP ? k : k + 2;
+            double ox = d.xVOE[(size_t)(other + 2) * pe + e], oy = d.yVOE[(size_t)(other + 2) * pe + e];
+            if (tc < NTRI)
+                emitTriangle(d, e, tc, xt, yt, k, cell, ev[o][0] - ev[k][0], ev[o][1] - ev[k][1], ox - ev[k][0],
+                             oy - ev[k][1], inHP ? 1 : -1);
+            tc = tc + 1;
+        }
+    }
+    d.triCount[e] = tc < NTRI ? tc : NTRI;
+}
+
+// integrate_fluxes_over_triangles :6667-6967 for one tracer: thread = (edge, plane)
+__global__ void __launch_bounds__(256) k_ir_flux(IrDev d, IrArgs a)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= d.nEdges) return;
+    const int l = blockIdx.y, cat = l / a.L, layer = l - cat * a.L;
+    const size_t pe = d.padE, pc = d.padC;
+    const int cnt = d.triCount[e];
+    double flux = 0.0;
+    size_t plane[4];
+    for (int j = 0; j < a.nLev; j++) plane[j] = (size_t)(a.lev[j].L == 1 ? cat : cat * a.lev[j].L + layer) * pc;
+    for (int t = 0; t < cnt; t++) {
+        const double area = d.triArea[(size_t)t * pe + e];
+        if (area == 0.0) continue;
+        const int c = d.triCell[(size_t)t * pe + e];
+        const double x1 = d.xTri[(size_t)(t * 3) * pe + e], x2 = d.xTri[(size_t)(t * 3 + 1) * pe + e],
+                     x3 = d.xTri[(size_t)(t * 3 + 2) * pe + e];
+        const double y1 = d.yTri[(size_t)(t * 3) * pe + e], y2 = d.yTri[(size_t)(t * 3 + 1) * pe + e],
+                     y3 = d.yTri[(size_t)(t * 3 + 2) * pe + e];
+        double xq[6], yq[6];  // get_triangle_quadrature_points :6605-6644
+        xq[0] = Q1QP * x1 + Q1QP * x2 + Q2QP * x3;  yq[0] = Q1QP * y1 + Q1QP * y2 + Q2QP * y3;
+        xq[1] = Q1QP * x1 + Q2QP * x2 + Q1QP * x3;  yq[1] = Q1QP * y1 + Q2QP * y2 + Q1QP * y3;
+        xq[2] = Q2QP * x1 + Q1QP * x2 + Q1QP * x3;  yq[2] = Q2QP * y1 + Q1QP * y2 + Q1QP * y3;
+        xq[3] = Q3QP * x1 + Q4QP * x2 + Q4QP * x3;  yq[3] = Q3QP * y1 + Q4QP * y2 + Q4QP * y3;
+        xq[4] = Q4QP * x1 + Q3QP * x2 + Q4QP * x3;  yq[4] = Q4QP * y1 + Q3QP * y2 + Q4QP * y3;
+        xq[5] = Q4QP * x1 + Q4QP * x2 + Q3QP * x3;  yq[5] = Q4QP * y1 + Q4QP * y2 + Q3QP * y3;
+        double val[6] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+        for (int j = 0; j < a.nLev; j++) {
+            const double cj = a.lev[j].center[plane[j] + c], gxj = a.lev[j].gx[plane[j] + c],
+                         gyj = a.lev[j].gy[plane[j] + c];
+#pragma unroll
+            for (int q = 0; q < 6; q++) val[q] = val[q] * (cj + gxj * xq[q] + gyj * yq[q]);
+        }
+        double integral = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) integral = integral + (q < 3 ? W1QP : W2QP) * val[q];
+        if (a.isMass) {
+            bool neg = false;
+#pragma unroll
+            for (int q = 0; q < 6; q++) neg = neg || (val[q] < 0.0);
+            if (neg) atomicOr(d.flag, FLAG_NEGAREA);
+        }
+        flux = flux + area * integral;
+    }
+    a.flux[(size_t)l * pe + e] = flux;
+}
+
+// update_mass_and_tracers :7125-7523 for one tracer: thread = (owned cell, plane)
+__global__ void __launch_bounds__(256) k_ir_update(IrDev d, IrArgs a)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nCellsSolve) return;
+    const int l = blockIdx.y, cat = l / a.L;
+    const size_t pc = d.padC, pe = d.padE;
+    const size_t k = (size_t)l * pc + c;
+    const int n = d.nEdgesOnCell[c];
+    double flux = 0.0;
+    for (int ie = 0; ie < n; ie++) {
+        int e = d.eoc[(size_t)ie * pc + c];
+        double sg = (c == d.coe[e]) ? 1.0 : -1.0;
+        flux = flux + a.flux[(size_t)l * pe + e] * sg;
+    }
+    const double pp = a.parentProd ? a.parentProd[(size_t)(a.Lp == 1 ? cat : l) * pc + c] : 1.0;
+    double nv;
+    if (pp > 0.0)
+        nv = (a.prod[k] - (flux / d.areaCell[c])) / pp;
+    else
+        nv = 0.0;
+    a.prod[k] = pp * nv;
+    if (a.isMass) {  // :7465-7507
+        if (nv < -EPS11 * EPS11)
+            atomicOr(d.flag, FLAG_NEGMASS);
+        else if (nv < 0.0)
+            nv = 0.0;
+    }
+    a.val[k] = nv;
+}
+
+// zap_small_mass :8764-8886: thread = (owned cell, category)
+__global__ void k_ir_zap(IrDev d, const IrZapEntry *tab, int nTracers)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nCellsSolve) return;
+    const int cat = blockIdx.y;
+    double *mass = tab[0].val;
+    double m = mass[(size_t)cat * d.padC + c];
+    if (m > 0.0 && m < 1.0e-22) {
+        mass[(size_t)cat * d.padC + c] = 0.0;
+        for (int i = 1; i < nTracers; i++)
+            for (int ly = 0; ly < tab[i].L; ly++) tab[i].val[(size_t)(cat * tab[i].L + ly) * d.padC + c] = 0.0;
+    }
+}
+
+// sum_tracers :7998-8111: one block per plane, sum over the owned cells of areaCell * (product of the chain's
+// values); the order of additions differs from the reference's serial loop (tree reduction)
+__global__ void k_ir_sum(IrDev d, IrArgs a, double *out)
+{
+    __shared__ double sh[256];
+    const int l = blockIdx.x, cat = l / a.L, layer = l - cat * a.L;
+    double s = 0.0;
+    for (int c = threadIdx.x; c < d.nCellsSolve; c += blockDim.x) {
+        double p = 1.0;
+        for (int j = 0; j < a.nLev; j++)
+            p = p * a.lev[j].val[(size_t)(a.lev[j].L == 1 ? cat : cat * a.lev[j].L + layer) * d.padC + c];
+        s = s + d.areaCell[c] * p;
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = blockDim.x / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] = sh[threadIdx.x] + sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[l] = sh[0];
+}
+
+__global__ void k_ir_zero_flags(int *p)
+{
+    if (threadIdx.x < 16) p[threadIdx.x] = 0;
+}
+
+// ------------------------------------------------------------------------------------------ host side
+static int uploadPlaneInts(sih_ctx *c, int *dst, const std::vector<int> &v)
+{
+    HIPCHK(hipMemcpyAsync(dst, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SIH_OK;
+}
+
+extern "C" int sih_ir_init(sih_ctx *c, const sih_ir_desc *m)
+{
+    if (!c || !m) {
+        sih_set_error("sih_ir_init: null argument");
+        return SIH_ERR_ARG;
+    }
+    if (!m->edgesOnCell || !m->cellsOnEdge || !m->verticesOnEdge || !m->edgesOnVertex || !m->xEdge || !m->yEdge ||
+        !m->zEdge || !m->dcEdge || !m->dvEdge || !m->coeffsReconstruct || m->nCategories < 1 || c->nEdges < 1) {
+        sih_set_error("sih_ir_init: incomplete edge description of the mesh");
+        return SIH_ERR_ARG;
+    }
+    if (c->D != 3) {
+        sih_set_error("incremental remap: only vertexDegree = 3 (hexagonal meshes) is implemented");
+        return SIH_ERR_UNSUPPORTED;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    const int nC = c->nCells, nV = c->nVertices, nE = c->nEdges, M = c->M;
+    // validate connectivity before the device dereferences it
+    for (int e = 0; e < nE; e++)
+        for (int k = 0; k < 2; k++) {
+            int cc = m->cellsOnEdge[(size_t)e * 2 + k], vv = m->verticesOnEdge[(size_t)e * 2 + k];
+            if (cc < 0 || cc > nC + 1 || vv < 1 || vv > nV) {
+                sih_set_error("sih_ir_init: cellsOnEdge / verticesOnEdge index out of range");
+                return SIH_ERR_ARG;
+            }
+        }
+    for (int i = 0; i < nC; i++)
+        for (int s = 0; s < M; s++) {
+            int e = m->edgesOnCell[(size_t)i * M + s];
+            if (e < 0 || e > nE + 1) {
+                sih_set_error("sih_ir_init: edgesOnCell index out of range");
+                return SIH_ERR_ARG;
+            }
+        }
+    for (size_t k = 0; k < (size_t)nV * 3; k++)
+        if (m->edgesOnVertex[k] < 0 || m->edgesOnVertex[k] > nE + 1) {
+            sih_set_error("sih_ir_init: edgesOnVertex index out of range");
+            return SIH_ERR_ARG;
+        }
+    if (c->ir) sih_ir_destroy(c);
+    sih_ir_state *ir = new sih_ir_state();
+    c->ir = ir;
+    ir->nCat = m->nCategories;
+
+    // internal edge numbering: edges follow the lower-numbered (internal) of their two cells
+    c->edgePerm.resize(nE);
+    for (int e = 0; e < nE; e++) c->edgePerm[e] = e;
+    if (c->renumber) {
+        std::vector<int> key(nE, nC);
+        for (int e = 0; e < nE; e++)
+            for (int k = 0; k < 2; k++) {
+                int cc = m->cellsOnEdge[(size_t)e * 2 + k];
+                if (cc >= 1 && cc <= nC) key[e] = std::min(key[e], c->cellInv[cc - 1]);
+            }
+        std::stable_sort(c->edgePerm.begin(), c->edgePerm.end(), [&](int a, int b) { return key[a] < key[b]; });
+    }
+    c->edgeInv.assign(nE + 1, nE);
+    for (int i = 0; i < nE; i++) c->edgeInv[c->edgePerm[i]] = i;
+    int rc;
+    if (!c->d_edgePerm && (rc = sih_dev_alloc(c, (void **)&c->d_edgePerm, sizeof(int) * c->padE))) return rc;
+    HIPCHK(hipMemcpyAsync(c->d_edgePerm, c->edgePerm.data(), sizeof(int) * nE, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+
+    struct Spec {
+        const char *name;
+        SihLoc loc;
+        int lead;
+        bool isInt;
+    };
+    const Spec specs[] = {
+        {"_eoc", LOC_CELL, M, true}, {"_coe", LOC_EDGE, 2, true}, {"_voe", LOC_EDGE, 2, true},
+        {"_eov", LOC_VERTEX, 3, true}, {"remapEdge", LOC_EDGE, 1, true}, {"_eoer", LOC_EDGE, 4, true},
+        {"_coer", LOC_EDGE, 4, true}, {"_g2c", LOC_CELL, 6, false},
+        {"xVertexOnCell", LOC_CELL, M, false}, {"yVertexOnCell", LOC_CELL, M, false},
+        {"xVertexOnEdge", LOC_EDGE, 6, false}, {"yVertexOnEdge", LOC_EDGE, 6, false},
+        {"geomAvgCell", LOC_CELL, 14, false}, {"minLengthEdgesOnVertex", LOC_VERTEX, 1, false},
+        {"xEdge", LOC_EDGE, 1, false}, {"yEdge", LOC_EDGE, 1, false}, {"zEdge", LOC_EDGE, 1, false},
+        {"dcEdge", LOC_EDGE, 1, false}, {"dvEdge", LOC_EDGE, 1, false},
+        {"coeffs_reconstruct", LOC_CELL, 3 * M, false},
+        {"departurePoint", LOC_VERTEX, 2, false}, {"_triCount", LOC_EDGE, 1, true},
+        {"_triCell", LOC_EDGE, NTRI, true}, {"xTriangle", LOC_EDGE, 3 * NTRI, false},
+        {"yTriangle", LOC_EDGE, 3 * NTRI, false}, {"triangleArea", LOC_EDGE, NTRI, false},
+        {"maskCell", LOC_CELL, 1, true},
+    };
+    for (const Spec &s : specs)
+        if ((rc = sih_add_field(c, s.name, s.loc, s.lead, s.isInt))) return rc;
+    auto fi = [&](const char *n) { return (int *)sih_find_field(c, n)->d; };
+    auto fd = [&](const char *n) { return (double *)sih_find_field(c, n)->d; };
+
+    // connectivity in internal numbering
+    {
+        std::vector<int> eoc((size_t)M * c->padC, nE), coe((size_t)2 * c->padE, nC), voe((size_t)2 * c->padE, nV),
+            eov((size_t)3 * c->padV, nE);
+        for (int i = 0; i < nC; i++) {
+            int h = c->cellPerm[i];
+            for (int s = 0; s < M; s++) {
+                int e = m->edgesOnCell[(size_t)h * M + s];
+                eoc[(size_t)s * c->padC + i] = (e >= 1 && e <= nE) ? c->edgeInv[e - 1] : nE;
+            }
+        }
+        for (int i = 0; i < nE; i++) {
+            int h = c->edgePerm[i];
+            for (int k = 0; k < 2; k++) {
+                int cc = m->cellsOnEdge[(size_t)h * 2 + k], vv = m->verticesOnEdge[(size_t)h * 2 + k];
+                coe[(size_t)k * c->padE + i] = (cc >= 1 && cc <= nC) ? c->cellInv[cc - 1] : nC;
+                voe[(size_t)k * c->padE + i] = c->vertInv[vv - 1];
+            }
+        }
+        for (int i = 0; i < nV; i++) {
+            int h = c->vertPerm[i];
+            for (int k = 0; k < 3; k++) {
+                int e = m->edgesOnVertex[(size_t)h * 3 + k];
+                eov[(size_t)k * c->padV + i] = (e >= 1 && e <= nE) ? c->edgeInv[e - 1] : nE;
+            }
+        }
+        if ((rc = uploadPlaneInts(c, fi("_eoc"), eoc))) return rc;
+        if ((rc = uploadPlaneInts(c, fi("_coe"), coe))) return rc;
+        if ((rc = uploadPlaneInts(c, fi("_voe"), voe))) return rc;
+        if ((rc = uploadPlaneInts(c, fi("_eov"), eov))) return rc;
+    }
+    if ((rc = sih_field_put(c, "xEdge", m->xEdge, nE))) return rc;
+    if ((rc = sih_field_put(c, "yEdge", m->yEdge, nE))) return rc;
+    if ((rc = sih_field_put(c, "zEdge", m->zEdge, nE))) return rc;
+    if ((rc = sih_field_put(c, "dcEdge", m->dcEdge, nE))) return rc;
+    if ((rc = sih_field_put(c, "dvEdge", m->dvEdge, nE))) return rc;
+    if ((rc = sih_field_put(c, "coeffs_reconstruct", m->coeffsReconstruct, (size_t)3 * M * nC))) return rc;
+
+    IrDev &d = ir->d;
+    d.nCells = nC;
+    d.nCellsSolve = c->nCellsSolve;
+    d.nVertices = nV;
+    d.nEdges = nE;
+    d.M = M;
+    d.nCat = ir->nCat;
+    d.padC = c->padC;
+    d.padV = c->padV;
+    d.padE = c->padE;
+    d.onSphere = c->onASphere;
+    d.rotate = m->rotateCartesianGrid;
+    d.nEdgesOnCell = fi("_nEdgesOnCell");
+    d.voc = fi("_voc");
+    d.coc = fi("_coc");
+    d.eoc = fi("_eoc");
+    d.coe = fi("_coe");
+    d.voe = fi("_voe");
+    d.eov = fi("_eov");
+    d.remapEdge = fi("remapEdge");
+    d.eoer = fi("_eoer");
+    d.coer = fi("_coer");
+    d.g2c = fd("_g2c");
+    d.xVOC = fd("xVertexOnCell");
+    d.yVOC = fd("yVertexOnCell");
+    d.xVOE = fd("xVertexOnEdge");
+    d.yVOE = fd("yVertexOnEdge");
+    d.geom = fd("geomAvgCell");
+    d.minLen = fd("minLengthEdgesOnVertex");
+    d.dcEdge = fd("dcEdge");
+    d.dvEdge = fd("dvEdge");
+    d.coeffs = fd("coeffs_reconstruct");
+    d.areaCell = fd("areaCell");
+    d.u = fd("uVelocity");
+    d.v = fd("vVelocity");
+    d.dp = fd("departurePoint");
+    d.triCount = fi("_triCount");
+    d.triCell = fi("_triCell");
+    d.xTri = fd("xTriangle");
+    d.yTri = fd("yTriangle");
+    d.triArea = fd("triangleArea");
+    d.maskCell = fi("maskCell");
+    d.flag = c->d_flag;
+
+    IrInitArgs a{fd("xCell"), fd("yCell"), fd("zCell"), fd("xVertex"), fd("yVertex"), fd("zVertex"),
+                 fd("xEdge"), fd("yEdge"),  fd("zEdge")};
+    dim3 blk(256);
+    hipLaunchKernelGGL(k_ir_zero_flags, dim3(1), dim3(64), 0, c->stream, c->d_flag);
+    hipLaunchKernelGGL(k_ir_init_cells, dim3((nC + 255) / 256), blk, 0, c->stream, d, a);
+    hipLaunchKernelGGL(k_ir_init_edges, dim3((nE + 255) / 256), blk, 0, c->stream, d, a);
+    hipLaunchKernelGGL(k_ir_init_edge_vertices, dim3((nE + 255) / 256), blk, 0, c->stream, d, a);
+    hipLaunchKernelGGL(k_ir_init_vertices, dim3((nV + 255) / 256), blk, 0, c->stream, d, a);
+    hipLaunchKernelGGL(k_ir_init_geom, dim3((nC + 255) / 256), blk, 0, c->stream, d);
+    HIPCHK(hipGetLastError());
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (flag & FLAG_CCW) {
+        sih_set_error("IR requires convex cells with vertices arranged CCW around the cell");
+        return SIH_ERR_ARG;
+    }
+    if (flag & FLAG_HALFPLANE) {
+        sih_set_error("IR: cell 1 is not in the left half-plane of an edge");
+        return SIH_ERR_ARG;
+    }
+    if (flag & FLAG_AREA) {
+        sih_set_error("IR: Bad cell area");
+        return SIH_ERR_ARG;
+    }
+    for (hipEvent_t &e : ir->ev) HIPCHK(hipEventCreate(&e));
+    ir->inited = true;
+    return SIH_OK;
+}
+
+extern "C" int sih_ir_set_tracers(sih_ctx *c, int nTracers, const char *const *names, const char *const *parents,
+                                  const int32_t *nLayers)
+{
+    if (!c || !c->ir || !c->ir->inited) {
+        sih_set_error("sih_ir_set_tracers: call sih_ir_init first");
+        return SIH_ERR_STATE;
+    }
+    if (nTracers < 1 || !names || !parents || !nLayers) {
+        sih_set_error("IR tracers: No active tracers for IR");
+        return SIH_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    sih_ir_state *ir = c->ir;
+    std::vector<IrTracer> list(nTracers);
+    for (int i = 0; i < nTracers; i++) {
+        IrTracer &t = list[i];
+        t.name = names[i];
+        t.L = nLayers[i];
+        if (t.L < 1) {
+            sih_set_error("IR tracers: nLayers must be positive");
+            return SIH_ERR_ARG;
+        }
+        std::string p = parents[i] ? parents[i] : "None";
+        if (i == 0) {
+            if (p != "None" || t.L != 1) {
+                sih_set_error("IR: mass-like field must come first, have no parent and be 2D");
+                return SIH_ERR_ARG;
+            }
+        } else {
+            for (int j = 0; j < i; j++)
+                if (list[j].name == p) t.parent = j;
+            if (t.parent < 0) {
+                sih_set_error("IR tracers: parent must precede its child in the list: " + t.name);
+                return SIH_ERR_ARG;
+            }
+            IrTracer &pt = list[t.parent];
+            pt.hasChild = true;
+            t.nParents = pt.nParents + 1;
+            if (t.nParents > 3) {
+                sih_set_error("Tracer has > 3 parents: " + t.name);
+                return SIH_ERR_ARG;
+            }
+            if (pt.L != 1 && pt.L != t.L) {
+                sih_set_error("IR tracers: a layered parent must have the layer count of its child: " + t.name);
+                return SIH_ERR_ARG;
+            }
+        }
+    }
+    for (IrTracer &t : list)
+        if (t.hasChild && t.nParents == 3) {
+            sih_set_error("IR, construct_linear_tracer_fields: Tracers with 3 parents should not have children");
+            return SIH_ERR_ARG;
+        }
+    int rc;
+    int maxLead = 0;
+    for (IrTracer &t : list) {
+        const int lead = t.L * ir->nCat;
+        maxLead = std::max(maxLead, lead);
+        if ((rc = sih_add_field(c, t.name.c_str(), LOC_CELL, lead, false))) return rc;
+        t.val = (double *)sih_find_field(c, t.name.c_str())->d;
+        struct {
+            const char *suffix;
+            double **p;
+            SihLoc loc;
+            bool need;
+        } sc[] = {{"Center", &t.center, LOC_CELL, true},       {"Gradx", &t.gx, LOC_CELL, true},
+                  {"Grady", &t.gy, LOC_CELL, true},            {"Product", &t.prod, LOC_CELL, true},
+                  {"Barycenterx", &t.xB, LOC_CELL, t.hasChild}, {"Barycentery", &t.yB, LOC_CELL, t.hasChild},
+                  {"EdgeFlux", &t.flux, LOC_EDGE, true}};
+        for (auto &s : sc) {
+            if (!s.need) continue;
+            std::string fn = t.name + s.suffix;
+            if ((rc = sih_add_field(c, fn.c_str(), s.loc, lead, false))) return rc;
+            *s.p = (double *)sih_find_field(c, fn.c_str())->d;
+        }
+        t.sumInit.assign(lead, 0.0);
+        t.sumFinal.assign(lead, 0.0);
+    }
+    ir->tracers = list;
+    ir->iVol = ir->iSnow = -1;
+    for (int i = 0; i < nTracers; i++) {
+        if (list[i].name == "iceVolumeCategory") ir->iVol = i;
+        if (list[i].name == "snowVolumeCategory") ir->iSnow = i;
+    }
+    std::vector<IrZapEntry> tab(nTracers);
+    for (int i = 0; i < nTracers; i++) tab[i] = IrZapEntry{list[i].val, list[i].L};
+    if (ir->d_zap) HIPCHK(hipFree(ir->d_zap));
+    HIPCHK(hipMalloc((void **)&ir->d_zap, sizeof(IrZapEntry) * nTracers));
+    HIPCHK(hipMemcpy(ir->d_zap, tab.data(), sizeof(IrZapEntry) * nTracers, hipMemcpyHostToDevice));
+    if (ir->d_sums) HIPCHK(hipFree(ir->d_sums));
+    HIPCHK(hipMalloc((void **)&ir->d_sums, sizeof(double) * maxLead));
+    return SIH_OK;
+}
+
+static IrArgs makeArgs(const sih_ir_state *ir, int i)
+{
+    const IrTracer &t = ir->tracers[i];
+    IrArgs a{};
+    a.L = t.L;
+    a.isMass = t.parent < 0;
+    a.nLev = t.nParents + 1;
+    int j = i;
+    for (int k = a.nLev - 1; k >= 0; k--) {
+        const IrTracer &tj = ir->tracers[j];
+        a.lev[k] = IrLevel{tj.val, tj.center, tj.gx, tj.gy, tj.L};
+        j = tj.parent;
+    }
+    a.val = t.val;
+    a.center = t.center;
+    a.gx = t.gx;
+    a.gy = t.gy;
+    a.xB = t.xB;
+    a.yB = t.yB;
+    a.prod = t.prod;
+    a.flux = t.flux;
+    if (t.parent >= 0) {
+        const IrTracer &p = ir->tracers[t.parent];
+        a.Lp = p.L;
+        a.parentVal = p.val;
+        a.parentXB = p.xB;
+        a.parentYB = p.yB;
+        a.parentProd = p.prod;
+    } else {
+        a.Lp = 1;
+    }
+    return a;
+}
+
+static int irSums(sih_ctx *c, bool init)
+{
+    sih_ir_state *ir = c->ir;
+    for (size_t i = 0; i < ir->tracers.size(); i++) {
+        IrTracer &t = ir->tracers[i];
+        const int lead = t.L * ir->nCat;
+        hipLaunchKernelGGL(k_ir_sum, dim3(lead), dim3(256), 0, c->stream, ir->d, makeArgs(ir, (int)i), ir->d_sums);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync((init ? t.sumInit : t.sumFinal).data(), ir->d_sums, sizeof(double) * lead,
+                              hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return SIH_OK;
+}
+
+static int irRun(sih_ctx *c, double dt, int checkConservation, bool timed, double *totalMs, double *phaseMs)
+{
+    if (!c || !c->ir || !c->ir->inited || c->ir->tracers.empty()) {
+        sih_set_error("sih_ir_run: call sih_ir_init and sih_ir_set_tracers first");
+        return SIH_ERR_STATE;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    sih_ir_state *ir = c->ir;
+    IrDev &d = ir->d;
+    const int nT = (int)ir->tracers.size();
+    const dim3 blk(256);
+    const unsigned gC = (d.nCells + 255) / 256, gCs = (d.nCellsSolve + 255) / 256, gE = (d.nEdges + 255) / 256,
+                   gV = (d.nVertices + 255) / 256;
+    hipStream_t s = c->stream;
+    auto mark = [&](int i) {
+        if (timed) hipEventRecord(ir->ev[i], s);
+    };
+    mark(0);
+    hipLaunchKernelGGL(k_ir_zero_flags, dim3(1), dim3(64), 0, s, c->d_flag);
+    // volume -> thickness :2502-2544, masks :3023-3029
+    const double *area = ir->tracers[0].val;
+    for (int i : {ir->iVol, ir->iSnow})
+        if (i >= 0)
+            hipLaunchKernelGGL(k_ir_convert, dim3(gC, d.nCat), blk, 0, s, d, area, ir->tracers[i].val, 1);
+    hipLaunchKernelGGL(k_ir_mask_cell, dim3(gC), blk, 0, s, d, area);
+    mark(1);
+    // construct_linear_tracer_fields :3580-4189, compute_mass_tracer_products :6982
+    for (int i = 0; i < nT; i++)
+        hipLaunchKernelGGL(k_ir_reconstruct, dim3(gC, ir->tracers[i].L * d.nCat), blk, 0, s, d, makeArgs(ir, i));
+    mark(2);
+    hipLaunchKernelGGL(k_ir_departure_points, dim3(gV), blk, 0, s, d, dt);
+    hipLaunchKernelGGL(k_ir_triangles, dim3((d.nEdges + 127) / 128), dim3(128), 0, s, d);
+    mark(3);
+    for (int i = 0; i < nT; i++)
+        hipLaunchKernelGGL(k_ir_flux, dim3(gE, ir->tracers[i].L * d.nCat), blk, 0, s, d, makeArgs(ir, i));
+    mark(4);
+    HIPCHK(hipGetLastError());
+    int rc;
+    if (checkConservation && (rc = irSums(c, true))) return rc;
+    for (int i = 0; i < nT; i++)
+        hipLaunchKernelGGL(k_ir_update, dim3(gCs, ir->tracers[i].L * d.nCat), blk, 0, s, d, makeArgs(ir, i));
+    if (checkConservation && (rc = irSums(c, false))) return rc;
+    hipLaunchKernelGGL(k_ir_zap, dim3(gCs, d.nCat), blk, 0, s, d, ir->d_zap, nT);
+    // thickness -> volume :2608-2650
+    for (int i : {ir->iVol, ir->iSnow})
+        if (i >= 0)
+            hipLaunchKernelGGL(k_ir_convert, dim3(gC, d.nCat), blk, 0, s, d, area, ir->tracers[i].val, 0);
+    mark(5);
+    HIPCHK(hipGetLastError());
+    int flags[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(flags, c->d_flag, sizeof(flags), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    ir->cflWarnings = flags[1];
+    if (timed) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ir->ev[0], ir->ev[5]));
+        if (totalMs) *totalMs = ms;
+        for (int i = 0; i < 5 && phaseMs; i++) {
+            HIPCHK(hipEventElapsedTime(&ms, ir->ev[i], ir->ev[i + 1]));
+            phaseMs[i] = ms;
+        }
+    }
+    if (flags[0] & FLAG_PARALLEL) {
+        sih_set_error("IR: basis vectors for IR coordinate transformations must not be parallel");
+        return SIH_ERR_IR;
+    }
+    if (flags[0] & FLAG_NEGAREA) {
+        sih_set_error("MPAS-seaice: IR negative reconstructed ice area");
+        return SIH_ERR_IR;
+    }
+    if (flags[0] & FLAG_NEGMASS) {
+        sih_set_error("IR: Negative mass in IR");
+        return SIH_ERR_IR;
+    }
+    return SIH_OK;
+}
+
+extern "C" int sih_ir_run(sih_ctx *c, double dt, int checkConservation)
+{
+    return irRun(c, dt, checkConservation, false, nullptr, nullptr);
+}
+
+extern "C" int sih_ir_run_timed(sih_ctx *c, double dt, double *totalMs, double *phaseMs5)
+{
+    return irRun(c, dt, 0, true, totalMs, phaseMs5);
+}
+
+extern "C" int sih_ir_get_sums(sih_ctx *c, const char *tracer, double *initSums, double *finalSums)
+{
+    if (!c || !c->ir || !tracer || !initSums || !finalSums) {
+        sih_set_error("sih_ir_get_sums: bad argument");
+        return SIH_ERR_ARG;
+    }
+    for (IrTracer &t : c->ir->tracers)
+        if (t.name == tracer) {
+            memcpy(initSums, t.sumInit.data(), sizeof(double) * t.sumInit.size());
+            memcpy(finalSums, t.sumFinal.data(), sizeof(double) * t.sumFinal.size());
+            return SIH_OK;
+        }
+    sih_set_error(std::string("sih_ir_get_sums: unknown tracer ") + tracer);
+    return SIH_ERR_ARG;
+}
+
+int sih_ir_cfl_warnings(sih_ctx *c) { return c && c->ir ? c->ir->cflWarnings : 0; }

@@ -78,7 +78,7 @@ static int locCount(const sih_ctx *c, SihLoc loc)
 static int locPad(const sih_ctx *c, SihLoc loc) { return loc == LOC_CELL ? c->padC : loc == LOC_VERTEX ? c->padV : c->padE; }
 static const int *locPerm(const sih_ctx *c, SihLoc loc)
 {
-    return loc == LOC_CELL ? c->d_cellPerm : loc == LOC_VERTEX ? c->d_vertPerm : nullptr;
+    return loc == LOC_CELL ? c->d_cellPerm : loc == LOC_VERTEX ? c->d_vertPerm : c->d_edgePerm;
 }
 
 static int devAlloc(sih_ctx *c, void **p, size_t bytes)
@@ -102,6 +102,19 @@ static int addField(sih_ctx *c, const char *name, SihLoc loc, int lead, bool isI
     if (rc) return rc;
     c->fields[name] = f;
     return SIH_OK;
+}
+
+int sih_dev_alloc(sih_ctx *c, void **p, size_t bytes) { return devAlloc(c, p, bytes); }
+
+int sih_add_field(sih_ctx *c, const char *name, SihLoc loc, int lead, bool isInt)
+{
+    if (c->fields.count(name)) {
+        SihField &f = c->fields[name];
+        if (f.loc == loc && f.lead == lead && f.isInt == isInt) return SIH_OK;
+        sih_set_error(std::string("field exists with another shape: ") + name);
+        return SIH_ERR_STATE;
+    }
+    return addField(c, name, loc, lead, isInt);
 }
 
 SihField *sih_find_field(sih_ctx *c, const char *name)
@@ -372,6 +385,7 @@ extern "C" int sih_block_destroy(sih_ctx *c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     if (c->graphExec) hipGraphExecDestroy(c->graphExec);
+    sih_ir_destroy(c);
     for (hipEvent_t e : c->events) hipEventDestroy(e);
     for (void *p : c->allocs) hipFree(p);
     for (int k = 0; k < 2; k++) {

@@ -60,7 +60,9 @@ struct sih_ctx {
     int padC = 0, padV = 0, padE = 0;
     bool renumber = false;
     std::vector<int> cellPerm, cellInv, vertPerm, vertInv;  // perm: internal -> host (0-based); inv: host -> internal
-    int *d_cellPerm = nullptr, *d_vertPerm = nullptr;
+    std::vector<int> edgePerm, edgeInv;                      // filled by sih_ir_init (identity until then)
+    int *d_cellPerm = nullptr, *d_vertPerm = nullptr, *d_edgePerm = nullptr;
+    struct sih_ir_state *ir = nullptr;                       // incremental-remap advection state
     std::map<std::string, SihField> fields;
     std::vector<void *> allocs;
     sih_evp_config cfg{};
@@ -80,6 +82,10 @@ struct sih_ctx {
 };
 
 void sih_set_error(const std::string &s);
+SihField *sih_find_field(sih_ctx *c, const char *name);
+int sih_add_field(sih_ctx *c, const char *name, SihLoc loc, int lead, bool isInt);
+int sih_dev_alloc(sih_ctx *c, void **p, size_t bytes);
+void sih_ir_destroy(sih_ctx *c);
 int sih_hip_fail(hipError_t e, const char *what, const char *file, int line);
 #define HIPCHK(x)                                                             \
     do {                                                                      \

@@ -53,11 +53,22 @@ class EvpConfig(ctypes.Structure):
     ]
 
 
+class IrDesc(ctypes.Structure):
+    _fields_ = [
+        ("edgesOnCell", ctypes.c_void_p), ("cellsOnEdge", ctypes.c_void_p), ("verticesOnEdge", ctypes.c_void_p),
+        ("edgesOnVertex", ctypes.c_void_p),
+        ("xEdge", ctypes.c_void_p), ("yEdge", ctypes.c_void_p), ("zEdge", ctypes.c_void_p),
+        ("dcEdge", ctypes.c_void_p), ("dvEdge", ctypes.c_void_p), ("coeffsReconstruct", ctypes.c_void_p),
+        ("nCategories", ctypes.c_int32), ("rotateCartesianGrid", ctypes.c_int32),
+    ]
+
+
 EXPORTS = [
     "sih_block_create", "sih_block_destroy", "sih_last_error", "sih_set_stream", "sih_sync",
     "sih_evp_init", "sih_evp_static_changed", "sih_field_put", "sih_field_get", "sih_field_count",
     "sih_evp_pre_subcycle", "sih_evp_subcycle", "sih_evp_post_subcycle", "sih_evp_run",
     "sih_evp_subcycle_timed", "sih_halo_set_lists", "sih_halo_pack", "sih_halo_unpack", "sih_get_info",
+    "sih_ir_init", "sih_ir_set_tracers", "sih_ir_run", "sih_ir_get_sums", "sih_ir_run_timed",
 ]
 
 
@@ -104,6 +115,13 @@ def load():
     lib.sih_halo_unpack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                     ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
     lib.sih_get_info.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]
+    lib.sih_ir_init.argtypes = [ctypes.c_void_p, ctypes.POINTER(IrDesc)]
+    lib.sih_ir_set_tracers.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
+                                       ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
+    lib.sih_ir_run.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int]
+    lib.sih_ir_get_sums.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.sih_ir_run_timed.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
+                                     ctypes.c_void_p]
     _lib = lib
     return lib
 
@@ -244,6 +262,44 @@ class BlockContext:
     def halo_unpack(self, location, names, device_ptr):
         check(self._lib.sih_halo_unpack(self.handle, int(location), len(names), self._names(names),
                                         ctypes.c_void_p(device_ptr)), "sih_halo_unpack")
+
+    # -- incremental remap ---------------------------------------------------------------------
+    def ir_init(self, mesh_pool, nCategories, rotate):
+        d = IrDesc()
+        for k in ("edgesOnCell", "cellsOnEdge", "verticesOnEdge", "edgesOnVertex"):
+            a = mesh_pool[k]
+            assert a.dtype == np.int32 and a.flags["F_CONTIGUOUS"], k
+            setattr(d, k, _ptr(a))
+        for k in ("xEdge", "yEdge", "zEdge", "dcEdge", "dvEdge"):
+            a = mesh_pool[k]
+            assert a.dtype == np.float64, k
+            setattr(d, k, _ptr(a))
+        a = mesh_pool["coeffs_reconstruct"]
+        assert a.dtype == np.float64 and a.flags["F_CONTIGUOUS"]
+        d.coeffsReconstruct = _ptr(a)
+        d.nCategories = int(nCategories)
+        d.rotateCartesianGrid = int(bool(rotate))
+        check(self._lib.sih_ir_init(self.handle, ctypes.byref(d)), "sih_ir_init")
+
+    def ir_set_tracers(self, names, parents, nLayers):
+        nl = np.ascontiguousarray(nLayers, dtype=np.int32)
+        check(self._lib.sih_ir_set_tracers(self.handle, len(names), self._names(names), self._names(parents),
+                                           _ptr(nl)), "sih_ir_set_tracers")
+
+    def ir_run(self, dt, check_conservation=False):
+        check(self._lib.sih_ir_run(self.handle, float(dt), int(bool(check_conservation))), "sih_ir_run")
+
+    def ir_get_sums(self, name, n):
+        a = np.zeros(n)
+        b = np.zeros(n)
+        check(self._lib.sih_ir_get_sums(self.handle, name.encode(), _ptr(a), _ptr(b)), "sih_ir_get_sums")
+        return a, b
+
+    def ir_run_timed(self, dt):
+        t = ctypes.c_double(0)
+        ph = np.zeros(5)
+        check(self._lib.sih_ir_run_timed(self.handle, float(dt), ctypes.byref(t), _ptr(ph)), "sih_ir_run_timed")
+        return t.value, ph
 
     def info(self, key):
         v = ctypes.c_double(0)

@@ -330,7 +330,9 @@ def make_sphere_mesh(n: int, radius: float = EARTH_RADIUS, reorder: bool = False
         pos = lloyd_relax(pos, tris, lloyd_iters)
     pos, tris = _reorder(pos, tris, reorder)
     m = _build_from_triangulation(pos, tris, radius, True)
-    return _finish_sphere(m, radius)
+    m = _finish_sphere(m, radius)
+    add_reconstruction_coefficients(m)
+    return m
 
 
 QU_FREQ = {"QU480": 16, "QU240": 32, "QU120": 64, "QU60": 128, "QU30": 256}
@@ -441,7 +443,64 @@ def make_planar_hex_mesh(nx: int, ny: int, dc: float) -> Mesh:
     m["fVertex"] = np.zeros(T)
     m["fCell"] = np.zeros(N)
     m["fEdge"] = np.zeros(nE)
+    add_reconstruction_coefficients(m)
     return m
+
+
+# ----------------------------------------------------------------------------- reconstruction
+def edges_on_vertex(m: Mesh):
+    """edgesOnVertex (3, nVertices) from verticesOnEdge, nEdges+1 where a vertex has fewer edges."""
+    nV, nE = m["nVertices"], m["nEdges"]
+    eov = np.full((3, nV), nE + 1, dtype=np.int32, order="F")
+    cnt = np.zeros(nV, dtype=np.int64)
+    voe = np.asarray(m["verticesOnEdge"]) - 1
+    for e in range(nE):
+        for k in range(2):
+            v = voe[k, e]
+            if 0 <= v < nV and cnt[v] < 3:
+                eov[cnt[v], v] = e + 1
+                cnt[v] += 1
+    return eov
+
+
+def add_reconstruction_coefficients(m: Mesh):
+    """``coeffs_reconstruct(3, maxEdges, nCells)``: weights that turn the normal components of a
+    gradient on the edges of a cell into the gradient vector at the cell centre (global x, y, z).
+
+    In the reference this array is the output of the MPAS framework operator ``mpas_init_reconstruct``
+    (radial basis functions), called from
+    /root/reference/src/shared/mpas_seaice_advection_incremental_remap.F:744-746; the framework is not
+    part of the reference repository.  Here a least-squares reconstruction plays that role: with n_e
+    the unit vector from cellsOnEdge(1,e) to cellsOnEdge(2,e) projected on the tangent plane at the
+    cell centre and r the local vertical, G = A^-1 sum_e n_e g_e with A = sum_e n_e n_e^T + r r^T,
+    which is exact for linear fields.  The same array feeds the device library and the CPU oracle.
+    """
+    nC, M = m["nCells"], m["maxEdges"]
+    xyz = np.stack([m["xCell"], m["yCell"], m["zCell"]], axis=1)
+    coe = np.asarray(m["cellsOnEdge"]).astype(np.int64) - 1
+    eoc = np.asarray(m["edgesOnCell"]).astype(np.int64) - 1
+    ne = np.asarray(m["nEdgesOnCell"]).astype(np.int64)
+    if m["on_a_sphere"]:
+        r = xyz / np.linalg.norm(xyz, axis=1, keepdims=True)
+    else:
+        r = np.tile(np.array([0.0, 0.0, 1.0]), (nC, 1))
+    nvec = np.zeros((nC, M, 3))
+    for i in range(M):
+        e = np.clip(eoc[i], 0, m["nEdges"] - 1)
+        c1, c2 = coe[0, e], coe[1, e]
+        ok = (i < ne) & (c1 >= 0) & (c1 < nC) & (c2 >= 0) & (c2 < nC)
+        c1c, c2c = np.clip(c1, 0, nC - 1), np.clip(c2, 0, nC - 1)
+        d = xyz[c2c] - xyz[c1c]
+        d = d - (d * r).sum(axis=1, keepdims=True) * r
+        nrm = np.linalg.norm(d, axis=1, keepdims=True)
+        d = np.where(nrm > 0, d / np.where(nrm > 0, nrm, 1.0), 0.0)
+        nvec[:, i, :] = np.where(ok[:, None], d, 0.0)
+    A = np.einsum("cik,cil->ckl", nvec, nvec) + np.einsum("ck,cl->ckl", r, r)
+    Ainv = np.linalg.inv(A)
+    coeffs = np.einsum("ckl,cil->cik", Ainv, nvec)        # (nC, M, 3)
+    m["coeffs_reconstruct"] = np.asfortranarray(coeffs.transpose(2, 1, 0))
+    if "edgesOnVertex" not in m:
+        m["edgesOnVertex"] = edges_on_vertex(m)
 
 
 # ----------------------------------------------------------------------------- checks

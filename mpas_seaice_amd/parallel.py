@@ -36,10 +36,27 @@ FIELD_POOL = {
 }
 
 
+def field_loc(name):
+    """Fields not listed above are advected tracers: cell fields of the `tracers` pool."""
+    return FIELD_LOC.get(name, "cell")
+
+
+def field_pool(name):
+    return FIELD_POOL.get(name, "tracers")
+
+
+def _planes_of(a):
+    """(lead..., n) Fortran-ordered pool array -> 2-D view with one row per leading index combination,
+    first index fastest (the plane order of the device library)."""
+    if a.ndim == 1:
+        return a.reshape((1, -1))
+    return a.reshape((-1, a.shape[-1]), order="F")
+
+
 def _group(names):
     groups = {}
     for n in names:
-        groups.setdefault((FIELD_LOC[n], n in INT_FIELDS), []).append(n)
+        groups.setdefault((field_loc(n), n in INT_FIELDS), []).append(n)
     return groups
 
 
@@ -69,11 +86,8 @@ class HostFields:
     def planes(self, names):
         out = []
         for n in names:
-            a = self.block.structs[FIELD_POOL[n]][n]
-            if a.ndim == 1:
-                out.append(a)
-            else:
-                out.extend(a[l] for l in range(a.shape[0]))
+            a2 = _planes_of(self.block.structs[field_pool(n)][n])
+            out.extend(a2[l] for l in range(a2.shape[0]))
         return out
 
     def pack(self, lists, names, is_int):
@@ -113,8 +127,8 @@ class CommBase:
     def n_planes(self, domain, names):
         tot = 0
         for n in names:
-            a = domain.blocklist[0].structs[FIELD_POOL[n]][n]
-            tot += 1 if a.ndim == 1 else a.shape[0]
+            a = domain.blocklist[0].structs[field_pool(n)][n]
+            tot += 1 if a.ndim == 1 else int(np.prod(a.shape[:-1]))
         return tot
 
     def _torch_buf(self, key, n, is_int, device):
@@ -132,6 +146,9 @@ class LocalComm(CommBase):
 
     def allreduce_min(self, x):
         return x
+
+    def allreduce_sum(self, a):
+        return a
 
     def halo_exchange(self, domain, names):
         for (loc, is_int), ns in _group(names).items():
@@ -192,6 +209,14 @@ class DistComm(CommBase):
             t = t.cuda()
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
         return float(t.item())
+
+    def allreduce_sum(self, a):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy())
+        if self.dist.get_backend() == "nccl":
+            t = t.cuda()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy()
 
     def halo_exchange(self, domain, names):
         import torch

@@ -132,6 +132,8 @@ def partition_mesh(mesh: Mesh, nblocks: int, num_halos: int = 2, cell_owner=None
         for k in ("xVertex", "yVertex", "zVertex", "latVertex", "lonVertex", "areaTriangle", "fVertex"):
             m[k] = np.ascontiguousarray(mesh[k][verts])
         m["kiteAreasOnVertex"] = np.asfortranarray(mesh["kiteAreasOnVertex"][:, verts])
+        if "coeffs_reconstruct" in mesh:
+            m["coeffs_reconstruct"] = np.asfortranarray(mesh["coeffs_reconstruct"][:, :, cells])
         for k in ("xEdge", "yEdge", "zEdge", "latEdge", "lonEdge", "dcEdge", "dvEdge", "fEdge"):
             m[k] = np.ascontiguousarray(mesh[k][edges])
         meshes.append(m)

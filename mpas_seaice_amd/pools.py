@@ -51,7 +51,13 @@ DEFAULT_CONFIGS = {
     # config_num_halos >= k halo layers; the solver then also updates halo vertices/cells redundantly and
     # exchanges uVelocity, vVelocity and stress11/22/12 every k subcycles (results identical to k = 1)
     "config_halo_exchange_interval": 1,
+    "config_use_advection": True,
     "config_advection_type": "incremental_remap",
+    "config_conservation_check": False,
+    "config_monotonicity_check": False,
+    "config_recover_tracer_means_check": False,
+    "config_nIceLayers": 7,
+    "config_nSnowLayers": 1,
     "config_earth_radius": 6371229.0,
 }
 
@@ -65,6 +71,8 @@ class Block:
             "maxEdges", "vertexDegree")}
         self.dimensions["nCategories"] = nCategories
         self.dimensions["ONE"] = 1
+        self.dimensions["nIceLayers"] = int(configs.get("config_nIceLayers", 7))
+        self.dimensions["nSnowLayers"] = int(configs.get("config_nSnowLayers", 1))
         self.structs = {}
         self.halo = None  # filled by the partitioner for multi-block runs
         self._alloc(mesh)
@@ -108,6 +116,10 @@ class Block:
         meshp["verticesOnEdge"] = pad1(mesh["verticesOnEdge"].astype(np.int32), nV + 1)
         if "edgesOnVertex" in mesh:
             meshp["edgesOnVertex"] = pad1(mesh["edgesOnVertex"].astype(np.int32), nE + 1)
+        # output of the framework operator mpas_init_reconstruct (called at
+        # mpas_seaice_advection_incremental_remap.F:744-746); supplied with the mesh here
+        if "coeffs_reconstruct" in mesh:
+            meshp["coeffs_reconstruct"] = pad1(np.asarray(mesh["coeffs_reconstruct"], dtype=np.float64), 0.0)
         self.structs["mesh"] = meshp
 
         self.structs["boundary"] = {"interiorVertex": iv(), "interiorCell": ic(),
@@ -142,8 +154,15 @@ class Block:
         self.structs["icestate"] = {k: (rv() if "Vertex" in k else rc()) for k in (
             "iceAreaVertex", "totalMassVertex", "iceAreaCellInitial", "totalMassCell", "openWaterArea")}
         self.structs["tracers_aggregate"] = {k: rc() for k in ("iceAreaCell", "iceVolumeCell", "snowVolumeCell")}
+        # the tracers that are always advected (mpas_seaice_advection_incremental_remap_tracers.F:218-224;
+        # Registry.xml:2439-2524); optional ones are added to this pool by the caller
+        nIce, nSnow = d["nIceLayers"], d["nSnowLayers"]
         self.structs["tracers"] = {k: rc(1, nCat) for k in ("iceAreaCategory", "iceVolumeCategory",
-                                                            "snowVolumeCategory")}
+                                                            "snowVolumeCategory", "surfaceTemperature")}
+        self.structs["tracers"]["iceEnthalpy"] = rc(nIce, nCat)
+        self.structs["tracers"]["iceSalinity"] = rc(nIce, nCat)
+        self.structs["tracers"]["snowEnthalpy"] = rc(nSnow, nCat)
+        self.structs["incremental_remap"] = {}
         self.structs["ocean_coupling"] = {"uOceanVelocity": rc(), "vOceanVelocity": rc(),
                                           "seaSurfaceTiltU": rc(), "seaSurfaceTiltV": rc(),
                                           "landIceMask": ic(), "landIceMaskVertex": iv()}

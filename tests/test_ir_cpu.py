@@ -1,0 +1,201 @@
+"""CPU tests of the incremental-remap oracle (invariants the reference checks at run time) and of the
+host-side tracer list logic.  The oracle's parity status is "unpinned" at bit level (see ir_oracle.c);
+these tests pin its behaviour through conservation, monotonicity, exactness and closed-form moments."""
+import numpy as np
+import pytest
+
+from mpas_seaice_amd import cases, tracers as trc
+from util import get_mesh
+
+
+def _ir():
+    from oracle import ir_flow
+    return ir_flow
+
+
+def _setup(oracle, meshname, name=None, configs=None, **kw):
+    ir = _ir()
+    dom = cases.make_domain(get_mesh(meshname), name, configs=configs, **kw)
+    oracle.seaice_init_velocity_solver(dom)
+    ir.seaice_init_advection(dom)
+    return dom
+
+
+def _neighbour_minmax(b, arr, parent_mask):
+    """min / max of a (L, nCat, nCells) tracer over each cell and its edge neighbours, counting only
+    cells where the parent is present (tracer_local_min_max, incremental_remap.F:8268-8392)."""
+    m = b.structs["mesh"]
+    nC = b.dimensions["nCells"]
+    coc = m["cellsOnCell"][:, :nC] - 1
+    ne = m["nEdgesOnCell"][:nC]
+    big = 1e300
+    lo = np.where(parent_mask, arr[..., :nC], big)
+    hi = np.where(parent_mask, arr[..., :nC], -big)
+    padlo = np.concatenate([lo, np.full(lo.shape[:-1] + (1,), big)], axis=-1)
+    padhi = np.concatenate([hi, np.full(hi.shape[:-1] + (1,), -big)], axis=-1)
+    mn, mx = lo.copy(), hi.copy()
+    for i in range(coc.shape[0]):
+        nb = np.where(i < ne, np.minimum(coc[i], nC), nC)
+        mn = np.minimum(mn, padlo[..., nb])
+        mx = np.maximum(mx, padhi[..., nb])
+    # the reference widens the range by one more layer of cells (extendedMinMax, :8460-8541): a
+    # departure triangle lying in a neighbour carries values bounded by that neighbour's own range
+    padlo = np.concatenate([mn, np.full(lo.shape[:-1] + (1,), big)], axis=-1)
+    padhi = np.concatenate([mx, np.full(lo.shape[:-1] + (1,), -big)], axis=-1)
+    for i in range(coc.shape[0]):
+        nb = np.where(i < ne, np.minimum(coc[i], nC), nC)
+        mn = np.minimum(mn, padlo[..., nb])
+        mx = np.maximum(mx, padhi[..., nb])
+    return mn, mx
+
+
+def test_tracer_list_order_and_hierarchy():
+    dom = cases.make_domain(get_mesh("QU480"), "QU480")
+    lst = trc.seaice_add_tracers_to_linked_list(dom)
+    names = [t.tracerName for t in lst]
+    assert names == ["iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory", "surfaceTemperature",
+                     "iceEnthalpy", "iceSalinity", "snowEnthalpy"]
+    assert [t.nParents for t in lst] == [0, 1, 1, 1, 2, 2, 2]
+    assert [t.nLayers for t in lst] == [1, 1, 1, 1, 7, 7, 1]
+    assert [t.hasChild for t in lst] == [True, True, True, False, False, False, False]
+    # an optional tracer becomes active when its field is in the pool, and keeps the level order
+    b = dom.blocklist[0]
+    b.structs["tracers"]["iceAge"] = np.zeros_like(b.structs["tracers"]["iceVolumeCategory"])
+    lst = trc.seaice_add_tracers_to_linked_list(dom)
+    assert [t.tracerName for t in lst][-1] == "iceAge" and lst[-1].nParents == 2
+    del b.structs["tracers"]["iceVolumeCategory"]
+    with pytest.raises(RuntimeError):
+        trc.seaice_add_tracers_to_linked_list(dom)
+
+
+def test_geometric_averages_regular_hexagon(oracle):
+    """Cell averages of monomials over a regular hexagon of circumradius h (closed forms): the 6-point
+    rule is exact up to degree 4 (incremental_remap.F:6504-6544)."""
+    dom = _setup(oracle, "hex_8_8")
+    b = dom.blocklist[0]
+    g = b.structs["incremental_remap"]["geomAvgCell"]
+    h = (1.28e6 / 8) / np.sqrt(3.0)
+    c = 3 * 8 + 4
+    x, y, xx, xy, yy = g[c, 0], g[c, 1], g[c, 2], g[c, 3], g[c, 4]
+    assert abs(x) < 1e-9 * h and abs(y) < 1e-9 * h and abs(xy) < 1e-9 * h * h
+    assert xx == pytest.approx(5.0 * h * h / 24.0, rel=1e-12)
+    assert yy == pytest.approx(5.0 * h * h / 24.0, rel=1e-12)
+    # <x^4> = <y^4> = 3 <x^2 y^2> for a regular hexagon; <r^4> = 7 h^4 / 30
+    assert g[c, 9] + 2.0 * g[c, 11] + g[c, 13] == pytest.approx(7.0 * h ** 4 / 30.0, rel=1e-12)
+    assert g[c, 9] == pytest.approx(3.0 * g[c, 11], rel=1e-11)
+    assert g[c, 13] == pytest.approx(3.0 * g[c, 11], rel=1e-11)
+    for k in (5, 6, 7, 8, 10, 12):
+        assert abs(g[c, k]) < 1e-9 * h ** 4
+
+
+@pytest.mark.parametrize("meshname,name", [("QU480", "QU480"), ("hex_24_20", None)])
+def test_conservation_and_monotonicity(oracle, meshname, name):
+    ir = _ir()
+    cfg = {"config_conservation_check": True}
+    if name is None:
+        cfg.update({"config_dt": 600.0, "config_elastic_subcycle_number": 60})
+    dom = _setup(oracle, meshname, name, configs=cfg)
+    oracle.seaice_run_velocity_solver(dom)
+    b = dom.blocklist[0]
+    nC, nCs = b.dimensions["nCells"], b.dimensions["nCellsSolve"]
+    tp = b.structs["tracers"]
+    area = b.structs["mesh"]["areaCell"][:nC]
+    before = {k: v.copy() for k, v in tp.items()}
+    ir.seaice_run_advection(dom)        # raises on a conservation error > 1e-11 (all mass*tracer products)
+    a0, a1 = before["iceAreaCategory"], tp["iceAreaCategory"]
+    assert np.abs(a1 - a0).max() > 1e-6            # something moved
+    for nm in ("iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory"):
+        s0 = (before[nm][0, :, :nC] * area).sum()
+        s1 = (tp[nm][0, :, :nC] * area).sum()
+        assert abs(s1 - s0) <= 1e-11 * abs(s0)
+    # monotonicity of the thickness-like and enthalpy-like tracers (check_tracer_monotonicity :8416):
+    # new values stay within the old local range, up to roundoff
+    h0 = np.where(a0 > 0, before["iceVolumeCategory"] / np.where(a0 > 0, a0, 1.0), 0.0)
+    h1 = np.where(a1 > 0, tp["iceVolumeCategory"] / np.where(a1 > 0, a1, 1.0), 0.0)
+    mn, mx = _neighbour_minmax(b, h0, a0[..., :nC] > 0)
+    ok = a1[..., :nCs] > 1e-11
+    tol = 1e-9 * np.abs(h0).max()
+    assert (h1[..., :nCs][ok] >= mn[..., :nCs][ok] - tol).all()
+    assert (h1[..., :nCs][ok] <= mx[..., :nCs][ok] + tol).all()
+    e0, e1 = before["iceEnthalpy"], tp["iceEnthalpy"]
+    mn, mx = _neighbour_minmax(b, e0, np.broadcast_to(before["iceVolumeCategory"][..., :nC] > 0, e0[..., :nC].shape))
+    ok = np.broadcast_to(tp["iceVolumeCategory"][..., :nCs] > 1e-11, e1[..., :nCs].shape)
+    tol = 1e-9 * np.abs(e0).max()
+    assert (e1[..., :nCs][ok] >= mn[..., :nCs][ok] - tol).all()
+    assert (e1[..., :nCs][ok] <= mx[..., :nCs][ok] + tol).all()
+
+
+def test_uniform_tracers_stay_uniform(oracle):
+    """A tracer that is uniform in space stays uniform whatever the (divergent) velocity does."""
+    ir = _ir()
+    dom = _setup(oracle, "QU480", "QU480")
+    oracle.seaice_run_velocity_solver(dom)
+    b = dom.blocklist[0]
+    nC = b.dimensions["nCells"]
+    tp = b.structs["tracers"]
+    a = tp["iceAreaCategory"]
+    tp["iceVolumeCategory"][:] = 1.7 * a
+    tp["snowVolumeCategory"][:] = 0.3 * a
+    tp["surfaceTemperature"][..., :nC] = -3.0
+    tp["iceEnthalpy"][..., :nC] = -2.5e8
+    ir.seaice_run_advection(dom)
+    a1 = tp["iceAreaCategory"][..., :nC]
+    ok = a1 > 1e-11
+    assert np.abs(tp["iceVolumeCategory"][..., :nC][ok] / a1[ok] - 1.7).max() < 1e-12
+    assert np.abs(tp["snowVolumeCategory"][..., :nC][ok] / a1[ok] - 0.3).max() < 1e-12
+    assert np.abs(tp["surfaceTemperature"][..., :nC][ok] + 3.0).max() < 1e-12
+    okL = np.broadcast_to(ok, tp["iceEnthalpy"][..., :nC].shape)
+    assert np.abs(tp["iceEnthalpy"][..., :nC][okL] / -2.5e8 - 1.0).max() < 1e-12
+
+
+def test_planar_translation_of_linear_field_is_exact(oracle):
+    """Uniform velocity on the planar hexagonal mesh: a concentration field that is linear in x and y is
+    transported exactly (IR is second-order; the limiter leaves a linear field alone up to its 1e-11
+    safety factor)."""
+    ir = _ir()
+    dom = _setup(oracle, "hex_24_20", configs={"config_dt": 600.0})
+    b = dom.blocklist[0]
+    m = b.structs["mesh"]
+    nC, nV = b.dimensions["nCells"], b.dimensions["nVertices"]
+    u0, v0 = 0.4, -0.25
+    b.structs["velocity_solver"]["uVelocity"][:nV] = u0
+    b.structs["velocity_solver"]["vVelocity"][:nV] = v0
+    dt = float(b.structs["velocity_solver"]["dynamicsTimeStep"][0])
+    Lx = m["xCell"][:nC].max()
+    f = lambda x, y: 0.1 + 0.05 * x / Lx + 0.03 * y / Lx   # noqa: E731
+    tp = b.structs["tracers"]
+    for k in tp:
+        tp[k][:] = 0.0
+    nCat = b.dimensions["nCategories"]
+    for k in range(nCat):
+        tp["iceAreaCategory"][0, k, :nC] = f(m["xCell"][:nC], m["yCell"][:nC]) * (1.0 + 0.1 * k)
+        tp["iceVolumeCategory"][0, k, :nC] = 2.0 * tp["iceAreaCategory"][0, k, :nC]
+    ir.seaice_run_advection(dom)
+    # interior cells (all six neighbours and their neighbours exist)
+    coc = m["cellsOnCell"][:, :nC]
+    interior = (coc <= nC).all(axis=0)
+    inner = interior.copy()
+    for i in range(6):
+        inner &= interior[np.minimum(coc[i] - 1, nC - 1)]
+    exact = f(m["xCell"][:nC] - u0 * dt, m["yCell"][:nC] - v0 * dt)
+    for k in range(nCat):
+        err = np.abs(tp["iceAreaCategory"][0, k, :nC] - exact * (1.0 + 0.1 * k))[inner].max()
+        assert err < 1e-10, err
+        h = tp["iceVolumeCategory"][0, k, :nC][inner] / tp["iceAreaCategory"][0, k, :nC][inner]
+        assert np.abs(h - 2.0).max() < 1e-11
+
+
+def test_open_water_and_small_mass(oracle):
+    """Ice edge: cells without ice stay consistent (no negative area, tracers zero where area is zero)."""
+    ir = _ir()
+    dom = _setup(oracle, "QU480", "QU480", configs={"config_conservation_check": True},
+                 open_water_band=(-0.3, 0.4))
+    oracle.seaice_run_velocity_solver(dom)
+    for _ in range(3):
+        ir.seaice_run_advection(dom)
+    b = dom.blocklist[0]
+    nC = b.dimensions["nCells"]
+    tp = b.structs["tracers"]
+    a = tp["iceAreaCategory"][0, :, :nC]
+    assert (a >= 0.0).all() and (a == 0.0).any() and np.isfinite(a).all()
+    assert (tp["iceVolumeCategory"][0, :, :nC][a == 0.0] == 0.0).all()

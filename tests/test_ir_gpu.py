@@ -1,0 +1,220 @@
+"""GPU parity of the HIP incremental-remap advection against the CPU oracle (through the C ABI)."""
+import numpy as np
+import pytest
+
+from mpas_seaice_amd import advection as adv, cases, parallel, velocity_solver as vs
+from util import get_mesh, rel_linf
+
+pytestmark = pytest.mark.gpu
+
+# tracer parity bar of the project: 1e-10 relative L-infinity, fp64
+TOL = 1e-10
+TRACERS = ["iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory", "surfaceTemperature", "iceEnthalpy",
+           "iceSalinity", "snowEnthalpy"]
+
+
+def _ir():
+    from oracle import ir_flow
+    return ir_flow
+
+
+def make_pair(oracle, meshname, name=None, configs=None, **kw):
+    mesh = get_mesh(meshname)
+    ref = cases.make_domain(mesh, name, configs=configs, **kw)
+    oracle.seaice_init_velocity_solver(ref)
+    _ir().seaice_init_advection(ref)
+    dom = cases.make_domain(mesh, name, configs=configs, **kw)
+    vs.seaice_mesh_pool_create(dom)
+    vs.seaice_init_velocity_solver(dom)
+    adv.seaice_init_advection(dom)
+    return dom, ref
+
+
+def copy_velocity(ref, dom):
+    for br, bd in zip(ref.blocklist, dom.blocklist):
+        for k in ("uVelocity", "vVelocity"):
+            bd.structs["velocity_solver"][k][:] = br.structs["velocity_solver"][k]
+
+
+def compare_tracers(dom, ref, tol=TOL):
+    rep = {}
+    for bd, br in zip(dom.blocklist, ref.blocklist):
+        nC = bd.dimensions["nCells"]
+        for n in TRACERS:
+            x, y = bd.structs["tracers"][n][..., :nC], br.structs["tracers"][n][..., :nC]
+            e = rel_linf(x, y)
+            rep[n] = max(rep.get(n, 0.0), e)
+            assert np.isfinite(x).all(), n
+            assert e <= tol, f"{n}: rel Linf {e:.3e} > {tol:.1e}"
+    return rep
+
+
+def dget(b, name, lead, n, dtype=np.float64):
+    a = np.zeros((lead, n + 1), dtype=dtype, order="F")
+    b.ctx.get(name, a)
+    return a[:, :n]
+
+
+@pytest.mark.parametrize("meshname", ["QU480", "hex_12_10"])
+def test_init_geometry_matches_oracle(oracle, meshname):
+    dom, ref = make_pair(oracle, meshname, "QU480" if meshname == "QU480" else None)
+    try:
+        b, r = dom.blocklist[0], ref.blocklist[0]
+        d = b.dimensions
+        nC, nV, nE, M = d["nCells"], d["nVertices"], d["nEdges"], d["maxEdges"]
+        ir = r.structs["incremental_remap"]
+        rep = {}
+        for nm in ("xVertexOnCell", "yVertexOnCell"):
+            rep[nm] = rel_linf(dget(b, nm, M, nC), ir[nm][:, :nC])
+        for nm in ("xVertexOnEdge", "yVertexOnEdge"):
+            rep[nm] = rel_linf(dget(b, nm, 6, nE), ir[nm][:6, :nE])
+        rep["geomAvgCell"] = max(rel_linf(dget(b, "geomAvgCell", 14, nC)[k], ir["geomAvgCell"][:nC, k])
+                                 for k in range(14))
+        rep["minLength"] = rel_linf(dget(b, "minLengthEdgesOnVertex", 1, nV)[0], ir["minLengthEdgesOnVertex"][:nV])
+        remap = dget(b, "remapEdge", 1, nE, np.int32)[0]
+        assert np.array_equal(remap, ir["remapEdge"][:nE])
+        print(rep)
+        assert max(rep.values()) <= 1e-14, rep
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+
+
+@pytest.mark.parametrize("meshname,name,cfg,kw", [
+    ("QU480", "QU480", {}, {}),
+    ("QU480", "QU480", {}, {"open_water_band": (-0.3, 0.4)}),
+    ("QU240", "QU240", {"config_elastic_subcycle_number": 30}, {}),
+    ("hex_24_20", None, {"config_dt": 600.0, "config_elastic_subcycle_number": 60}, {}),
+])
+def test_advection_step_matches_oracle(oracle, meshname, name, cfg, kw):
+    """One incremental-remap step from identical velocities: every advected tracer, plus the
+    intermediate departure triangles, edge fluxes and reconstructions."""
+    ir = _ir()
+    cfg = dict(cfg, config_conservation_check=True)
+    dom, ref = make_pair(oracle, meshname, name, configs=cfg, **kw)
+    try:
+        oracle.seaice_run_velocity_solver(ref)
+        copy_velocity(ref, dom)
+        diag = {}
+        ir.seaice_run_advection(ref, diagnostics=diag)
+        adv.seaice_run_advection(dom)
+        rep = compare_tracers(dom, ref)
+        b, r = dom.blocklist[0], ref.blocklist[0]
+        d = b.dimensions
+        nC, nE, nCat = d["nCells"], d["nEdges"], d["nCategories"]
+        rir = r.structs["incremental_remap"]
+        ta = dget(b, "triangleArea", 6, nE)
+        rep["triangleArea"] = rel_linf(ta, rir["triangleArea"][:, :nE])
+        assert np.array_equal(ta != 0.0, rir["triangleArea"][:, :nE] != 0.0)
+        xt = dget(b, "xTriangle", 18, nE).reshape((3, 6, nE), order="F")
+        live = (rir["triangleArea"][:, :nE] != 0.0)[None, :, :]
+        rep["xTriangle"] = rel_linf(np.where(live, xt, 0.0), np.where(live, diag["xTriangleVertices"][:3, :, :nE], 0.0))
+        W = diag["work"]
+        for n, L in (("iceAreaCategory", 1), ("iceVolumeCategory", 1), ("iceEnthalpy", 7)):
+            lead = L * nCat
+            rep[n + "Gradx"] = rel_linf(dget(b, n + "Gradx", lead, nC),
+                                        W[n].xGrad[..., :nC].reshape((lead, nC), order="F"))
+            rep[n + "Center"] = rel_linf(dget(b, n + "Center", lead, nC),
+                                         W[n].center[..., :nC].reshape((lead, nC), order="F"))
+            rep[n + "EdgeFlux"] = rel_linf(dget(b, n + "EdgeFlux", lead, nE),
+                                           W[n].edgeFlux[..., :nE].reshape((lead, nE), order="F"))
+        rep["BaryX"] = rel_linf(dget(b, "iceVolumeCategoryBarycenterx", nCat, nC),
+                                W["iceVolumeCategory"].xBary[..., :nC].reshape((nCat, nC), order="F"))
+        print({k: float(f"{v:.2e}") for k, v in rep.items()})
+        assert max(rep.values()) <= TOL, rep
+        # device-side conservation sums agree with the oracle's
+        s0, s1 = dom.solver_state["ir_sums"]["iceVolumeCategory"]
+        assert np.abs(s1 - s0).max() <= 1e-11 * np.abs(s0).max()
+        o0 = r._ir_sums["iceVolumeCategory"][0].reshape(-1, order="F")
+        assert rel_linf(s0, o0) < 1e-12
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+
+
+def test_dynamics_and_advection_two_steps(oracle):
+    """seaice_run_velocity_solver + seaice_run_advection, twice, each side with its own velocities."""
+    ir = _ir()
+    dom, ref = make_pair(oracle, "QU480", "QU480", configs={"config_elastic_subcycle_number": 60})
+    try:
+        for _ in range(2):
+            oracle.seaice_run_velocity_solver(ref)
+            ir.seaice_run_advection(ref)
+            vs.seaice_run_velocity_solver(dom)
+            adv.seaice_run_advection(dom)
+        rep = compare_tracers(dom, ref)
+        print(rep)
+        u, ur = (x.blocklist[0].structs["velocity_solver"]["uVelocity"] for x in (dom, ref))
+        assert rel_linf(u, ur) <= TOL
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+
+
+def test_no_renumbering_gives_same_bits(oracle):
+    mesh = get_mesh("QU480")
+    outs = []
+    for renumber in (True, False):
+        dom = cases.make_domain(mesh, "QU480")
+        vs.seaice_mesh_pool_create(dom, renumber=renumber)
+        try:
+            vs.seaice_init_velocity_solver(dom)
+            adv.seaice_init_advection(dom)
+            vs.seaice_run_velocity_solver(dom)
+            adv.seaice_run_advection(dom)
+            outs.append({n: dom.blocklist[0].structs["tracers"][n].copy() for n in TRACERS})
+        finally:
+            vs.seaice_mesh_pool_destroy(dom)
+    for n in TRACERS:
+        assert np.array_equal(outs[0][n], outs[1][n]), n
+
+
+@pytest.mark.parametrize("nblocks", [2, 4])
+def test_multiblock_advection_matches_single_block_oracle(oracle, nblocks):
+    """Blocks with two halo layers, halo updates of velocity and tracers through the device pack /
+    unpack path: owned cells of every block equal the single-block oracle."""
+    ir = _ir()
+    mesh = get_mesh("QU480")
+    cfg = {"config_elastic_subcycle_number": 30}
+    ref = cases.make_domain(mesh, "QU480", configs=cfg)
+    oracle.seaice_init_velocity_solver(ref)
+    ir.seaice_init_advection(ref)
+    oracle.seaice_run_velocity_solver(ref)
+    ir.seaice_run_advection(ref)
+    dom, halos, _ = parallel.make_partitioned_domain(mesh, "QU480", nblocks, configs=cfg)
+    vs.seaice_mesh_pool_create(dom)
+    try:
+        dom.comm = parallel.LocalComm(dom, halos, nblocks)
+        vs.seaice_init_velocity_solver(dom)
+        adv.seaice_init_advection(dom)
+        vs.seaice_run_velocity_solver(dom)
+        adv.seaice_run_advection(dom)
+        nC = mesh.nCells
+        for n in TRACERS:
+            g = parallel.gather_global(dom.blocklist, halos, "tracers", n, nC, "cell")
+            e = rel_linf(g, ref.blocklist[0].structs["tracers"][n][..., :nC])
+            assert e <= TOL, (n, e)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+
+
+def test_unsupported_and_error_paths():
+    mesh = get_mesh("QU480")
+    dom = cases.make_domain(mesh, "QU480")
+    vs.seaice_mesh_pool_create(dom)
+    try:
+        from mpas_seaice_amd.lib import SeaiceHipError
+        b = dom.blocklist[0]
+        with pytest.raises(SeaiceHipError):
+            b.ctx.ir_run(100.0)                      # before init
+        vs.seaice_init_velocity_solver(dom)
+        adv.seaice_init_advection(dom)
+        with pytest.raises(SeaiceHipError):        # child listed before its parent
+            b.ctx.ir_set_tracers(["iceAreaCategory", "iceEnthalpy", "iceVolumeCategory"],
+                                 ["None", "iceVolumeCategory", "iceAreaCategory"], [1, 7, 1])
+        # a negative concentration somewhere aborts like the reference ("IR negative reconstructed ice area")
+        adv.seaice_init_advection(dom)
+        nV = b.dimensions["nVertices"]
+        b.structs["velocity_solver"]["uVelocity"][:nV] = 0.3
+        b.structs["tracers"]["iceAreaCategory"][0, 0, 100:140] = -0.5
+        with pytest.raises(SeaiceHipError):
+            adv.seaice_run_advection(dom)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
