@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "sih_internal.h"
@@ -56,16 +57,11 @@ struct IrDev {
     int *maskCell, *flag;
 };
 
-struct IrLevel {
-    const double *val, *center, *gx, *gy;
-    int L;
-};
-
-struct IrArgs {
-    int L, Lp, nLev, isMass;
-    IrLevel lev[4];  // chain from the mass-like field to this tracer (lev[nLev-1])
+// device-resident tracer table (one entry per tracer, in list order: parents before children)
+struct IrTabEntry {
     double *val, *center, *gx, *gy, *xB, *yB, *prod, *flux;
-    const double *parentVal, *parentXB, *parentYB, *parentProd;
+    int L, parent, nLev, hasChild;
+    int chain[4];  // tracer indices from the mass-like field (chain[0]) to this tracer (chain[nLev-1])
 };
 
 struct IrTracer {
@@ -77,17 +73,15 @@ struct IrTracer {
     std::vector<double> sumInit, sumFinal;
 };
 
-struct IrZapEntry {
-    double *val;
-    int L;
-};
-
 struct sih_ir_state {
     IrDev d{};
     std::vector<IrTracer> tracers;
     int nCat = 0;
     bool inited = false;
-    IrZapEntry *d_zap = nullptr;
+    IrTabEntry *d_tab = nullptr;
+    struct IrPlane *d_planes = nullptr;
+    int nPlanes = 0;
+    int fluxMode = 1;  // 1: one thread per (edge, plane); 0: one thread per (edge, category)
     double *d_sums = nullptr;
     int iVol = -1, iSnow = -1;
     int cflWarnings = 0;
@@ -97,7 +91,8 @@ struct sih_ir_state {
 void sih_ir_destroy(sih_ctx *c)
 {
     if (!c->ir) return;
-    if (c->ir->d_zap) hipFree(c->ir->d_zap);
+    if (c->ir->d_tab) hipFree(c->ir->d_tab);
+    if (c->ir->d_planes) hipFree(c->ir->d_planes);
     if (c->ir->d_sums) hipFree(c->ir->d_sums);
     for (hipEvent_t e : c->ir->ev)
         if (e) hipEventDestroy(e);
@@ -470,142 +465,191 @@ __global__ void k_ir_mask_cell(IrDev d, const double *mass)
     d.maskCell[c] = s > 0.0 ? 1 : 0;
 }
 
-// One tracer plane per blockIdx.y: compute_gradient :4204/:4429, limit_tracer_gradient :4802/:4999,
-// centre value :3785-3791, compute_barycenter_coordinates :4658-4787 (if the tracer has children) and
-// this tracer's mass*tracer product (compute_mass_tracer_products :6982-7109).
-__global__ void __launch_bounds__(256) k_ir_reconstruct(IrDev d, IrArgs a)
+// All tracers of one (cell, category): compute_gradient :4204/:4429, limit_tracer_gradient :4802/:4999,
+// centre value :3785-3791, compute_barycenter_coordinates :4658-4787 (tracers with children) and the
+// mass*tracer products (compute_mass_tracer_products :6982-7109).  Everything a child needs from its
+// ancestors (barycentre, centre value, gradient, product) belongs to the same cell and category, so one
+// thread walks the tracer list in order; the cell's geometry stays in registers for all of them.
+template <int M>
+__global__ void __launch_bounds__(256) k_ir_reconstruct(IrDev d, const IrTabEntry *__restrict__ tab, int nT)
 {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.nCells) return;
-    const int l = blockIdx.y, cat = l / a.L, layer = l - cat * a.L;
+    const int cat = blockIdx.y;
     const size_t pc = d.padC;
-    const size_t k = (size_t)l * pc + c;
-    const size_t lp = (size_t)(a.Lp == 1 ? cat : l) * pc;
-    const double f = a.val[k];
-    a.prod[k] = (a.parentProd ? a.parentProd[lp + c] : 1.0) * f;
-    double xb, yb;
-    if (a.parentXB) {
-        xb = a.parentXB[lp + c];
-        yb = a.parentYB[lp + c];
-    } else {
-        xb = d.geom[c];
-        yb = d.geom[pc + c];
-    }
-    double gxv = 0.0, gyv = 0.0;
     const bool ice = d.maskCell[c] == 1;
+    const int n = d.nEdgesOnCell[c];
+    int nb[M];
+    double rdc[M], cf0[M], cf1[M], cf2[M], xv[M], yv[M];
+    unsigned plus = 0;
+    double t11 = 0, t12 = 0, t13 = 0, t21 = 0, t22 = 0, t23 = 0;
     if (ice) {
-        const int n = d.nEdgesOnCell[c];
-        const bool mc = a.parentVal ? (a.parentVal[lp + c] > EPS11) : true;
-        double g0 = 0.0, g1 = 0.0, g2 = 0.0, mx = f, mn = f;
-        for (int ie = 0; ie < n; ie++) {
-            int nb = d.coc[(size_t)ie * pc + c];
-            double ng = 0.0;
-            if (nb < d.nCells) {
-                bool mnb = a.parentVal ? (a.parentVal[lp + nb] > EPS11) : true;
-                double fnb = a.val[(size_t)l * pc + nb];
-                if (mc && mnb) {
-                    int e = d.eoc[(size_t)ie * pc + c];
-                    double sg = (c == d.coe[e]) ? 1.0 : -1.0;
-                    ng = sg * (fnb - f) / d.dcEdge[e];
-                }
-                if (mnb) {
-                    mx = fmax(mx, fnb);
-                    mn = fmin(mn, fnb);
-                }
+#pragma unroll
+        for (int ie = 0; ie < M; ie++) {
+            nb[ie] = d.nCells;
+            rdc[ie] = 1.0;
+            cf0[ie] = cf1[ie] = cf2[ie] = xv[ie] = yv[ie] = 0.0;
+            if (ie < n) {
+                nb[ie] = d.coc[(size_t)ie * pc + c];
+                int e = d.eoc[(size_t)ie * pc + c];
+                rdc[ie] = d.dcEdge[e];
+                if (c == d.coe[e]) plus |= 1u << ie;
+                cf0[ie] = d.coeffs[(size_t)(ie * 3 + 0) * pc + c];
+                cf1[ie] = d.coeffs[(size_t)(ie * 3 + 1) * pc + c];
+                cf2[ie] = d.coeffs[(size_t)(ie * 3 + 2) * pc + c];
+                xv[ie] = d.xVOC[(size_t)ie * pc + c];
+                yv[ie] = d.yVOC[(size_t)ie * pc + c];
             }
-            g0 = g0 + d.coeffs[(size_t)(ie * 3 + 0) * pc + c] * ng;
-            g1 = g1 + d.coeffs[(size_t)(ie * 3 + 1) * pc + c] * ng;
-            g2 = g2 + d.coeffs[(size_t)(ie * 3 + 2) * pc + c] * ng;
-        }
-        if (d.rotate && d.onSphere) {  // :4353-4359
-            double t = g0;
-            g0 = -g2;
-            g2 = t;
         }
         if (d.onSphere) {
-            gxv = d.g2c[c] * g0 + d.g2c[pc + c] * g1 + d.g2c[2 * pc + c] * g2;
-            gyv = d.g2c[3 * pc + c] * g0 + d.g2c[4 * pc + c] * g1 + d.g2c[5 * pc + c] * g2;
-        } else {
-            gxv = g0;
-            gyv = g1;
+            t11 = d.g2c[c];
+            t12 = d.g2c[pc + c];
+            t13 = d.g2c[2 * pc + c];
+            t21 = d.g2c[3 * pc + c];
+            t22 = d.g2c[4 * pc + c];
+            t23 = d.g2c[5 * pc + c];
         }
-        // limiter
-        mx = mx - f;
-        mn = mn - f;
-        double lmx = 0.0, lmn = 0.0;
-        for (int iv = 0; iv < n; iv++) {
-            double dev = gxv * (d.xVOC[(size_t)iv * pc + c] - xb) + gyv * (d.yVOC[(size_t)iv * pc + c] - yb);
-            lmx = fmax(lmx, dev);
-            lmn = fmin(lmn, dev);
-        }
-        double f1 = fabs(lmx) > fabs(mx) ? fmax(0.0, mx / lmx) : 1.0;
-        double f2 = fabs(lmn) > fabs(mn) ? fmax(0.0, mn / lmn) : 1.0;
-        double fac = fmin(f1, f2);
-        fac = fmax(0.0, fac - EPS11);
-        gxv = gxv * fac;
-        gyv = gyv * fac;
     }
-    const double cen = f - gxv * xb - gyv * yb;
-    a.gx[k] = gxv;
-    a.gy[k] = gyv;
-    a.center[k] = cen;
-    if (a.xB) {
-        double bx = 0.0, by = 0.0;
-        if (ice) {
-#define G(j) d.geom[(size_t)(j) * pc + c]
-            double mean[3], ce[3], gx[3], gy[3];
-            for (int j = 0; j < a.nLev - 1; j++) {
-                size_t kj = (size_t)(a.lev[j].L == 1 ? cat : cat * a.lev[j].L + layer) * pc + c;
-                mean[j] = a.lev[j].val[kj];
-                ce[j] = a.lev[j].center[kj];
-                gx[j] = a.lev[j].gx[kj];
-                gy[j] = a.lev[j].gy[kj];
-            }
-            mean[a.nLev - 1] = f;
-            ce[a.nLev - 1] = cen;
-            gx[a.nLev - 1] = gxv;
-            gy[a.nLev - 1] = gyv;
-            if (a.nLev == 1) {
-                double c0 = ce[0], cx = gx[0], cy = gy[0];
-                double rcp = fabs(mean[0]) > 0.0 ? 1.0 / mean[0] : 0.0;
-                bx = (c0 * G(0) + cx * G(2) + cy * G(3)) * rcp;
-                by = (c0 * G(1) + cx * G(3) + cy * G(4)) * rcp;
-            } else if (a.nLev == 2) {
-                double c0 = ce[0] * ce[1];
-                double cx = ce[0] * gx[1] + gx[0] * ce[1];
-                double cy = ce[0] * gy[1] + gy[0] * ce[1];
-                double cxx = gx[0] * gx[1];
-                double cxy = gx[0] * gy[1] + gy[0] * gx[1];
-                double cyy = gy[0] * gy[1];
-                double pr = mean[0] * mean[1];
-                double rcp = fabs(pr) > 0.0 ? 1.0 / pr : 0.0;
-                bx = (c0 * G(0) + cx * G(2) + cy * G(3) + cxx * G(5) + cxy * G(6) + cyy * G(7)) * rcp;
-                by = (c0 * G(1) + cx * G(3) + cy * G(4) + cxx * G(6) + cxy * G(7) + cyy * G(8)) * rcp;
+    const double xc0 = d.geom[c], yc0 = d.geom[pc + c];
+    for (int ti = 0; ti < nT; ti++) {
+        const IrTabEntry T = tab[ti];
+        const bool hasParent = T.parent >= 0;
+        const IrTabEntry *P = hasParent ? &tab[T.parent] : nullptr;
+        for (int layer = 0; layer < T.L; layer++) {
+            const size_t k = (size_t)(cat * T.L + layer) * pc + c;
+            const size_t lp = hasParent ? (size_t)(P->L == 1 ? cat : cat * T.L + layer) * pc : 0;
+            const double f = T.val[k];
+            T.prod[k] = (hasParent ? P->prod[lp + c] : 1.0) * f;
+            double xb, yb;
+            if (hasParent) {
+                xb = P->xB[lp + c];
+                yb = P->yB[lp + c];
             } else {
-                double c0 = ce[0] * ce[1] * ce[2];
-                double cx = ce[0] * ce[1] * gx[2] + ce[0] * gx[1] * ce[2] + gx[0] * ce[1] * ce[2];
-                double cy = ce[0] * ce[1] * gy[2] + ce[0] * gy[1] * ce[2] + gy[0] * ce[1] * ce[2];
-                double cxx = ce[0] * gx[1] * gx[2] + gx[0] * ce[1] * gx[2] + gx[0] * gx[1] * ce[2];
-                double cxy = ce[0] * gx[1] * gy[2] + gx[0] * gy[1] * ce[2] + gy[0] * ce[1] * gx[2] +
-                             ce[0] * gy[1] * gx[2] + gx[0] * ce[1] * gy[2] + gy[0] * gx[1] * ce[2];
-                double cyy = ce[0] * gy[1] * gy[2] + gy[0] * ce[1] * gy[2] + gy[0] * gy[1] * ce[2];
-                double cxxx = gx[0] * gx[1] * gx[2];
-                double cxxy = gx[0] * gx[1] * gy[2] + gx[0] * gy[1] * gx[2] + gy[0] * gx[1] * gx[2];
-                double cxyy = gy[0] * gy[1] * gx[2] + gy[0] * gx[1] * gy[2] + gx[0] * gy[1] * gy[2];
-                double cyyy = gy[0] * gy[1] * gy[2];
-                double pr = mean[0] * mean[1] * mean[2];
-                double rcp = fabs(pr) > 0.0 ? 1.0 / pr : 0.0;
-                bx = (c0 * G(0) + cx * G(2) + cy * G(3) + cxx * G(5) + cxy * G(6) + cyy * G(7) + cxxx * G(9) +
-                      cxxy * G(10) + cxyy * G(11) + cyyy * G(12)) *
-                     rcp;
-                by = (c0 * G(1) + cx * G(3) + cy * G(4) + cxx * G(6) + cxy * G(7) + cyy * G(8) + cxxx * G(10) +
-                      cxxy * G(11) + cxyy * G(12) + cyyy * G(13)) *
-                     rcp;
+                xb = xc0;
+                yb = yc0;
             }
+            double gxv = 0.0, gyv = 0.0;
+            if (ice) {
+                const bool mc = hasParent ? (P->val[lp + c] > EPS11) : true;
+                double g0 = 0.0, g1 = 0.0, g2 = 0.0, mx = f, mn = f;
+#pragma unroll
+                for (int ie = 0; ie < M; ie++) {
+                    if (ie < n) {
+                        double ng = 0.0;
+                        if (nb[ie] < d.nCells) {
+                            bool mnb = hasParent ? (P->val[lp + nb[ie]] > EPS11) : true;
+                            double fnb = T.val[k - c + nb[ie]];
+                            if (mc && mnb) {
+                                double sg = (plus >> ie) & 1u ? 1.0 : -1.0;
+                                ng = sg * (fnb - f) / rdc[ie];
+                            }
+                            if (mnb) {
+                                mx = fmax(mx, fnb);
+                                mn = fmin(mn, fnb);
+                            }
+                        }
+                        g0 = g0 + cf0[ie] * ng;
+                        g1 = g1 + cf1[ie] * ng;
+                        g2 = g2 + cf2[ie] * ng;
+                    }
+                }
+                if (d.rotate && d.onSphere) {  // :4353-4359
+                    double t = g0;
+                    g0 = -g2;
+                    g2 = t;
+                }
+                if (d.onSphere) {
+                    gxv = t11 * g0 + t12 * g1 + t13 * g2;
+                    gyv = t21 * g0 + t22 * g1 + t23 * g2;
+                } else {
+                    gxv = g0;
+                    gyv = g1;
+                }
+                mx = mx - f;
+                mn = mn - f;
+                double lmx = 0.0, lmn = 0.0;
+#pragma unroll
+                for (int iv = 0; iv < M; iv++) {
+                    if (iv < n) {
+                        double dev = gxv * (xv[iv] - xb) + gyv * (yv[iv] - yb);
+                        lmx = fmax(lmx, dev);
+                        lmn = fmin(lmn, dev);
+                    }
+                }
+                double f1 = fabs(lmx) > fabs(mx) ? fmax(0.0, mx / lmx) : 1.0;
+                double f2 = fabs(lmn) > fabs(mn) ? fmax(0.0, mn / lmn) : 1.0;
+                double fac = fmin(f1, f2);
+                fac = fmax(0.0, fac - EPS11);
+                gxv = gxv * fac;
+                gyv = gyv * fac;
+            }
+            const double cen = f - gxv * xb - gyv * yb;
+            T.gx[k] = gxv;
+            T.gy[k] = gyv;
+            T.center[k] = cen;
+            if (T.hasChild) {
+                double bx = 0.0, by = 0.0;
+                if (ice) {
+#define G(j) d.geom[(size_t)(j) * pc + c]
+                    double mean[3], ce[3], gx[3], gy[3];
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {  // constant trip count keeps the arrays in registers
+                        mean[j] = f;
+                        ce[j] = cen;
+                        gx[j] = gxv;
+                        gy[j] = gyv;
+                        if (j < T.nLev - 1) {
+                            const IrTabEntry &A = tab[T.chain[j]];
+                            size_t kj = (size_t)(A.L == 1 ? cat : cat * A.L + layer) * pc + c;
+                            mean[j] = A.val[kj];
+                            ce[j] = A.center[kj];
+                            gx[j] = A.gx[kj];
+                            gy[j] = A.gy[kj];
+                        }
+                    }
+                    if (T.nLev == 1) {
+                        double c0 = ce[0], cx = gx[0], cy = gy[0];
+                        double rcp = fabs(mean[0]) > 0.0 ? 1.0 / mean[0] : 0.0;
+                        bx = (c0 * G(0) + cx * G(2) + cy * G(3)) * rcp;
+                        by = (c0 * G(1) + cx * G(3) + cy * G(4)) * rcp;
+                    } else if (T.nLev == 2) {
+                        double c0 = ce[0] * ce[1];
+                        double cx = ce[0] * gx[1] + gx[0] * ce[1];
+                        double cy = ce[0] * gy[1] + gy[0] * ce[1];
+                        double cxx = gx[0] * gx[1];
+                        double cxy = gx[0] * gy[1] + gy[0] * gx[1];
+                        double cyy = gy[0] * gy[1];
+                        double pr = mean[0] * mean[1];
+                        double rcp = fabs(pr) > 0.0 ? 1.0 / pr : 0.0;
+                        bx = (c0 * G(0) + cx * G(2) + cy * G(3) + cxx * G(5) + cxy * G(6) + cyy * G(7)) * rcp;
+                        by = (c0 * G(1) + cx * G(3) + cy * G(4) + cxx * G(6) + cxy * G(7) + cyy * G(8)) * rcp;
+                    } else {
+                        double c0 = ce[0] * ce[1] * ce[2];
+                        double cx = ce[0] * ce[1] * gx[2] + ce[0] * gx[1] * ce[2] + gx[0] * ce[1] * ce[2];
+                        double cy = ce[0] * ce[1] * gy[2] + ce[0] * gy[1] * ce[2] + gy[0] * ce[1] * ce[2];
+                        double cxx = ce[0] * gx[1] * gx[2] + gx[0] * ce[1] * gx[2] + gx[0] * gx[1] * ce[2];
+                        double cxy = ce[0] * gx[1] * gy[2] + gx[0] * gy[1] * ce[2] + gy[0] * ce[1] * gx[2] +
+                                     ce[0] * gy[1] * gx[2] + gx[0] * ce[1] * gy[2] + gy[0] * gx[1] * ce[2];
+                        double cyy = ce[0] * gy[1] * gy[2] + gy[0] * ce[1] * gy[2] + gy[0] * gy[1] * ce[2];
+                        double cxxx = gx[0] * gx[1] * gx[2];
+                        double cxxy = gx[0] * gx[1] * gy[2] + gx[0] * gy[1] * gx[2] + gy[0] * gx[1] * gx[2];
+                        double cxyy = gy[0] * gy[1] * gx[2] + gy[0] * gx[1] * gy[2] + gx[0] * gy[1] * gy[2];
+                        double cyyy = gy[0] * gy[1] * gy[2];
+                        double pr = mean[0] * mean[1] * mean[2];
+                        double rcp = fabs(pr) > 0.0 ? 1.0 / pr : 0.0;
+                        bx = (c0 * G(0) + cx * G(2) + cy * G(3) + cxx * G(5) + cxy * G(6) + cyy * G(7) + cxxx * G(9) +
+                              cxxy * G(10) + cxyy * G(11) + cyyy * G(12)) *
+                             rcp;
+                        by = (c0 * G(1) + cx * G(3) + cy * G(4) + cxx * G(6) + cxy * G(7) + cyy * G(8) + cxxx * G(10) +
+                              cxxy * G(11) + cxyy * G(12) + cyyy * G(13)) *
+                             rcp;
+                    }
 #undef G
+                }
+                T.xB[k] = bx;
+                T.yB[k] = by;
+            }
         }
-        a.xB[k] = bx;
-        a.yB[k] = by;
     }
 }
 
@@ -768,17 +812,104 @@ __global__ void __launch_bounds__(128) k_ir_triangles(IrDev d)
     d.triCount[e] = tc < NTRI ? tc : NTRI;
 }
 
-// integrate_fluxes_over_triangles :6667-6967 for one tracer: thread = (edge, plane)
-__global__ void __launch_bounds__(256) k_ir_flux(IrDev d, IrArgs a)
+// integrate_fluxes_over_triangles :6667-6967, all tracers of one (edge, category).  The loop over the
+// tracers is outermost, like the reference's, so each flux is the same sum over triangles in the same
+// order; the edge's few triangles are re-read from cache for every tracer plane.
+__global__ void __launch_bounds__(256) k_ir_flux(IrDev d, const IrTabEntry *__restrict__ tab, int nT)
 {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= d.nEdges) return;
-    const int l = blockIdx.y, cat = l / a.L, layer = l - cat * a.L;
+    const int cat = blockIdx.y;
     const size_t pe = d.padE, pc = d.padC;
     const int cnt = d.triCount[e];
-    double flux = 0.0;
-    size_t plane[4];
-    for (int j = 0; j < a.nLev; j++) plane[j] = (size_t)(a.lev[j].L == 1 ? cat : cat * a.lev[j].L + layer) * pc;
+    for (int ti = 0; ti < nT; ti++) {
+        const IrTabEntry T = tab[ti];
+        for (int layer = 0; layer < T.L; layer++) {
+            double flux = 0.0;
+            for (int t = 0; t < cnt; t++) {
+                const double area = d.triArea[(size_t)t * pe + e];
+                if (area == 0.0) continue;
+                const int c = d.triCell[(size_t)t * pe + e];
+                const double x1 = d.xTri[(size_t)(t * 3) * pe + e], x2 = d.xTri[(size_t)(t * 3 + 1) * pe + e],
+                             x3 = d.xTri[(size_t)(t * 3 + 2) * pe + e];
+                const double y1 = d.yTri[(size_t)(t * 3) * pe + e], y2 = d.yTri[(size_t)(t * 3 + 1) * pe + e],
+                             y3 = d.yTri[(size_t)(t * 3 + 2) * pe + e];
+                double xq[6], yq[6];  // get_triangle_quadrature_points :6605-6644
+                xq[0] = Q1QP * x1 + Q1QP * x2 + Q2QP * x3;  yq[0] = Q1QP * y1 + Q1QP * y2 + Q2QP * y3;
+                xq[1] = Q1QP * x1 + Q2QP * x2 + Q1QP * x3;  yq[1] = Q1QP * y1 + Q2QP * y2 + Q1QP * y3;
+                xq[2] = Q2QP * x1 + Q1QP * x2 + Q1QP * x3;  yq[2] = Q2QP * y1 + Q1QP * y2 + Q1QP * y3;
+                xq[3] = Q3QP * x1 + Q4QP * x2 + Q4QP * x3;  yq[3] = Q3QP * y1 + Q4QP * y2 + Q4QP * y3;
+                xq[4] = Q4QP * x1 + Q3QP * x2 + Q4QP * x3;  yq[4] = Q4QP * y1 + Q3QP * y2 + Q4QP * y3;
+                xq[5] = Q4QP * x1 + Q4QP * x2 + Q3QP * x3;  yq[5] = Q4QP * y1 + Q4QP * y2 + Q3QP * y3;
+                double val[6] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (j < T.nLev) {
+                        const IrTabEntry &A = tab[T.chain[j]];
+                        const size_t kj = (size_t)(A.L == 1 ? cat : cat * A.L + layer) * pc + c;
+                        const double cj = A.center[kj], gxj = A.gx[kj], gyj = A.gy[kj];
+#pragma unroll
+                        for (int q = 0; q < 6; q++) val[q] = val[q] * (cj + gxj * xq[q] + gyj * yq[q]);
+                    }
+                }
+                double integral = 0.0;
+#pragma unroll
+                for (int q = 0; q < 6; q++) integral = integral + (q < 3 ? W1QP : W2QP) * val[q];
+                if (ti == 0) {  // "IR negative reconstructed ice area", :6903-6951
+                    bool neg = false;
+#pragma unroll
+                    for (int q = 0; q < 6; q++) neg = neg || (val[q] < 0.0);
+                    if (neg) atomicOr(d.flag, FLAG_NEGAREA);
+                }
+                flux = flux + area * integral;
+            }
+            T.flux[(size_t)(cat * T.L + layer) * pe + e] = flux;
+        }
+    }
+}
+
+// The same fluxes with one thread per (edge, tracer, category, chunk of up to 8 layers): blockIdx.x runs
+// over these groups (fastest in dispatch order, so the blocks that share an edge chunk's triangles run
+// together), blockIdx.y over chunks of edges.  The quadrature points of a triangle and the product of
+// the single-layer ancestors are evaluated once for all layers of the group; every flux is still the
+// reference's sum over triangles of area * (sum over quadrature points), in the same order.
+#define IR_LCHUNK 8
+struct IrPlane {
+    int ti, layer0, cat;
+};
+
+__global__ void __launch_bounds__(256) k_ir_flux_planes(IrDev d, const IrTabEntry *__restrict__ tab,
+                                                        const IrPlane *__restrict__ planes)
+{
+    const int e = blockIdx.y * blockDim.x + threadIdx.x;
+    if (e >= d.nEdges) return;
+    const IrPlane pl = planes[blockIdx.x];
+    const IrTabEntry T = tab[pl.ti];
+    const int cat = pl.cat, layer0 = pl.layer0;
+    const int nl = min(IR_LCHUNK, T.L - layer0);
+    const size_t pe = d.padE, pc = d.padC;
+    const int cnt = d.triCount[e];
+    // ancestors (and the tracer itself if it has one layer) whose value does not depend on the layer
+    int nShared = 0;
+    const double *cenp[4], *gxp[4], *gyp[4];
+    int Lk[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        cenp[j] = gxp[j] = gyp[j] = nullptr;
+        Lk[j] = 1;
+        if (j < T.nLev) {
+            const IrTabEntry &A = tab[T.chain[j]];
+            Lk[j] = A.L;
+            const size_t kj = (size_t)(A.L == 1 ? cat : cat * A.L + layer0) * pc;
+            cenp[j] = A.center + kj;
+            gxp[j] = A.gx + kj;
+            gyp[j] = A.gy + kj;
+            if (A.L == 1 && nShared == j) nShared = j + 1;
+        }
+    }
+    double flux[IR_LCHUNK];
+#pragma unroll
+    for (int ly = 0; ly < IR_LCHUNK; ly++) flux[ly] = 0.0;
     for (int t = 0; t < cnt; t++) {
         const double area = d.triArea[(size_t)t * pe + e];
         if (area == 0.0) continue;
@@ -794,60 +925,101 @@ __global__ void __launch_bounds__(256) k_ir_flux(IrDev d, IrArgs a)
         xq[3] = Q3QP * x1 + Q4QP * x2 + Q4QP * x3;  yq[3] = Q3QP * y1 + Q4QP * y2 + Q4QP * y3;
         xq[4] = Q4QP * x1 + Q3QP * x2 + Q4QP * x3;  yq[4] = Q4QP * y1 + Q3QP * y2 + Q4QP * y3;
         xq[5] = Q4QP * x1 + Q4QP * x2 + Q3QP * x3;  yq[5] = Q4QP * y1 + Q4QP * y2 + Q3QP * y3;
-        double val[6] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
-        for (int j = 0; j < a.nLev; j++) {
-            const double cj = a.lev[j].center[plane[j] + c], gxj = a.lev[j].gx[plane[j] + c],
-                         gyj = a.lev[j].gy[plane[j] + c];
+        double pv[6] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
 #pragma unroll
-            for (int q = 0; q < 6; q++) val[q] = val[q] * (cj + gxj * xq[q] + gyj * yq[q]);
+        for (int j = 0; j < 4; j++) {
+            if (j < nShared) {
+                const double cj = cenp[j][c], gxj = gxp[j][c], gyj = gyp[j][c];
+#pragma unroll
+                for (int q = 0; q < 6; q++) pv[q] = pv[q] * (cj + gxj * xq[q] + gyj * yq[q]);
+            }
         }
-        double integral = 0.0;
-#pragma unroll
-        for (int q = 0; q < 6; q++) integral = integral + (q < 3 ? W1QP : W2QP) * val[q];
-        if (a.isMass) {
+        if (pl.ti == 0) {  // "IR negative reconstructed ice area", :6903-6951
             bool neg = false;
 #pragma unroll
-            for (int q = 0; q < 6; q++) neg = neg || (val[q] < 0.0);
+            for (int q = 0; q < 6; q++) neg = neg || (pv[q] < 0.0);
             if (neg) atomicOr(d.flag, FLAG_NEGAREA);
         }
-        flux = flux + area * integral;
+#pragma unroll
+        for (int ly = 0; ly < IR_LCHUNK; ly++) {
+            if (ly < nl) {
+                double val[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) val[q] = pv[q];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (j >= nShared && j < T.nLev) {
+                        const size_t off = (Lk[j] == 1 ? 0 : (size_t)ly * pc) + c;
+                        const double cj = cenp[j][off], gxj = gxp[j][off], gyj = gyp[j][off];
+#pragma unroll
+                        for (int q = 0; q < 6; q++) val[q] = val[q] * (cj + gxj * xq[q] + gyj * yq[q]);
+                    }
+                }
+                double integral = 0.0;
+#pragma unroll
+                for (int q = 0; q < 6; q++) integral = integral + (q < 3 ? W1QP : W2QP) * val[q];
+                flux[ly] = flux[ly] + area * integral;
+            }
+        }
     }
-    a.flux[(size_t)l * pe + e] = flux;
+#pragma unroll
+    for (int ly = 0; ly < IR_LCHUNK; ly++)
+        if (ly < nl) T.flux[(size_t)(cat * T.L + layer0 + ly) * pe + e] = flux[ly];
 }
 
-// update_mass_and_tracers :7125-7523 for one tracer: thread = (owned cell, plane)
-__global__ void __launch_bounds__(256) k_ir_update(IrDev d, IrArgs a)
+// update_mass_and_tracers :7125-7523, all tracers of one (owned cell, category), followed by
+// zap_small_mass :8764-8886 for that cell and category
+template <int M>
+__global__ void __launch_bounds__(256) k_ir_update(IrDev d, const IrTabEntry *__restrict__ tab, int nT)
 {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.nCellsSolve) return;
-    const int l = blockIdx.y, cat = l / a.L;
+    const int cat = blockIdx.y;
     const size_t pc = d.padC, pe = d.padE;
-    const size_t k = (size_t)l * pc + c;
     const int n = d.nEdgesOnCell[c];
-    double flux = 0.0;
-    for (int ie = 0; ie < n; ie++) {
-        int e = d.eoc[(size_t)ie * pc + c];
-        double sg = (c == d.coe[e]) ? 1.0 : -1.0;
-        flux = flux + a.flux[(size_t)l * pe + e] * sg;
+    int ed[M];
+    unsigned plus = 0;
+#pragma unroll
+    for (int ie = 0; ie < M; ie++) {
+        ed[ie] = d.nEdges;
+        if (ie < n) {
+            ed[ie] = d.eoc[(size_t)ie * pc + c];
+            if (c == d.coe[ed[ie]]) plus |= 1u << ie;
+        }
     }
-    const double pp = a.parentProd ? a.parentProd[(size_t)(a.Lp == 1 ? cat : l) * pc + c] : 1.0;
-    double nv;
-    if (pp > 0.0)
-        nv = (a.prod[k] - (flux / d.areaCell[c])) / pp;
-    else
-        nv = 0.0;
-    a.prod[k] = pp * nv;
-    if (a.isMass) {  // :7465-7507
-        if (nv < -EPS11 * EPS11)
-            atomicOr(d.flag, FLAG_NEGMASS);
-        else if (nv < 0.0)
-            nv = 0.0;
+    const double area = d.areaCell[c];
+    for (int ti = 0; ti < nT; ti++) {
+        const IrTabEntry T = tab[ti];
+        const bool hasParent = T.parent >= 0;
+        const IrTabEntry *P = hasParent ? &tab[T.parent] : nullptr;
+        for (int layer = 0; layer < T.L; layer++) {
+            const int l = cat * T.L + layer;
+            const size_t k = (size_t)l * pc + c;
+            double flux = 0.0;
+#pragma unroll
+            for (int ie = 0; ie < M; ie++)
+                if (ie < n) flux = flux + T.flux[(size_t)l * pe + ed[ie]] * ((plus >> ie) & 1u ? 1.0 : -1.0);
+            const double pp = hasParent ? P->prod[(size_t)(P->L == 1 ? cat : l) * pc + c] : 1.0;
+            double nv;
+            if (pp > 0.0)
+                nv = (T.prod[k] - (flux / area)) / pp;
+            else
+                nv = 0.0;
+            T.prod[k] = pp * nv;
+            if (!hasParent) {  // :7465-7507
+                if (nv < -EPS11 * EPS11)
+                    atomicOr(d.flag, FLAG_NEGMASS);
+                else if (nv < 0.0)
+                    nv = 0.0;
+            }
+            T.val[k] = nv;
+        }
     }
-    a.val[k] = nv;
 }
 
-// zap_small_mass :8764-8886: thread = (owned cell, category)
-__global__ void k_ir_zap(IrDev d, const IrZapEntry *tab, int nTracers)
+// zap_small_mass :8764-8886: thread = (owned cell, category).  A separate launch: the conservation sums of
+// the reference are taken between the update and the zap.
+__global__ void k_ir_zap(IrDev d, const IrTabEntry *__restrict__ tab, int nT)
 {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.nCellsSolve) return;
@@ -856,22 +1028,25 @@ __global__ void k_ir_zap(IrDev d, const IrZapEntry *tab, int nTracers)
     double m = mass[(size_t)cat * d.padC + c];
     if (m > 0.0 && m < 1.0e-22) {
         mass[(size_t)cat * d.padC + c] = 0.0;
-        for (int i = 1; i < nTracers; i++)
+        for (int i = 1; i < nT; i++)
             for (int ly = 0; ly < tab[i].L; ly++) tab[i].val[(size_t)(cat * tab[i].L + ly) * d.padC + c] = 0.0;
     }
 }
 
-// sum_tracers :7998-8111: one block per plane, sum over the owned cells of areaCell * (product of the chain's
-// values); the order of additions differs from the reference's serial loop (tree reduction)
-__global__ void k_ir_sum(IrDev d, IrArgs a, double *out)
+// sum_tracers :7998-8111: one block per plane of tracer ti, sum over the owned cells of areaCell * (product
+// of the chain's values); the order of additions differs from the reference's serial loop (tree reduction)
+__global__ void k_ir_sum(IrDev d, const IrTabEntry *__restrict__ tab, int ti, double *out)
 {
     __shared__ double sh[256];
-    const int l = blockIdx.x, cat = l / a.L, layer = l - cat * a.L;
+    const IrTabEntry T = tab[ti];
+    const int l = blockIdx.x, cat = l / T.L, layer = l - cat * T.L;
     double s = 0.0;
     for (int c = threadIdx.x; c < d.nCellsSolve; c += blockDim.x) {
         double p = 1.0;
-        for (int j = 0; j < a.nLev; j++)
-            p = p * a.lev[j].val[(size_t)(a.lev[j].L == 1 ? cat : cat * a.lev[j].L + layer) * d.padC + c];
+        for (int j = 0; j < T.nLev; j++) {
+            const IrTabEntry &A = tab[T.chain[j]];
+            p = p * A.val[(size_t)(A.L == 1 ? cat : cat * A.L + layer) * d.padC + c];
+        }
         s = s + d.areaCell[c] * p;
     }
     sh[threadIdx.x] = s;
@@ -1181,48 +1356,59 @@ extern "C" int sih_ir_set_tracers(sih_ctx *c, int nTracers, const char *const *n
         if (list[i].name == "iceVolumeCategory") ir->iVol = i;
         if (list[i].name == "snowVolumeCategory") ir->iSnow = i;
     }
-    std::vector<IrZapEntry> tab(nTracers);
-    for (int i = 0; i < nTracers; i++) tab[i] = IrZapEntry{list[i].val, list[i].L};
-    if (ir->d_zap) HIPCHK(hipFree(ir->d_zap));
-    HIPCHK(hipMalloc((void **)&ir->d_zap, sizeof(IrZapEntry) * nTracers));
-    HIPCHK(hipMemcpy(ir->d_zap, tab.data(), sizeof(IrZapEntry) * nTracers, hipMemcpyHostToDevice));
+    std::vector<IrTabEntry> tab(nTracers);
+    for (int i = 0; i < nTracers; i++) {
+        const IrTracer &t = list[i];
+        IrTabEntry &q = tab[i];
+        q = IrTabEntry{t.val, t.center, t.gx, t.gy, t.xB, t.yB, t.prod, t.flux, t.L, t.parent, t.nParents + 1,
+                       t.hasChild ? 1 : 0, {0, 0, 0, 0}};
+        int j = i;
+        for (int k = t.nParents; k >= 0; k--) {
+            q.chain[k] = j;
+            j = list[j].parent;
+        }
+    }
+    if (ir->d_tab) HIPCHK(hipFree(ir->d_tab));
+    HIPCHK(hipMalloc((void **)&ir->d_tab, sizeof(IrTabEntry) * nTracers));
+    HIPCHK(hipMemcpy(ir->d_tab, tab.data(), sizeof(IrTabEntry) * nTracers, hipMemcpyHostToDevice));
+    {
+        std::vector<IrPlane> pls;
+        for (int i = 0; i < nTracers; i++)
+            for (int cat = 0; cat < ir->nCat; cat++)
+                for (int ly = 0; ly < list[i].L; ly += IR_LCHUNK) pls.push_back(IrPlane{i, ly, cat});
+        if (ir->d_planes) HIPCHK(hipFree(ir->d_planes));
+        HIPCHK(hipMalloc((void **)&ir->d_planes, sizeof(IrPlane) * pls.size()));
+        HIPCHK(hipMemcpy(ir->d_planes, pls.data(), sizeof(IrPlane) * pls.size(), hipMemcpyHostToDevice));
+        ir->nPlanes = (int)pls.size();
+        const char *fm = getenv("SIH_IR_FLUX_MODE");
+        if (fm) ir->fluxMode = atoi(fm);
+    }
     if (ir->d_sums) HIPCHK(hipFree(ir->d_sums));
     HIPCHK(hipMalloc((void **)&ir->d_sums, sizeof(double) * maxLead));
     return SIH_OK;
 }
 
-static IrArgs makeArgs(const sih_ir_state *ir, int i)
+template <int M>
+static void launchCellKernels(sih_ir_state *ir, hipStream_t s, bool update)
 {
-    const IrTracer &t = ir->tracers[i];
-    IrArgs a{};
-    a.L = t.L;
-    a.isMass = t.parent < 0;
-    a.nLev = t.nParents + 1;
-    int j = i;
-    for (int k = a.nLev - 1; k >= 0; k--) {
-        const IrTracer &tj = ir->tracers[j];
-        a.lev[k] = IrLevel{tj.val, tj.center, tj.gx, tj.gy, tj.L};
-        j = tj.parent;
-    }
-    a.val = t.val;
-    a.center = t.center;
-    a.gx = t.gx;
-    a.gy = t.gy;
-    a.xB = t.xB;
-    a.yB = t.yB;
-    a.prod = t.prod;
-    a.flux = t.flux;
-    if (t.parent >= 0) {
-        const IrTracer &p = ir->tracers[t.parent];
-        a.Lp = p.L;
-        a.parentVal = p.val;
-        a.parentXB = p.xB;
-        a.parentYB = p.yB;
-        a.parentProd = p.prod;
-    } else {
-        a.Lp = 1;
-    }
-    return a;
+    IrDev &d = ir->d;
+    const int nT = (int)ir->tracers.size();
+    if (!update)
+        hipLaunchKernelGGL(k_ir_reconstruct<M>, dim3((d.nCells + 255) / 256, d.nCat), dim3(256), 0, s, d, ir->d_tab, nT);
+    else
+        hipLaunchKernelGGL(k_ir_update<M>, dim3((d.nCellsSolve + 255) / 256, d.nCat), dim3(256), 0, s, d, ir->d_tab,
+                           nT);
+}
+
+static void launchCells(sih_ir_state *ir, hipStream_t s, bool update)
+{
+    const int M = ir->d.M;
+    if (M <= 6)
+        launchCellKernels<6>(ir, s, update);
+    else if (M <= 8)
+        launchCellKernels<8>(ir, s, update);
+    else
+        launchCellKernels<SIH_MAXE>(ir, s, update);
 }
 
 static int irSums(sih_ctx *c, bool init)
@@ -1231,7 +1417,7 @@ static int irSums(sih_ctx *c, bool init)
     for (size_t i = 0; i < ir->tracers.size(); i++) {
         IrTracer &t = ir->tracers[i];
         const int lead = t.L * ir->nCat;
-        hipLaunchKernelGGL(k_ir_sum, dim3(lead), dim3(256), 0, c->stream, ir->d, makeArgs(ir, (int)i), ir->d_sums);
+        hipLaunchKernelGGL(k_ir_sum, dim3(lead), dim3(256), 0, c->stream, ir->d, ir->d_tab, (int)i, ir->d_sums);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync((init ? t.sumInit : t.sumFinal).data(), ir->d_sums, sizeof(double) * lead,
                               hipMemcpyDeviceToHost, c->stream));
@@ -1267,22 +1453,22 @@ static int irRun(sih_ctx *c, double dt, int checkConservation, bool timed, doubl
     hipLaunchKernelGGL(k_ir_mask_cell, dim3(gC), blk, 0, s, d, area);
     mark(1);
     // construct_linear_tracer_fields :3580-4189, compute_mass_tracer_products :6982
-    for (int i = 0; i < nT; i++)
-        hipLaunchKernelGGL(k_ir_reconstruct, dim3(gC, ir->tracers[i].L * d.nCat), blk, 0, s, d, makeArgs(ir, i));
+    launchCells(ir, s, false);
     mark(2);
     hipLaunchKernelGGL(k_ir_departure_points, dim3(gV), blk, 0, s, d, dt);
     hipLaunchKernelGGL(k_ir_triangles, dim3((d.nEdges + 127) / 128), dim3(128), 0, s, d);
     mark(3);
-    for (int i = 0; i < nT; i++)
-        hipLaunchKernelGGL(k_ir_flux, dim3(gE, ir->tracers[i].L * d.nCat), blk, 0, s, d, makeArgs(ir, i));
+    if (ir->fluxMode == 1)
+        hipLaunchKernelGGL(k_ir_flux_planes, dim3(ir->nPlanes, gE), blk, 0, s, d, ir->d_tab, ir->d_planes);
+    else
+        hipLaunchKernelGGL(k_ir_flux, dim3(gE, d.nCat), blk, 0, s, d, ir->d_tab, nT);
     mark(4);
     HIPCHK(hipGetLastError());
     int rc;
     if (checkConservation && (rc = irSums(c, true))) return rc;
-    for (int i = 0; i < nT; i++)
-        hipLaunchKernelGGL(k_ir_update, dim3(gCs, ir->tracers[i].L * d.nCat), blk, 0, s, d, makeArgs(ir, i));
+    launchCells(ir, s, true);
     if (checkConservation && (rc = irSums(c, false))) return rc;
-    hipLaunchKernelGGL(k_ir_zap, dim3(gCs, d.nCat), blk, 0, s, d, ir->d_zap, nT);
+    hipLaunchKernelGGL(k_ir_zap, dim3(gCs, d.nCat), blk, 0, s, d, ir->d_tab, nT);
     // thickness -> volume :2608-2650
     for (int i : {ir->iVol, ir->iSnow})
         if (i >= 0)
