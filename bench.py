@@ -63,6 +63,57 @@ def cpu_baseline(mesh, name, max_seconds=25.0):
             "sample": f"{n} subcycles of the full {name} mesh ({nC} cells), OpenMP threads = cores"}
 
 
+def advection_timing(dom, mesh, name, reps=7, with_cpu=True):
+    """Secondary measurement: one incremental-remap advection step (7 tracers, 19 layer fields x 5
+    categories = 95 scalars per cell) on the same mesh, tracers resident on the device, timed with HIP
+    events inside the library; next to it the CPU oracle on a smaller mesh (it materialises the reference's
+    per-quadrature-point arrays, which at QU60 take tens of GB)."""
+    from mpas_seaice_amd import advection as adv
+    adv.seaice_init_advection(dom)
+    b = dom.blocklist[0]
+    for k in ("uVelocity", "vVelocity"):  # the velocities the subcycle loop left on the device
+        b.ctx.get(k, b.structs["velocity_solver"][k])
+    adv.seaice_run_advection(dom, download=False)
+    dt = float(b.structs["velocity_solver"]["dynamicsTimeStep"][0])
+    tot, ph = [], []
+    for _ in range(reps):
+        t, p = b.ctx.ir_run_timed(dt)
+        tot.append(t)
+        ph.append(p)
+    nCat = b.dimensions["nCategories"]
+    ns = sum(t.nLayers for t in dom.solver_state["tracersHead"]) * nCat
+    ms = float(np.median(tot))
+    # nominal compulsory traffic per scalar per cell: value read + written, centre/gradient/product written
+    # and read back, three edge fluxes per cell written once and read twice
+    bytes_per_scalar_cell = 8 + 8 + 4 * 8 * 2 + 3 * 8 * 3
+    out = {"workload": f"incremental remap, {ns} scalars per cell on {name}", "ms_per_step": ms,
+           "tracer_cell_updates_per_s": mesh.nCells * ns / (ms * 1e-3),
+           "phase_ms": dict(zip(["convert+masks", "reconstruct", "departure_triangles", "fluxes", "update+zap"],
+                                [round(float(x), 4) for x in np.median(np.array(ph), axis=0)])),
+           "nominal_GBps": mesh.nCells * ns * bytes_per_scalar_cell / (ms * 1e-3) / 1e9}
+    a = np.zeros_like(b.structs["tracers"]["iceAreaCategory"])
+    b.ctx.get("iceAreaCategory", a)
+    if not np.isfinite(a).all():
+        raise SystemExit("non-finite ice area after the advection loop")
+    if with_cpu:
+        from mpas_seaice_amd import cases, mesh as meshmod
+        from oracle import evp_flow as ora, ir_flow as ir
+        small = "QU240"
+        m2 = meshmod.make_named_mesh(small)
+        d2 = cases.make_domain(m2, small, configs={"config_elastic_subcycle_number": 4})
+        ora.seaice_init_velocity_solver(d2)
+        ir.seaice_init_advection(d2)
+        ora.seaice_run_velocity_solver(d2)
+        t0 = time.perf_counter()
+        nrep = 5
+        for _ in range(nrep):
+            ir.seaice_run_advection(d2)
+        dtc = (time.perf_counter() - t0) / nrep
+        out["cpu_baseline"] = {"value": m2.nCells * ns / dtc, "unit": "tracer-cell-updates/s", "cores": ora.num_threads(),
+                               "kind": "port", "sample": f"{nrep} advection steps on {small} ({m2.nCells} cells)"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +125,7 @@ def main():
     ap.add_argument("--sample-every", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-renumber", action="store_true")
+    ap.add_argument("--no-advection", action="store_true", help="skip the incremental-remap timing")
     args = ap.parse_args()
 
     import torch
@@ -91,6 +143,7 @@ def main():
     mesh = meshmod.make_named_mesh(args.mesh)
     nsub = args.subcycles
     M = int(mesh.maxEdges)
+    advection = None
 
     if world == 1:
         dom = cases.make_domain(mesh, args.mesh, configs={"config_elastic_subcycle_number": nsub})
@@ -132,6 +185,8 @@ def main():
         if not np.isfinite(u).all():
             raise SystemExit("non-finite velocities after the benchmark loop")
         n_cells_total = mesh.nCells
+        if not args.no_advection:
+            advection = advection_timing(dom, mesh, args.mesh, with_cpu=not args.no_cpu_baseline)
         vs.seaice_mesh_pool_destroy(dom)
         parallelism = "1 block"
     else:
@@ -175,6 +230,8 @@ def main():
                          "frac_of_peak": (b_cell + b_vert) * value / 1e9 / HBM_PEAK_GBS},
         "pre_ms": pre_ms, "post_ms": post_ms,
     }
+    if world == 1 and advection is not None:
+        out["advection"] = advection
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(mesh, args.mesh)
     print(json.dumps(out), flush=True)

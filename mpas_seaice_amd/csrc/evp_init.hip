@@ -469,16 +469,8 @@ extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
     if (!sih_find_field(c, "iceAreaCategory")) {
         const char *cats[3] = {"iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory"};
         for (const char *n : cats) {
-            SihField f;
-            f.name = n;
-            f.loc = LOC_CELL;
-            f.lead = cfg->nCategories;
-            f.isInt = false;
-            size_t bytes = (size_t)f.lead * c->padC * 8;
-            HIPCHK(hipMalloc(&f.d, bytes));
-            HIPCHK(hipMemsetAsync(f.d, 0, bytes, c->stream));
-            c->allocs.push_back(f.d);
-            c->fields[n] = f;
+            int rc = sih_add_field(c, n, LOC_CELL, cfg->nCategories, false);
+            if (rc) return rc;
         }
     } else if (sih_find_field(c, "iceAreaCategory")->lead != cfg->nCategories) {
         sih_set_error("sih_evp_init: nCategories cannot change after the first initialisation");

@@ -129,6 +129,7 @@ void sih_bind_dev(sih_ctx *c)
     d.useAir = c->cfg.useAirStress;
     d.tiltMode = c->cfg.surfaceTilt;
     d.useColumn = c->cfg.useColumnPackage;
+    d.haloVertices = c->cfg.computeHaloVertices ? 1 : 0;
 }
 
 __device__ inline double sign1(double x) { return copysign(1.0, x); }
@@ -500,7 +501,11 @@ __global__ void __launch_bounds__(256) k_sub_vertices(SihDev d)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= d.nVertices) return;
-    if (!d.vActive[v]) return;
+    if (d.haloVertices) {  // halo vertices with all three cells in the block are updated redundantly
+        if (!d.vActive[v]) return;
+    } else if (v >= d.nVerticesSolve) {
+        return;
+    }
     if (d.solveVelocity[v] != 1) {
         if (LAST && !d.useOcean) d.ocnCoeff[v] = 0.0;
         return;

@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -48,28 +49,6 @@ __global__ void k_get(T *__restrict__ dst, const T *__restrict__ src, const int 
     dst[(size_t)h * L + l] = src[(size_t)l * pad + i];
 }
 
-template <typename T>
-__global__ void k_pack(T *__restrict__ buf, const T *__restrict__ f, const int *__restrict__ idx,
-                       const int *__restrict__ segStart, const int *__restrict__ segCnt, int n, int nf, int fi)
-{
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) {
-        int s0 = segStart[t], sc = segCnt[t];
-        buf[(size_t)s0 * nf + (size_t)fi * sc + (t - s0)] = f[idx[t]];
-    }
-}
-
-template <typename T>
-__global__ void k_unpack(const T *__restrict__ buf, T *__restrict__ f, const int *__restrict__ idx,
-                         const int *__restrict__ segStart, const int *__restrict__ segCnt, int n, int nf, int fi)
-{
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) {
-        int s0 = segStart[t], sc = segCnt[t];
-        f[idx[t]] = buf[(size_t)s0 * nf + (size_t)fi * sc + (t - s0)];
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 static int locCount(const sih_ctx *c, SihLoc loc)
 {
@@ -81,11 +60,33 @@ static const int *locPerm(const sih_ctx *c, SihLoc loc)
     return loc == LOC_CELL ? c->d_cellPerm : loc == LOC_VERTEX ? c->d_vertPerm : c->d_edgePerm;
 }
 
+// Device memory of a context comes from a few large chunks (one hipMalloc each) that are carved up
+// here: hundreds of megabyte-sized arrays allocated one by one end up on small page fragments, and the
+// gather kernels then pay for translation misses.  SIH_ARENA_MB sets the chunk size (0: one hipMalloc per
+// array), SIH_ALLOC_ALIGN the alignment of the pieces in bytes.
 static int devAlloc(sih_ctx *c, void **p, size_t bytes)
 {
-    HIPCHK(hipMalloc(p, bytes));
+    static const size_t chunkMB = getenv("SIH_ARENA_MB") ? (size_t)atol(getenv("SIH_ARENA_MB")) : 512;
+    static const size_t align = getenv("SIH_ALLOC_ALIGN") ? (size_t)atol(getenv("SIH_ALLOC_ALIGN")) : 65536;
+    if (chunkMB == 0) {
+        HIPCHK(hipMalloc(p, bytes));
+        HIPCHK(hipMemsetAsync(*p, 0, bytes, c->stream));
+        c->allocs.push_back(*p);
+        return SIH_OK;
+    }
+    size_t need = (bytes + align - 1) / align * align;
+    if (!c->arenaBase || c->arenaUsed + need > c->arenaSize) {
+        size_t sz = std::max(chunkMB << 20, need);
+        void *base = nullptr;
+        HIPCHK(hipMalloc(&base, sz));
+        c->allocs.push_back(base);
+        c->arenaBase = (char *)base;
+        c->arenaSize = sz;
+        c->arenaUsed = 0;
+    }
+    *p = c->arenaBase + c->arenaUsed;
+    c->arenaUsed += need;
     HIPCHK(hipMemsetAsync(*p, 0, bytes, c->stream));
-    c->allocs.push_back(*p);
     return SIH_OK;
 }
 
@@ -397,6 +398,8 @@ extern "C" int sih_block_destroy(sih_ctx *c)
         }
     }
     if (c->d_stage) hipFree(c->d_stage);
+    for (auto &kv : c->haloTables)
+        if (kv.second.d_planes) hipFree(kv.second.d_planes);
     if (c->ownStream) hipStreamDestroy(c->ownStream);
     delete c;
     return SIH_OK;
@@ -580,6 +583,29 @@ extern "C" int sih_halo_set_lists(sih_ctx *c, int location, int nSend, const int
     return SIH_OK;
 }
 
+// all planes of one message group in a single launch: blockIdx.y = plane, planes[] = base pointers
+template <typename T>
+__global__ void k_pack_all(T *__restrict__ buf, T *const *__restrict__ planes, const int *__restrict__ idx,
+                           const int *__restrict__ segStart, const int *__restrict__ segCnt, int n, int nf)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        int s0 = segStart[t], sc = segCnt[t], fi = blockIdx.y;
+        buf[(size_t)s0 * nf + (size_t)fi * sc + (t - s0)] = planes[fi][idx[t]];
+    }
+}
+
+template <typename T>
+__global__ void k_unpack_all(const T *__restrict__ buf, T *const *__restrict__ planes, const int *__restrict__ idx,
+                             const int *__restrict__ segStart, const int *__restrict__ segCnt, int n, int nf)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        int s0 = segStart[t], sc = segCnt[t], fi = blockIdx.y;
+        planes[fi][idx[t]] = buf[(size_t)s0 * nf + (size_t)fi * sc + (t - s0)];
+    }
+}
+
 static int haloPackUnpack(sih_ctx *c, int location, int nFields, const char *const *names, void *buf, bool pack)
 {
     if (!c || location < 0 || location > 1 || nFields < 0 || !names) {
@@ -595,43 +621,54 @@ static int haloPackUnpack(sih_ctx *c, int location, int nFields, const char *con
         return SIH_ERR_ARG;
     }
     HIPCHK(hipSetDevice(c->device));
-    int nPlanes = 0;
+    // the table of plane pointers of a field group is built once and kept on the device
+    std::string key = std::to_string(location);
     for (int f = 0; f < nFields; f++) {
-        SihField *fl = sih_find_field(c, names[f]);
-        if (!fl || (int)fl->loc != location) {
-            sih_set_error(std::string("sih_halo_pack/unpack: not a field of this location: ") + names[f]);
-            return SIH_ERR_ARG;
-        }
-        if (f > 0 && fl->isInt != sih_find_field(c, names[0])->isInt) {
-            sih_set_error("sih_halo_pack/unpack: fields of one call must share a type");
-            return SIH_ERR_ARG;
-        }
-        nPlanes += fl->lead;
+        key += '|';
+        key += names[f];
     }
-    const int pad = location == 0 ? c->padC : c->padV;
-    int plane = 0;
-    for (int f = 0; f < nFields; f++) {
-        SihField *fl = sih_find_field(c, names[f]);
-        dim3 grid((n + 255) / 256), block(256);
-        for (int l = 0; l < fl->lead; l++, plane++) {
-            if (fl->isInt) {
-                int *fp = (int *)fl->d + (size_t)l * pad;
-                if (pack)
-                    hipLaunchKernelGGL(k_pack<int>, grid, block, 0, c->stream, (int *)buf, (const int *)fp, idx, sg0, sgc,
-                                       n, nPlanes, plane);
-                else
-                    hipLaunchKernelGGL(k_unpack<int>, grid, block, 0, c->stream, (const int *)buf, fp, idx, sg0, sgc, n,
-                                       nPlanes, plane);
-            } else {
-                double *fp = (double *)fl->d + (size_t)l * pad;
-                if (pack)
-                    hipLaunchKernelGGL(k_pack<double>, grid, block, 0, c->stream, (double *)buf, (const double *)fp, idx,
-                                       sg0, sgc, n, nPlanes, plane);
-                else
-                    hipLaunchKernelGGL(k_unpack<double>, grid, block, 0, c->stream, (const double *)buf, fp, idx, sg0,
-                                       sgc, n, nPlanes, plane);
+    auto it = c->haloTables.find(key);
+    if (it == c->haloTables.end()) {
+        std::vector<void *> planes;
+        bool isInt = false;
+        const int pad = location == 0 ? c->padC : c->padV;
+        for (int f = 0; f < nFields; f++) {
+            SihField *fl = sih_find_field(c, names[f]);
+            if (!fl || (int)fl->loc != location) {
+                sih_set_error(std::string("sih_halo_pack/unpack: not a field of this location: ") + names[f]);
+                return SIH_ERR_ARG;
             }
+            if (f == 0) isInt = fl->isInt;
+            if (fl->isInt != isInt) {
+                sih_set_error("sih_halo_pack/unpack: fields of one call must share a type");
+                return SIH_ERR_ARG;
+            }
+            for (int l = 0; l < fl->lead; l++)
+                planes.push_back((char *)fl->d + (size_t)l * pad * (isInt ? 4 : 8));
         }
+        sih_ctx::HaloTable tb;
+        tb.nPlanes = (int)planes.size();
+        tb.isInt = isInt;
+        HIPCHK(hipMalloc((void **)&tb.d_planes, sizeof(void *) * planes.size()));
+        HIPCHK(hipMemcpy(tb.d_planes, planes.data(), sizeof(void *) * planes.size(), hipMemcpyHostToDevice));
+        it = c->haloTables.emplace(key, tb).first;
+    }
+    const sih_ctx::HaloTable &tb = it->second;
+    dim3 grid((n + 255) / 256, tb.nPlanes), block(256);
+    if (tb.isInt) {
+        if (pack)
+            hipLaunchKernelGGL(k_pack_all<int>, grid, block, 0, c->stream, (int *)buf, (int *const *)tb.d_planes, idx,
+                               sg0, sgc, n, tb.nPlanes);
+        else
+            hipLaunchKernelGGL(k_unpack_all<int>, grid, block, 0, c->stream, (const int *)buf,
+                               (int *const *)tb.d_planes, idx, sg0, sgc, n, tb.nPlanes);
+    } else {
+        if (pack)
+            hipLaunchKernelGGL(k_pack_all<double>, grid, block, 0, c->stream, (double *)buf,
+                               (double *const *)tb.d_planes, idx, sg0, sgc, n, tb.nPlanes);
+        else
+            hipLaunchKernelGGL(k_unpack_all<double>, grid, block, 0, c->stream, (const double *)buf,
+                               (double *const *)tb.d_planes, idx, sg0, sgc, n, tb.nPlanes);
     }
     HIPCHK(hipGetLastError());
     return SIH_OK;

@@ -48,7 +48,7 @@ struct SihDev {
     const double *uOcn, *vOcn, *tiltU, *tiltV, *uAir, *vAir, *airDensity;
     // scalars
     double dtDyn, dtE, dampT, brlx;
-    int relation, useOcean, quadratic, useAir, tiltMode, useColumn;
+    int relation, useOcean, quadratic, useAir, tiltMode, useColumn, haloVertices;
 };
 
 struct sih_ctx {
@@ -65,6 +65,8 @@ struct sih_ctx {
     struct sih_ir_state *ir = nullptr;                       // incremental-remap advection state
     std::map<std::string, SihField> fields;
     std::vector<void *> allocs;
+    char *arenaBase = nullptr;  // current chunk of the device arena
+    size_t arenaSize = 0, arenaUsed = 0;
     sih_evp_config cfg{};
     bool inited = false, sparseGrad = false;
     double minDvEdge = 0.0;
@@ -75,6 +77,12 @@ struct sih_ctx {
     int *d_send[2] = {nullptr, nullptr}, *d_recv[2] = {nullptr, nullptr};
     // per entry: start offset and length of the neighbour segment it belongs to (send: [0], recv: [1])
     int *d_segStart[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *d_segCnt[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    struct HaloTable {
+        void **d_planes = nullptr;
+        int nPlanes = 0;
+        bool isInt = false;
+    };
+    std::map<std::string, HaloTable> haloTables;  // plane-pointer tables of the field groups exchanged so far
     hipGraphExec_t graphExec = nullptr;
     int graphN = 0;
     int *d_flag = nullptr;
