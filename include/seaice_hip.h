@@ -163,6 +163,9 @@ int sih_evp_pre_subcycle(sih_ctx *ctx, int stage);
  * stressDivergenceU/V and oceanStressCoeff are only materialised then (they are overwritten every
  * iteration and read by nothing else in between). */
 int sih_evp_subcycle(sih_ctx *ctx, int n, int last);
+/* the same n iterations (last = 0) replayed from a HIP graph captured on first use; asynchronous on the
+ * context's stream.  For blocks so small that launch overhead dominates (many-GPU strong scaling). */
+int sih_evp_subcycle_graph(sih_ctx *ctx, int n);
 /* velocity_solver_post_subcycle (velocity_solver.F:3360-3380):
  *   stage 0: final_divergence_shear, principal stresses, ocean stress on vertices -> halo oceanStressU/V
  *   stage 1: ocean stress vertex->cell, rescale;  stage -1: both */
@@ -179,7 +182,9 @@ int sih_evp_subcycle_timed(sih_ctx *ctx, int n, int useGraph, int sampleEvery, d
                            double *cellMs, double *vertexMs);
 
 /* ---- halo exchange (pack / unpack only) -------------------------------------------------------
- * location: 0 cells, 1 vertices.  sendIdx / recvIdx are 1-based local indices, all neighbours
+ * location: 0 cells, 1 vertices (pack / unpack also take 2: cell and vertex fields in one message, per
+ * neighbour [cell planes][vertex planes]; both lists must name the same neighbours in the same order).
+ * sendIdx / recvIdx are 1-based local indices, all neighbours
  * concatenated; sendCounts / recvCounts (nPeers entries each, may be NULL with nPeers = 0 for a single
  * segment) give the number of entries per neighbour in that order. */
 int sih_halo_set_lists(sih_ctx *ctx, int location, int nSend, const int32_t *sendIdx, int nRecv,

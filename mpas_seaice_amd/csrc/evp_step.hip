@@ -836,6 +836,35 @@ static int ensureEvents(sih_ctx *c, size_t n)
     return SIH_OK;
 }
 
+// n iterations (none of them the last of the dynamics step) replayed from a captured HIP graph; asynchronous
+extern "C" int sih_evp_subcycle_graph(sih_ctx *c, int n)
+{
+    int rc = checkInit(c, "sih_evp_subcycle_graph");
+    if (rc) return rc;
+    if (n < 1) {
+        sih_set_error("sih_evp_subcycle_graph: n must be >= 1");
+        return SIH_ERR_ARG;
+    }
+    if (!c->graphExec || c->graphN != n) {
+        if (c->graphExec) {
+            hipGraphExecDestroy(c->graphExec);
+            c->graphExec = nullptr;
+        }
+        hipGraph_t graph;
+        HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        for (int it = 0; it < n; it++) {
+            launchCellKernel(c, false);
+            launchVertexKernel(c, false);
+        }
+        HIPCHK(hipStreamEndCapture(c->stream, &graph));
+        HIPCHK(hipGraphInstantiate(&c->graphExec, graph, nullptr, nullptr, 0));
+        HIPCHK(hipGraphDestroy(graph));
+        c->graphN = n;
+    }
+    HIPCHK(hipGraphLaunch(c->graphExec, c->stream));
+    return SIH_OK;
+}
+
 extern "C" int sih_evp_subcycle_timed(sih_ctx *c, int n, int useGraph, int sampleEvery, double *totalMs, double *cellMs,
                                       double *vertexMs)
 {

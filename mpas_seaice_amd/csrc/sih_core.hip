@@ -398,8 +398,12 @@ extern "C" int sih_block_destroy(sih_ctx *c)
         }
     }
     if (c->d_stage) hipFree(c->d_stage);
-    for (auto &kv : c->haloTables)
+    for (auto &kv : c->haloTables) {
         if (kv.second.d_planes) hipFree(kv.second.d_planes);
+        for (int a = 0; a < 2; a++)
+            for (int b = 0; b < 2; b++)
+                if (kv.second.d_base[a][b]) hipFree(kv.second.d_base[a][b]);
+    }
     if (c->ownStream) hipStreamDestroy(c->ownStream);
     delete c;
     return SIH_OK;
@@ -571,6 +575,20 @@ extern "C" int sih_halo_set_lists(sih_ctx *c, int location, int nSend, const int
         }
     }
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (nPeers > 0) {
+        c->hSendCounts[location].assign(sendCounts, sendCounts + nPeers);
+        c->hRecvCounts[location].assign(recvCounts, recvCounts + nPeers);
+    } else {
+        c->hSendCounts[location].assign(1, nSend);
+        c->hRecvCounts[location].assign(1, nRecv);
+    }
+    for (auto &kv : c->haloTables) {  // tables built for the previous lists are stale
+        if (kv.second.d_planes) hipFree(kv.second.d_planes);
+        for (int a = 0; a < 2; a++)
+            for (int b = 0; b < 2; b++)
+                if (kv.second.d_base[a][b]) hipFree(kv.second.d_base[a][b]);
+    }
+    c->haloTables.clear();
     int rc;
     if ((rc = uploadInts(&c->d_send[location], s))) return rc;
     if ((rc = uploadInts(&c->d_recv[location], r))) return rc;
@@ -606,12 +624,133 @@ __global__ void k_unpack_all(const T *__restrict__ buf, T *const *__restrict__ p
     }
 }
 
+// cell and vertex fields of one exchange in a single message and a single launch; per neighbour the
+// message holds [cell planes][vertex planes]
+template <typename T, bool PACK>
+__global__ void k_halo_both(T *__restrict__ buf, T *const *__restrict__ planes, int nfC, const int *__restrict__ idxC,
+                            const int *__restrict__ baseC, const int *__restrict__ cntC, int nC,
+                            const int *__restrict__ idxV, const int *__restrict__ baseV,
+                            const int *__restrict__ cntV, int nV)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int fi = blockIdx.y;
+    size_t a;
+    T *f;
+    if (fi < nfC) {
+        if (t >= nC) return;
+        a = (size_t)baseC[t] + (size_t)fi * cntC[t];
+        f = planes[fi] + idxC[t];
+    } else {
+        if (t >= nV) return;
+        a = (size_t)baseV[t] + (size_t)(fi - nfC) * cntV[t];
+        f = planes[fi] + idxV[t];
+    }
+    if (PACK)
+        buf[a] = *f;
+    else
+        *f = buf[a];
+}
+
+static int haloBoth(sih_ctx *c, int nFields, const char *const *names, void *buf, bool pack)
+{
+    if (c->hSendCounts[0].size() != c->hSendCounts[1].size() || c->hSendCounts[0].empty()) {
+        sih_set_error("sih_halo_pack/unpack: combined messages need cell and vertex lists over the same neighbours");
+        return SIH_ERR_STATE;
+    }
+    if (!buf) {
+        sih_set_error("sih_halo_pack/unpack: null buffer");
+        return SIH_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    std::string key = "2";
+    for (int f = 0; f < nFields; f++) {
+        key += '|';
+        key += names[f];
+    }
+    auto it = c->haloTables.find(key);
+    if (it == c->haloTables.end()) {
+        std::vector<void *> planes[2];
+        bool isInt = false;
+        for (int f = 0; f < nFields; f++) {
+            SihField *fl = sih_find_field(c, names[f]);
+            if (!fl || (fl->loc != LOC_CELL && fl->loc != LOC_VERTEX)) {
+                sih_set_error(std::string("sih_halo_pack/unpack: not a cell or vertex field: ") + names[f]);
+                return SIH_ERR_ARG;
+            }
+            if (f == 0) isInt = fl->isInt;
+            if (fl->isInt != isInt) {
+                sih_set_error("sih_halo_pack/unpack: fields of one call must share a type");
+                return SIH_ERR_ARG;
+            }
+            const int pad = fl->loc == LOC_CELL ? c->padC : c->padV;
+            for (int l = 0; l < fl->lead; l++)
+                planes[fl->loc == LOC_CELL ? 0 : 1].push_back((char *)fl->d + (size_t)l * pad * (isInt ? 4 : 8));
+        }
+        sih_ctx::HaloTable tb;
+        tb.isInt = isInt;
+        tb.nPlanesCell = (int)planes[0].size();
+        tb.nPlanes = (int)(planes[0].size() + planes[1].size());
+        std::vector<void *> all(planes[0]);
+        all.insert(all.end(), planes[1].begin(), planes[1].end());
+        HIPCHK(hipMalloc((void **)&tb.d_planes, sizeof(void *) * std::max<size_t>(all.size(), 1)));
+        HIPCHK(hipMemcpy(tb.d_planes, all.data(), sizeof(void *) * all.size(), hipMemcpyHostToDevice));
+        const int nfC = (int)planes[0].size(), nfV = (int)planes[1].size();
+        for (int dir = 0; dir < 2; dir++) {
+            const std::vector<int> &cc = dir == 0 ? c->hSendCounts[0] : c->hRecvCounts[0];
+            const std::vector<int> &cv = dir == 0 ? c->hSendCounts[1] : c->hRecvCounts[1];
+            std::vector<int> bC, bV;
+            long base = 0;
+            for (size_t p = 0; p < cc.size(); p++) {
+                for (int i = 0; i < cc[p]; i++) bC.push_back((int)(base + i));
+                for (int i = 0; i < cv[p]; i++) bV.push_back((int)(base + (long)nfC * cc[p] + i));
+                base += (long)nfC * cc[p] + (long)nfV * cv[p];
+            }
+            if (base > 2147483647L) {
+                sih_set_error("sih_halo_pack/unpack: message too large");
+                return SIH_ERR_ARG;
+            }
+            int rc;
+            if ((rc = uploadInts(&tb.d_base[0][dir], bC))) return rc;
+            if ((rc = uploadInts(&tb.d_base[1][dir], bV))) return rc;
+        }
+        it = c->haloTables.emplace(key, tb).first;
+    }
+    const sih_ctx::HaloTable &tb = it->second;
+    const int dir = pack ? 0 : 1;
+    const int nC = pack ? c->nSend[0] : c->nRecv[0], nV = pack ? c->nSend[1] : c->nRecv[1];
+    if (std::max(nC, nV) == 0 || tb.nPlanes == 0) return SIH_OK;
+    const int *idxC = pack ? c->d_send[0] : c->d_recv[0], *idxV = pack ? c->d_send[1] : c->d_recv[1];
+    const int *cntC = c->d_segCnt[0][dir], *cntV = c->d_segCnt[1][dir];
+    dim3 grid((std::max(nC, nV) + 255) / 256, tb.nPlanes), block(256);
+    if (tb.isInt) {
+        if (pack)
+            hipLaunchKernelGGL((k_halo_both<int, true>), grid, block, 0, c->stream, (int *)buf, (int *const *)tb.d_planes,
+                               tb.nPlanesCell, idxC, tb.d_base[0][dir], cntC, nC, idxV, tb.d_base[1][dir], cntV, nV);
+        else
+            hipLaunchKernelGGL((k_halo_both<int, false>), grid, block, 0, c->stream, (int *)buf,
+                               (int *const *)tb.d_planes, tb.nPlanesCell, idxC, tb.d_base[0][dir], cntC, nC, idxV,
+                               tb.d_base[1][dir], cntV, nV);
+    } else {
+        if (pack)
+            hipLaunchKernelGGL((k_halo_both<double, true>), grid, block, 0, c->stream, (double *)buf,
+                               (double *const *)tb.d_planes, tb.nPlanesCell, idxC, tb.d_base[0][dir], cntC, nC, idxV,
+                               tb.d_base[1][dir], cntV, nV);
+        else
+            hipLaunchKernelGGL((k_halo_both<double, false>), grid, block, 0, c->stream, (double *)buf,
+                               (double *const *)tb.d_planes, tb.nPlanesCell, idxC, tb.d_base[0][dir], cntC, nC, idxV,
+                               tb.d_base[1][dir], cntV, nV);
+    }
+    HIPCHK(hipGetLastError());
+    return SIH_OK;
+}
+
 static int haloPackUnpack(sih_ctx *c, int location, int nFields, const char *const *names, void *buf, bool pack)
 {
-    if (!c || location < 0 || location > 1 || nFields < 0 || !names) {
+    if (!c || location < 0 || location > 2 || nFields < 0 || !names) {
         sih_set_error("sih_halo_pack/unpack: bad argument");
         return SIH_ERR_ARG;
     }
+    if (location == 2) return nFields ? haloBoth(c, nFields, names, buf, pack) : SIH_OK;
     int n = pack ? c->nSend[location] : c->nRecv[location];
     const int *idx = pack ? c->d_send[location] : c->d_recv[location];
     const int *sg0 = c->d_segStart[location][pack ? 0 : 1], *sgc = c->d_segCnt[location][pack ? 0 : 1];

@@ -81,7 +81,12 @@ struct sih_ctx {
         void **d_planes = nullptr;
         int nPlanes = 0;
         bool isInt = false;
+        // combined cell + vertex messages: planes of the cell fields first, then the vertex fields; per list
+        // entry the position of its first plane in the message ([0] send side, [1] receive side)
+        int nPlanesCell = 0;
+        int *d_base[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [location][send / recv]
     };
+    std::vector<int> hSendCounts[2], hRecvCounts[2];  // per neighbour, as given to sih_halo_set_lists
     std::map<std::string, HaloTable> haloTables;  // plane-pointer tables of the field groups exchanged so far
     hipGraphExec_t graphExec = nullptr;
     int graphN = 0;

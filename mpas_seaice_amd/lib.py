@@ -67,7 +67,7 @@ EXPORTS = [
     "sih_block_create", "sih_block_destroy", "sih_last_error", "sih_set_stream", "sih_sync",
     "sih_evp_init", "sih_evp_static_changed", "sih_field_put", "sih_field_get", "sih_field_count",
     "sih_evp_pre_subcycle", "sih_evp_subcycle", "sih_evp_post_subcycle", "sih_evp_run",
-    "sih_evp_subcycle_timed", "sih_halo_set_lists", "sih_halo_pack", "sih_halo_unpack", "sih_get_info",
+    "sih_evp_subcycle_timed", "sih_evp_subcycle_graph", "sih_halo_set_lists", "sih_halo_pack", "sih_halo_unpack", "sih_get_info",
     "sih_ir_init", "sih_ir_set_tracers", "sih_ir_run", "sih_ir_get_sums", "sih_ir_run_timed",
 ]
 
@@ -104,6 +104,7 @@ def load():
     lib.sih_evp_pre_subcycle.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.sih_evp_subcycle.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     lib.sih_evp_post_subcycle.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.sih_evp_subcycle_graph.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.sih_evp_run.argtypes = [ctypes.c_void_p]
     lib.sih_evp_subcycle_timed.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
@@ -214,6 +215,9 @@ class BlockContext:
 
     def subcycle(self, n, last=False):
         check(self._lib.sih_evp_subcycle(self.handle, int(n), int(bool(last))), "sih_evp_subcycle")
+
+    def subcycle_graph(self, n):
+        check(self._lib.sih_evp_subcycle_graph(self.handle, int(n)), "sih_evp_subcycle_graph")
 
     def post_subcycle(self, stage=-1):
         check(self._lib.sih_evp_post_subcycle(self.handle, stage), "sih_evp_post_subcycle")

@@ -141,6 +141,12 @@ class CommBase:
         return t
 
 
+def _combined(names):
+    """Cell and vertex float fields of one exchange travel in one message (device path)."""
+    g = _group(names)
+    return len(g) == 2 and ("cell", False) in g and ("vertex", False) in g
+
+
 class LocalComm(CommBase):
     """All blocks in this process; block i of the partition is domain.blocklist[i]."""
 
@@ -150,7 +156,40 @@ class LocalComm(CommBase):
     def allreduce_sum(self, a):
         return a
 
+    def _exchange_combined(self, domain, names):
+        import torch
+        g = _group(names)
+        nsC, nsV = g[("cell", False)], g[("vertex", False)]
+        nfC, nfV = self.n_planes(domain, nsC), self.n_planes(domain, nsV)
+        ordered = nsC + nsV
+        dev = torch.device("cuda", torch.cuda.current_device())
+        sends, recvs, soff, roff = [], [], [], []
+        for i, b in enumerate(domain.blocklist):
+            LC, LV = self.lists[i]["cell"], self.lists[i]["vertex"]
+            sc = np.array(LC.send_counts) * nfC + np.array(LV.send_counts) * nfV
+            rc = np.array(LC.recv_counts) * nfC + np.array(LV.recv_counts) * nfV
+            soff.append(np.concatenate([[0], np.cumsum(sc)]))
+            roff.append(np.concatenate([[0], np.cumsum(rc)]))
+            s = self._torch_buf(("s2", i), int(sc.sum()), False, dev)
+            r = self._torch_buf(("r2", i), int(rc.sum()), False, dev)
+            b.ctx.halo_pack(2, ordered, s.data_ptr())
+            sends.append(s)
+            recvs.append(r)
+        for b in domain.blocklist:
+            b.ctx.sync()
+        for i in range(self.nblocks):
+            for p in range(self.nblocks):
+                cnt = int(roff[i][p + 1] - roff[i][p])
+                if cnt:
+                    ro, so = int(roff[i][p]), int(soff[p][i])
+                    recvs[i][ro:ro + cnt].copy_(sends[p][so:so + cnt])
+        torch.cuda.synchronize()
+        for i, b in enumerate(domain.blocklist):
+            b.ctx.halo_unpack(2, ordered, recvs[i].data_ptr())
+
     def halo_exchange(self, domain, names):
+        if self.device and _combined(names):
+            return self._exchange_combined(domain, names)
         for (loc, is_int), ns in _group(names).items():
             nf = self.n_planes(domain, ns)
             if self.device:
@@ -218,9 +257,43 @@ class DistComm(CommBase):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t.cpu().numpy()
 
+    def _a2a(self, r, s, nr_tot, ns_tot, recv_split, send_split, b):
+        import torch
+        if self.dist.get_backend() == "gloo":
+            # gloo moves host memory only: stage through the host with synchronous copies
+            b.ctx.sync()
+            sh = s[:ns_tot].cpu()
+            rh = torch.empty(nr_tot, dtype=sh.dtype)
+            self.dist.all_to_all_single(rh, sh, recv_split, send_split)
+            r[:nr_tot].copy_(rh)
+            torch.cuda.synchronize()
+        else:
+            self.dist.all_to_all_single(r[:nr_tot], s[:ns_tot], recv_split, send_split)
+
     def halo_exchange(self, domain, names):
         import torch
         b = domain.blocklist[0]
+        if self.device and _combined(names):
+            g = _group(names)
+            nsC, nsV = g[("cell", False)], g[("vertex", False)]
+            key = tuple(names)
+            plan = self._plans.get(key) if hasattr(self, "_plans") else None
+            if plan is None:
+                if not hasattr(self, "_plans"):
+                    self._plans = {}
+                nfC, nfV = self.n_planes(domain, nsC), self.n_planes(domain, nsV)
+                LC, LV = self.lists[0]["cell"], self.lists[0]["vertex"]
+                send_split = [c * nfC + v * nfV for c, v in zip(LC.send_counts, LV.send_counts)]
+                recv_split = [c * nfC + v * nfV for c, v in zip(LC.recv_counts, LV.recv_counts)]
+                plan = self._plans[key] = (nsC + nsV, send_split, recv_split, sum(send_split), sum(recv_split))
+            ordered, send_split, recv_split, ns_tot, nr_tot = plan
+            dev = torch.device("cuda", torch.cuda.current_device())
+            s = self._torch_buf(("s2",), ns_tot, False, dev)
+            r = self._torch_buf(("r2",), nr_tot, False, dev)
+            b.ctx.halo_pack(2, ordered, s.data_ptr())
+            self._a2a(r, s, nr_tot, ns_tot, recv_split, send_split, b)
+            b.ctx.halo_unpack(2, ordered, r.data_ptr())
+            return
         for (loc, is_int), ns in _group(names).items():
             L = self.lists[0][loc]
             nf = self.n_planes(domain, ns)
@@ -232,16 +305,7 @@ class DistComm(CommBase):
                 s = self._torch_buf(("s", loc), ns_tot, is_int, dev)
                 r = self._torch_buf(("r", loc), nr_tot, is_int, dev)
                 b.ctx.halo_pack(LOC_ID[loc], ns, s.data_ptr())
-                if self.dist.get_backend() == "gloo":
-                    # gloo moves host memory only: stage through the host with synchronous copies
-                    b.ctx.sync()
-                    sh = s[:ns_tot].cpu()
-                    rh = torch.empty(nr_tot, dtype=sh.dtype)
-                    self.dist.all_to_all_single(rh, sh, recv_split, send_split)
-                    r[:nr_tot].copy_(rh)
-                    torch.cuda.synchronize()
-                else:
-                    self.dist.all_to_all_single(r[:nr_tot], s[:ns_tot], recv_split, send_split)
+                self._a2a(r, s, nr_tot, ns_tot, recv_split, send_split, b)
                 b.ctx.halo_unpack(LOC_ID[loc], ns, r.data_ptr())
             else:
                 hf = HostFields(b)
@@ -292,9 +356,21 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
 
     from . import velocity_solver as vs
     if interval is None:
-        interval = int(os.environ.get("SIH_HALO_INTERVAL", "4"))
+        # more ranks -> smaller blocks -> the exchange latency weighs more: deeper halos, fewer exchanges
+        default = 4 if int(os.environ.get("WORLD_SIZE", "1")) <= 2 else 8
+        interval = int(os.environ.get("SIH_HALO_INTERVAL", str(default)))
+    use_graph = os.environ.get("SIH_MULTI_GRAPH", "1") != "0"
+    backend = os.environ.get("SIH_DIST_BACKEND", "nccl")  # "gloo" only for rehearsals on a box with one GPU
     if not dist.is_initialized():
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
+
+    def reduce_scalar(x, op):
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=op)
+        return float(t.item())
     rank, world = dist.get_rank(), dist.get_world_size()
     cfg = {"config_elastic_subcycle_number": nsub, "config_num_halos": max(2, interval),
            "config_halo_exchange_interval": interval}
@@ -319,7 +395,10 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
         done = 0
         while done < nsub:
             m = min(interval, nsub - done)
-            ctx.subcycle(m, last=False)
+            if use_graph and m == interval:
+                ctx.subcycle_graph(m)
+            else:
+                ctx.subcycle(m, last=False)
             done += m
             dom.comm.halo_exchange(dom, names)
     for _ in range(warmup):
@@ -334,9 +413,7 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
     dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall = float(t.item())
+    wall = reduce_scalar(wall, dist.ReduceOp.MAX)
     t0 = time.perf_counter()
     ctx.subcycle(1, last=True)
     dom.comm.halo_exchange(dom, names)
@@ -346,9 +423,7 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
     _, cell_ms, vert_ms = ctx.subcycle_timed(8, use_graph=False, sample_every=1)
     u = np.zeros(dom.blocklist[0].dimensions["nVertices"] + 1)
     ctx.get("uVelocity", u)
-    ok = torch.tensor([1.0 if np.isfinite(u).all() else 0.0], device="cuda")
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if ok.item() < 1.0:
+    if reduce_scalar(1.0 if np.isfinite(u).all() else 0.0, dist.ReduceOp.MIN) < 1.0:
         raise SystemExit("non-finite velocities after the benchmark loop")
     n_block_cells = dom.blocklist[0].dimensions["nCells"]
     vs.seaice_mesh_pool_destroy(dom)
