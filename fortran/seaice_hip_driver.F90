@@ -18,6 +18,7 @@ program seaice_hip_driver
   character(len=1024) :: caseFile, resultFile
   integer :: iu, ou, ierr
   integer(c_int32_t) :: nCells, nVertices, nEdges, maxEdges, nCategories, nSubcycles, onASphere, vertexDegree
+  integer(c_int32_t) :: nIceLayers, nSnowLayers
   real(kind=RKIND) :: sphereRadius, config_dt
 
   ! mesh pool
@@ -35,8 +36,20 @@ program seaice_hip_driver
   real(kind=RKIND), dimension(:,:), allocatable, target :: stress11, stress22, stress12
   integer(c_int32_t), dimension(:), allocatable, target :: solveVelocityPrevious
 
+  ! incremental remap: extra mesh fields and the other advected tracers (Registry.xml:2439-2524)
+  integer(c_int32_t), dimension(:,:), allocatable, target :: edgesOnVertex
+  real(kind=RKIND), dimension(:), allocatable, target :: xEdge, yEdge, zEdge
+  real(kind=RKIND), dimension(:,:,:), allocatable, target :: coeffs_reconstruct
+  real(kind=RKIND), dimension(:,:,:), allocatable, target :: surfaceTemperature, iceEnthalpy, iceSalinity, snowEnthalpy
+  integer, parameter :: nTracers = 7
+  character(len=32, kind=c_char), dimension(nTracers), target :: tracerNames, parentNames
+  type(c_ptr), dimension(nTracers) :: namePtrs, parentPtrs
+  integer(c_int32_t), dimension(nTracers), target :: tracerLayers
+  integer :: iTracer
+
   type(sih_mesh_desc) :: mesh
   type(sih_evp_config) :: cfg
+  type(sih_ir_desc) :: irDesc
   type(c_ptr) :: ctx
 
   if (command_argument_count() < 2) then
@@ -47,7 +60,7 @@ program seaice_hip_driver
   call get_command_argument(2, resultFile)
 
   open(newunit=iu, file=trim(caseFile), access="stream", form="unformatted", status="old")
-  read(iu) nCells, nVertices, nEdges, maxEdges, nCategories, nSubcycles, onASphere
+  read(iu) nCells, nVertices, nEdges, maxEdges, nCategories, nSubcycles, onASphere, nIceLayers, nSnowLayers
   read(iu) sphereRadius, config_dt
   vertexDegree = 3
 
@@ -69,6 +82,12 @@ program seaice_hip_driver
   read(iu) xCell, yCell, zCell, xVertex, yVertex, zVertex, areaCell, areaTriangle, fVertex, dvEdge, dcEdge
   read(iu) iceAreaCategory, iceVolumeCategory, snowVolumeCategory
   read(iu) uOceanVelocity, vOceanVelocity, uAirVelocity, vAirVelocity, airDensity
+  allocate(edgesOnVertex(vertexDegree,nVertices), xEdge(nEdges), yEdge(nEdges), zEdge(nEdges))
+  allocate(coeffs_reconstruct(3,maxEdges,nCells))
+  allocate(surfaceTemperature(1,nCategories,nCells), iceEnthalpy(nIceLayers,nCategories,nCells), &
+           iceSalinity(nIceLayers,nCategories,nCells), snowEnthalpy(nSnowLayers,nCategories,nCells))
+  read(iu) edgesOnVertex, xEdge, yEdge, zEdge, coeffs_reconstruct
+  read(iu) surfaceTemperature, iceEnthalpy, iceSalinity, snowEnthalpy
   close(iu)
 
   uVelocity = 0.0_RKIND
@@ -142,8 +161,53 @@ program seaice_hip_driver
   call get_r1("divergence", divergence)
   call get_r1("shear", shear)
 
+  ! ---- seaice_init_advection (mpas_seaice_advection.F:40; incremental_remap.F:165) -------------------
+  irDesc % edgesOnCell = c_loc(edgesOnCell);       irDesc % cellsOnEdge = c_loc(cellsOnEdge)
+  irDesc % verticesOnEdge = c_loc(verticesOnEdge); irDesc % edgesOnVertex = c_loc(edgesOnVertex)
+  irDesc % xEdge = c_loc(xEdge); irDesc % yEdge = c_loc(yEdge); irDesc % zEdge = c_loc(zEdge)
+  irDesc % dcEdge = c_loc(dcEdge); irDesc % dvEdge = c_loc(dvEdge)
+  irDesc % coeffsReconstruct = c_loc(coeffs_reconstruct)
+  irDesc % nCategories = nCategories
+  irDesc % rotateCartesianGrid = 1
+  call check(sih_ir_init(ctx, irDesc), "sih_ir_init")
+
+  ! the ordered tracer list of seaice_add_tracers_to_linked_list (incremental_remap_tracers.F:218-224, 860-922)
+  tracerNames  = [character(len=32) :: "iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory", &
+                  "surfaceTemperature", "iceEnthalpy", "iceSalinity", "snowEnthalpy"]
+  parentNames  = [character(len=32) :: "None", "iceAreaCategory", "iceAreaCategory", "iceAreaCategory", &
+                  "iceVolumeCategory", "iceVolumeCategory", "snowVolumeCategory"]
+  tracerLayers = [1, 1, 1, 1, nIceLayers, nIceLayers, nSnowLayers]
+  do iTracer = 1, nTracers
+     tracerNames(iTracer) = trim(tracerNames(iTracer)) // c_null_char
+     parentNames(iTracer) = trim(parentNames(iTracer)) // c_null_char
+     namePtrs(iTracer) = c_loc(tracerNames(iTracer))
+     parentPtrs(iTracer) = c_loc(parentNames(iTracer))
+  enddo
+  call check(sih_ir_set_tracers(ctx, int(nTracers, c_int), namePtrs, parentPtrs, c_loc(tracerLayers)), &
+             "sih_ir_set_tracers")
+
+  ! ---- seaice_run_advection (mpas_seaice_advection.F:90; incremental_remap.F:2338) -------------------
+  ! uVelocity / vVelocity are already on the device; the tracers are uploaded in the pool layout
+  call put_r3("iceAreaCategory", iceAreaCategory)
+  call put_r3("iceVolumeCategory", iceVolumeCategory)
+  call put_r3("snowVolumeCategory", snowVolumeCategory)
+  call put_r3("surfaceTemperature", surfaceTemperature)
+  call put_r3("iceEnthalpy", iceEnthalpy)
+  call put_r3("iceSalinity", iceSalinity)
+  call put_r3("snowEnthalpy", snowEnthalpy)
+  call check(sih_ir_run(ctx, config_dt, 0_c_int), "sih_ir_run")
+  call get_r3("iceAreaCategory", iceAreaCategory)
+  call get_r3("iceVolumeCategory", iceVolumeCategory)
+  call get_r3("snowVolumeCategory", snowVolumeCategory)
+  call get_r3("surfaceTemperature", surfaceTemperature)
+  call get_r3("iceEnthalpy", iceEnthalpy)
+  call get_r3("iceSalinity", iceSalinity)
+  call get_r3("snowEnthalpy", snowEnthalpy)
+
   open(newunit=ou, file=trim(resultFile), access="stream", form="unformatted", status="replace")
   write(ou) uVelocity, vVelocity, stress11, stress22, stress12, divergence, shear
+  write(ou) iceAreaCategory, iceVolumeCategory, snowVolumeCategory, surfaceTemperature, iceEnthalpy, iceSalinity, &
+            snowEnthalpy
   close(ou)
 
   ! ---- seaice_mesh_pool_destroy ---------------------------------------------------------------
@@ -197,5 +261,11 @@ contains
     real(kind=RKIND), dimension(:,:), intent(inout), target, contiguous :: a
     call check(sih_field_get(ctx, name//c_null_char, c_loc(a), int(size(a), c_size_t)), "get "//name)
   end subroutine get_r2
+
+  subroutine get_r3(name, a)
+    character(len=*), intent(in) :: name
+    real(kind=RKIND), dimension(:,:,:), intent(inout), target, contiguous :: a
+    call check(sih_field_get(ctx, name//c_null_char, c_loc(a), int(size(a), c_size_t)), "get "//name)
+  end subroutine get_r3
 
 end program seaice_hip_driver

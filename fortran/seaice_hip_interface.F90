@@ -9,7 +9,7 @@ module seaice_hip_interface
   public
 
   integer(c_int), parameter :: SIH_OK = 0, SIH_ERR_ARG = 1, SIH_ERR_HIP = 2, SIH_ERR_STATE = 3, &
-                               SIH_ERR_UNSUPPORTED = 4
+                               SIH_ERR_UNSUPPORTED = 4, SIH_ERR_IR = 5
 
   !> struct sih_mesh_desc
   type, bind(C) :: sih_mesh_desc
@@ -40,6 +40,14 @@ module seaice_hip_interface
      real(c_double)     :: minEdgeLengthGlobal
      integer(c_int32_t) :: computeHaloVertices
   end type sih_evp_config
+
+  !> struct sih_ir_desc
+  type, bind(C) :: sih_ir_desc
+     type(c_ptr) :: edgesOnCell, cellsOnEdge, verticesOnEdge, edgesOnVertex
+     type(c_ptr) :: xEdge, yEdge, zEdge
+     type(c_ptr) :: dcEdge, dvEdge, coeffsReconstruct
+     integer(c_int32_t) :: nCategories, rotateCartesianGrid
+  end type sih_ir_desc
 
   interface
 
@@ -175,6 +183,56 @@ module seaice_hip_interface
        type(c_ptr), value :: deviceBuf
        integer(c_int) :: ierr
      end function sih_halo_unpack
+
+     function sih_evp_subcycle_graph(ctx, n) bind(C, name="sih_evp_subcycle_graph") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n
+       integer(c_int) :: ierr
+     end function sih_evp_subcycle_graph
+
+     function sih_ir_init(ctx, desc) bind(C, name="sih_ir_init") result(ierr)
+       import :: sih_ir_desc, c_int, c_ptr
+       type(c_ptr), value :: ctx
+       type(sih_ir_desc), intent(in) :: desc
+       integer(c_int) :: ierr
+     end function sih_ir_init
+
+     !> names / parents: arrays of C pointers to NUL-terminated strings; nLayers: int32 array
+     function sih_ir_set_tracers(ctx, nTracers, names, parents, nLayers) bind(C, name="sih_ir_set_tracers") &
+          result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nTracers
+       type(c_ptr), dimension(*), intent(in) :: names, parents
+       type(c_ptr), value :: nLayers
+       integer(c_int) :: ierr
+     end function sih_ir_set_tracers
+
+     function sih_ir_run(ctx, dt, checkConservation) bind(C, name="sih_ir_run") result(ierr)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: dt
+       integer(c_int), value :: checkConservation
+       integer(c_int) :: ierr
+     end function sih_ir_run
+
+     function sih_ir_get_sums(ctx, tracer, initSums, finalSums) bind(C, name="sih_ir_get_sums") result(ierr)
+       import :: c_int, c_ptr, c_char
+       type(c_ptr), value :: ctx
+       character(kind=c_char), dimension(*), intent(in) :: tracer
+       type(c_ptr), value :: initSums, finalSums
+       integer(c_int) :: ierr
+     end function sih_ir_get_sums
+
+     function sih_ir_run_timed(ctx, dt, totalMs, phaseMs5) bind(C, name="sih_ir_run_timed") result(ierr)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: dt
+       real(c_double), intent(out) :: totalMs
+       type(c_ptr), value :: phaseMs5
+       integer(c_int) :: ierr
+     end function sih_ir_run_timed
 
      function sih_get_info(ctx, key, value) bind(C, name="sih_get_info") result(ierr)
        import :: c_int, c_ptr, c_char, c_double

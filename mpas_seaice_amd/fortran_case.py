@@ -10,8 +10,8 @@ def write_case(path, block, cfg):
     oc, at = block.structs["ocean_coupling"], block.structs["atmos_coupling"]
     nC, nV, nE, M, nCat = d["nCells"], d["nVertices"], d["nEdges"], d["maxEdges"], d["nCategories"]
     with open(path, "wb") as f:
-        np.array([nC, nV, nE, M, nCat, cfg["config_elastic_subcycle_number"], int(bool(m["on_a_sphere"]))],
-                 dtype=np.int32).tofile(f)
+        np.array([nC, nV, nE, M, nCat, cfg["config_elastic_subcycle_number"], int(bool(m["on_a_sphere"])),
+                  d["nIceLayers"], d["nSnowLayers"]], dtype=np.int32).tofile(f)
         np.array([m["sphere_radius"], cfg["config_dt"]], dtype=np.float64).tofile(f)
 
         def w(a, n):
@@ -38,15 +38,26 @@ def write_case(path, block, cfg):
         w(at["uAirVelocity"], nC)
         w(at["vAirVelocity"], nC)
         w(at["airDensity"], nC)
+        w(m["edgesOnVertex"], nV)
+        for k in ("xEdge", "yEdge", "zEdge"):
+            w(m[k], nE)
+        w(m["coeffs_reconstruct"], nC)
+        for k in ("surfaceTemperature", "iceEnthalpy", "iceSalinity", "snowEnthalpy"):
+            w(tr[k], nC)
 
 
 def read_result(path, block):
     d = block.dimensions
-    nC, nV, M = d["nCells"], d["nVertices"], d["maxEdges"]
+    nC, nV, M, nCat = d["nCells"], d["nVertices"], d["maxEdges"], d["nCategories"]
+    nIce, nSnow = d["nIceLayers"], d["nSnowLayers"]
     raw = np.fromfile(path, dtype=np.float64)
     out, o = {}, 0
     for name, shape in (("uVelocity", (nV,)), ("vVelocity", (nV,)), ("stress11", (M, nC)), ("stress22", (M, nC)),
-                        ("stress12", (M, nC)), ("divergence", (nC,)), ("shear", (nC,))):
+                        ("stress12", (M, nC)), ("divergence", (nC,)), ("shear", (nC,)),
+                        ("iceAreaCategory", (1, nCat, nC)), ("iceVolumeCategory", (1, nCat, nC)),
+                        ("snowVolumeCategory", (1, nCat, nC)), ("surfaceTemperature", (1, nCat, nC)),
+                        ("iceEnthalpy", (nIce, nCat, nC)), ("iceSalinity", (nIce, nCat, nC)),
+                        ("snowEnthalpy", (nSnow, nCat, nC))):
         n = int(np.prod(shape))
         out[name] = raw[o:o + n].reshape(shape, order="F")
         o += n

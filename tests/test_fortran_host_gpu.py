@@ -22,8 +22,11 @@ def test_fortran_driver_matches_oracle(oracle, tmp_path):
     case = str(tmp_path / "case.bin")
     res = str(tmp_path / "result.bin")
     fortran_case.write_case(case, ref.blocklist[0], ref.configs)
+    from oracle import ir_flow
     oracle.seaice_init_velocity_solver(ref)
+    ir_flow.seaice_init_advection(ref)
     oracle.seaice_run_velocity_solver(ref)
+    ir_flow.seaice_run_advection(ref)
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = "/opt/rocm/lib/llvm/lib:/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
     out = subprocess.run([EXE, case, res], capture_output=True, text=True, timeout=200, env=env)
@@ -35,7 +38,10 @@ def test_fortran_driver_matches_oracle(oracle, tmp_path):
     for name, pool, n in (("uVelocity", "velocity_solver", nV), ("vVelocity", "velocity_solver", nV),
                           ("stress11", "velocity_variational", nC), ("stress22", "velocity_variational", nC),
                           ("stress12", "velocity_variational", nC), ("divergence", "velocity_solver", nC),
-                          ("shear", "velocity_solver", nC)):
+                          ("shear", "velocity_solver", nC), ("iceAreaCategory", "tracers", nC),
+                          ("iceVolumeCategory", "tracers", nC), ("snowVolumeCategory", "tracers", nC),
+                          ("surfaceTemperature", "tracers", nC), ("iceEnthalpy", "tracers", nC),
+                          ("iceSalinity", "tracers", nC), ("snowEnthalpy", "tracers", nC)):
         r = b.structs[pool][name][..., :n]
         err = np.abs(got[name] - r).max() / np.abs(r).max()
         assert err <= 1e-10, (name, err)
