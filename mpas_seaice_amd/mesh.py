@@ -335,6 +335,46 @@ def make_sphere_mesh(n: int, radius: float = EARTH_RADIUS, reorder: bool = False
     return m
 
 
+def _delaunay_on_sphere(pos):
+    """Delaunay triangulation of points on the unit sphere = their convex hull; triangles CCW seen from outside."""
+    from scipy.spatial import ConvexHull
+    tris = ConvexHull(pos).simplices.astype(np.int64)
+    pa, pb, pc = pos[tris[:, 0]], pos[tris[:, 1]], pos[tris[:, 2]]
+    flip = np.einsum("ij,ij->i", np.cross(pb - pa, pc - pa), pa + pb + pc) < 0.0
+    tris[flip] = tris[flip][:, [0, 2, 1]]
+    return tris
+
+
+def make_variable_sphere_mesh(n: int, ratio: float = 3.0, jitter: float = 0.22, radius: float = EARTH_RADIUS,
+                              lloyd_iters: int = 2, seed: int = 20241020) -> Mesh:
+    """Variable-resolution full-sphere Voronoi mesh with cells of 5, 6 and 7 (occasionally 8) edges: a stand-in
+    for the refined-region meshes (oRRS 18-6 km) the reference is run on, which are not redistributable.
+
+    The generators of the geodesic mesh are pulled towards the north pole by the map
+    z' = (z + a) / (1 + a z), a = (ratio - 1) / (ratio + 1) (spacing ratio ``ratio`` between the two poles),
+    displaced by a seeded pseudo-random fraction ``jitter`` of the local spacing, triangulated again
+    (Delaunay) and smoothed by a few Lloyd iterations with re-triangulation.
+    """
+    pos, _ = geodesic_triangulation(n)
+    a = (ratio - 1.0) / (ratio + 1.0)
+    z = pos[:, 2]
+    z2 = (z + a) / (1.0 + a * z)
+    s = np.sqrt(np.maximum(1.0 - z2 * z2, 0.0)) / np.sqrt(np.maximum(1.0 - z * z, 1e-300))
+    pos = _unit(np.stack([pos[:, 0] * s, pos[:, 1] * s, z2], axis=1) + 1e-300)
+    spacing = np.sqrt(4.0 * np.pi / len(pos)) * (1.0 - a * a) / (1.0 + a * z) ** 1.0 / np.sqrt(1.0 - a * a)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pos = _unit(pos + jitter * spacing[:, None] * rng.standard_normal(pos.shape) / np.sqrt(3.0))
+    tris = _delaunay_on_sphere(pos)
+    for _ in range(lloyd_iters):
+        pos = lloyd_relax(pos, tris, 1)
+        tris = _delaunay_on_sphere(pos)
+    pos, tris = _reorder(pos, tris, False)
+    m = _build_from_triangulation(pos, tris, radius, True)
+    m = _finish_sphere(m, radius)
+    add_reconstruction_coefficients(m)
+    return m
+
+
 QU_FREQ = {"QU480": 16, "QU240": 32, "QU120": 64, "QU60": 128, "QU30": 256}
 
 

@@ -57,6 +57,17 @@ def test_full_step_with_open_water_masks(oracle):
     compare_domains(dom, ref, RUN_OUTPUTS, TOL)
 
 
+def test_variable_resolution_mesh_with_heptagons(oracle):
+    """Irregular degrees (5-, 6- and 7-sided cells, maxEdges = 7) on a 3:1 variable-resolution sphere."""
+    mesh = get_mesh("var12")
+    assert mesh.maxEdges == 7 and (mesh["nEdgesOnCell"] == 7).any() and (mesh["nEdgesOnCell"] == 5).any()
+    cfg = {"config_dt": 1800.0, "config_elastic_subcycle_number": 120}
+    dom, ref = run_pair(oracle, mesh, None, configs=cfg)
+    compare_domains(dom, ref, STATIC_OUTPUTS + RUN_OUTPUTS, TOL)
+    u = dom.blocklist[0].structs["velocity_solver"]["uVelocity"]
+    assert np.isfinite(u).all() and np.abs(u).max() > 1e-3
+
+
 def test_planar_hex_with_boundary(oracle):
     mesh = get_mesh("hex_24_20")
     cfg = {"config_dt": 600.0, "config_elastic_subcycle_number": 60}

@@ -88,12 +88,14 @@ def test_geometric_averages_regular_hexagon(oracle):
         assert abs(g[c, k]) < 1e-9 * h ** 4
 
 
-@pytest.mark.parametrize("meshname,name", [("QU480", "QU480"), ("hex_24_20", None)])
+@pytest.mark.parametrize("meshname,name", [("QU480", "QU480"), ("hex_24_20", None), ("var12", "var")])
 def test_conservation_and_monotonicity(oracle, meshname, name):
     ir = _ir()
     cfg = {"config_conservation_check": True}
     if name is None:
         cfg.update({"config_dt": 600.0, "config_elastic_subcycle_number": 60})
+    if name == "var":
+        cfg.update({"config_dt": 1800.0, "config_elastic_subcycle_number": 60})
     dom = _setup(oracle, meshname, name, configs=cfg)
     oracle.seaice_run_velocity_solver(dom)
     b = dom.blocklist[0]

@@ -84,6 +84,8 @@ def test_init_geometry_matches_oracle(oracle, meshname):
     ("QU480", "QU480", {}, {"open_water_band": (-0.3, 0.4)}),
     ("QU240", "QU240", {"config_elastic_subcycle_number": 30}, {}),
     ("hex_24_20", None, {"config_dt": 600.0, "config_elastic_subcycle_number": 60}, {}),
+    # variable resolution, cells with 5, 6 and 7 edges (maxEdges = 7)
+    ("var12", None, {"config_dt": 1800.0, "config_elastic_subcycle_number": 60}, {}),
 ])
 def test_advection_step_matches_oracle(oracle, meshname, name, cfg, kw):
     """One incremental-remap step from identical velocities: every advected tracer, plus the

@@ -13,6 +13,8 @@ def get_mesh(name, **kw):
         if name.startswith("hex"):
             _, nx, ny = name.split("_")
             _MESH_CACHE[key] = meshmod.make_planar_hex_mesh(int(nx), int(ny), 1.28e6 / int(nx))
+        elif name.startswith("var"):
+            _MESH_CACHE[key] = meshmod.make_variable_sphere_mesh(int(name[3:]), **kw)
         elif name.startswith("geo"):
             _MESH_CACHE[key] = meshmod.make_sphere_mesh(int(name[3:]), **kw)
         else:
