@@ -19,6 +19,7 @@ import torch.distributed as dist  # noqa: E402
 
 from mpas_seaice_amd import cases, parallel  # noqa: E402
 from oracle import evp_flow as ora  # noqa: E402
+from oracle import ir_flow as ira  # noqa: E402
 from util import get_mesh  # noqa: E402
 
 
@@ -32,7 +33,9 @@ def main():
     cfg = {"config_elastic_subcycle_number": 12, "config_dt": 7200.0}
     ref = cases.make_domain(mesh, None, configs=cfg, open_water_band=(-0.2, 0.3))
     ora.seaice_init_velocity_solver(ref)
+    ira.seaice_init_advection(ref)
     ora.seaice_run_velocity_solver(ref)
+    ira.seaice_run_advection(ref)
     dom, halo, _ = parallel.make_partitioned_domain(mesh, None, world, configs=cfg, only_block=rank,
                                                     open_water_band=(-0.2, 0.3))
     if mode == "cpu":
@@ -40,15 +43,20 @@ def main():
         dom.halo = parallel.oracle_halo_callback(comm)
         dom.allreduce_min = comm.allreduce_min
         ora.seaice_init_velocity_solver(dom)
+        ira.seaice_init_advection(dom)
         ora.seaice_run_velocity_solver(dom)
+        ira.seaice_run_advection(dom)
         tol = 0.0
     else:
         from mpas_seaice_amd import velocity_solver as vs
         torch.cuda.set_device(0)
         vs.seaice_mesh_pool_create(dom, device=0)
         dom.comm = parallel.DistComm(dom, halo, world, rank)
+        from mpas_seaice_amd import advection as adv
         vs.seaice_init_velocity_solver(dom)
+        adv.seaice_init_advection(dom)
         vs.seaice_run_velocity_solver(dom)
+        adv.seaice_run_advection(dom)
         vs.seaice_mesh_pool_destroy(dom)
         tol = 1e-10
     b = dom.blocklist[0]
@@ -57,7 +65,9 @@ def main():
     for pool, name, loc in (("velocity_solver", "uVelocity", "vertex"), ("velocity_solver", "vVelocity", "vertex"),
                             ("velocity_variational", "stress11", "cell"), ("velocity_variational", "stress12", "cell"),
                             ("velocity_solver", "oceanStressCellU", "cell"), ("velocity_solver", "divergence", "cell"),
-                            ("velocity_solver", "solveVelocity", "vertex")):
+                            ("velocity_solver", "solveVelocity", "vertex"), ("tracers", "iceAreaCategory", "cell"),
+                            ("tracers", "iceVolumeCategory", "cell"), ("tracers", "iceEnthalpy", "cell"),
+                            ("tracers", "snowEnthalpy", "cell"), ("tracers", "surfaceTemperature", "cell")):
         nown = halo.nOwned[loc]
         g = halo.globalID[loc][:nown]
         mine = b.structs[pool][name][..., :nown]
