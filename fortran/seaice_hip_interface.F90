@@ -113,6 +113,28 @@ module seaice_hip_interface
        integer(c_int) :: ierr
      end function sih_field_get
 
+     ! names: array of C pointers to NUL-terminated strings (c_loc of character(kind=c_char) targets);
+     ! hosts: array of c_loc(array); counts: logical element counts
+     function sih_fields_put(ctx, nFields, names, hosts, counts) bind(C, name="sih_fields_put") result(ierr)
+       import :: c_int, c_ptr, c_size_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nFields
+       type(c_ptr), dimension(*), intent(in) :: names
+       type(c_ptr), dimension(*), intent(in) :: hosts
+       integer(c_size_t), dimension(*), intent(in) :: counts
+       integer(c_int) :: ierr
+     end function sih_fields_put
+
+     function sih_fields_get(ctx, nFields, names, hosts, counts) bind(C, name="sih_fields_get") result(ierr)
+       import :: c_int, c_ptr, c_size_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nFields
+       type(c_ptr), dimension(*), intent(in) :: names
+       type(c_ptr), dimension(*), intent(in) :: hosts
+       integer(c_size_t), dimension(*), intent(in) :: counts
+       integer(c_int) :: ierr
+     end function sih_fields_get
+
      function sih_field_count(ctx, name, elemSize) bind(C, name="sih_field_count") result(n)
        import :: c_int, c_ptr, c_char, c_size_t
        type(c_ptr), value :: ctx

@@ -144,6 +144,14 @@ int sih_evp_static_changed(sih_ctx *ctx);
  *   boundary : interiorVertex          ridging : ridgeConvergence ridgeShear */
 int sih_field_put(sih_ctx *ctx, const char *name, const void *host, size_t count);
 int sih_field_get(sih_ctx *ctx, const char *name, void *host, size_t count);
+/* The same for nFields fields in one call: all copies and layout kernels are queued back to back and
+ * the stream is waited for once, instead of once per field.  This is what a host that refreshes a
+ * whole pool per time step (the argument lists of the mpas_pool_get_array blocks in
+ * mpas_seaice_velocity_solver.F:613-671 and :2870-2960) should call.  Nothing is moved when any
+ * name or count is wrong. */
+int sih_fields_put(sih_ctx *ctx, int nFields, const char *const *names, const void *const *hosts,
+                   const size_t *counts);
+int sih_fields_get(sih_ctx *ctx, int nFields, const char *const *names, void *const *hosts, const size_t *counts);
 /* logical element count of a field, and 8 (float64) or 4 (int32) in *elemSize; 0 if unknown */
 size_t sih_field_count(sih_ctx *ctx, const char *name, int *elemSize);
 

@@ -59,10 +59,8 @@ def seaice_run_advection(domain, updateHaloInit=True, updateHaloFinal=False, upl
     if upload:
         for b in domain.blocklist:
             vs, tp = b.structs["velocity_solver"], b.structs["tracers"]
-            b.ctx.put("uVelocity", vs["uVelocity"])
-            b.ctx.put("vVelocity", vs["vVelocity"])
-            for n in names:
-                b.ctx.put(n, tp[n])
+            b.ctx.put_many([("uVelocity", vs["uVelocity"]), ("vVelocity", vs["vVelocity"])]
+                           + [(n, tp[n]) for n in names])
     # initial halo updates of velocity, mass and tracers, :2436-2487
     if updateHaloInit and comm is not None and cfg["config_use_halo_exch"]:
         comm.halo_exchange(domain, ["uVelocity", "vVelocity"])
@@ -94,5 +92,4 @@ def seaice_run_advection(domain, updateHaloInit=True, updateHaloFinal=False, upl
     if download:
         for b in domain.blocklist:
             tp = b.structs["tracers"]
-            for n in names:
-                b.ctx.get(n, tp[n])
+            b.ctx.get_many((n, tp[n]) for n in names)

@@ -438,50 +438,81 @@ extern "C" size_t sih_field_count(sih_ctx *c, const char *name, int *elemSize)
     return (size_t)f->lead * locCount(c, f->loc);
 }
 
-static int putget(sih_ctx *c, const char *name, void *host, size_t count, bool put)
+// One or many fields between host arrays and the device planes.  Every field gets its own 256-byte
+// aligned region of the staging buffer, so all copies and all layout kernels of a batch are queued
+// back to back and the stream is waited for once at the end.
+static int putgetMany(sih_ctx *c, int nf, const char *const *names, void *const *hosts, const size_t *counts, bool put)
 {
-    if (!c || !name || !host) {
+    if (!c || nf < 0 || (nf > 0 && (!names || !hosts || !counts))) {
         sih_set_error("sih_field_put/get: null argument");
         return SIH_ERR_ARG;
     }
-    SihField *f = sih_find_field(c, name);
-    if (!f) {
-        sih_set_error(std::string("unknown field: ") + name);
-        return SIH_ERR_ARG;
+    std::vector<SihField *> fs(nf);
+    std::vector<size_t> off(nf + 1, 0);
+    for (int k = 0; k < nf; k++) {
+        if (!names[k] || !hosts[k]) {
+            sih_set_error("sih_field_put/get: null argument");
+            return SIH_ERR_ARG;
+        }
+        SihField *f = sih_find_field(c, names[k]);
+        if (!f) {
+            sih_set_error(std::string("unknown field: ") + names[k]);
+            return SIH_ERR_ARG;
+        }
+        if (counts[k] != (size_t)locCount(c, f->loc) * f->lead) {
+            sih_set_error(std::string("field ") + names[k] + ": element count mismatch");
+            return SIH_ERR_ARG;
+        }
+        fs[k] = f;
+        size_t bytes = counts[k] * (f->isInt ? 4 : 8);
+        off[k + 1] = off[k] + ((bytes + 255) & ~(size_t)255);
     }
-    int n = locCount(c, f->loc), pad = locPad(c, f->loc), L = f->lead;
-    if (count != (size_t)n * L) {
-        sih_set_error(std::string("field ") + name + ": element count mismatch");
-        return SIH_ERR_ARG;
-    }
+    if (nf == 0) return SIH_OK;
     HIPCHK(hipSetDevice(c->device));
-    size_t es = f->isInt ? 4 : 8, bytes = count * es;
-    int rc = ensureStage(c, bytes);
+    int rc = ensureStage(c, off[nf]);
     if (rc) return rc;
-    const int *perm = c->renumber ? locPerm(c, f->loc) : nullptr;
-    long total = (long)n * L;
-    dim3 grid((unsigned)((total + 255) / 256)), block(256);
-    if (put) {
-        HIPCHK(hipMemcpyAsync(c->d_stage, host, bytes, hipMemcpyHostToDevice, c->stream));
-        if (f->isInt)
-            hipLaunchKernelGGL(k_put<int>, grid, block, 0, c->stream, (int *)f->d, (const int *)c->d_stage, perm, n, L, pad);
-        else
-            hipLaunchKernelGGL(k_put<double>, grid, block, 0, c->stream, (double *)f->d, (const double *)c->d_stage, perm,
-                               n, L, pad);
+    for (int k = 0; k < nf; k++) {
+        SihField *f = fs[k];
+        int n = locCount(c, f->loc), pad = locPad(c, f->loc), L = f->lead;
+        size_t bytes = counts[k] * (f->isInt ? 4 : 8);
+        char *stage = (char *)c->d_stage + off[k];
+        const int *perm = c->renumber ? locPerm(c, f->loc) : nullptr;
+        long total = (long)n * L;
+        dim3 grid((unsigned)((total + 255) / 256)), block(256);
+        if (put) {
+            HIPCHK(hipMemcpyAsync(stage, hosts[k], bytes, hipMemcpyHostToDevice, c->stream));
+            if (f->isInt)
+                hipLaunchKernelGGL(k_put<int>, grid, block, 0, c->stream, (int *)f->d, (const int *)stage, perm, n, L, pad);
+            else
+                hipLaunchKernelGGL(k_put<double>, grid, block, 0, c->stream, (double *)f->d, (const double *)stage, perm, n, L,
+                                   pad);
+        } else {
+            if (f->isInt)
+                hipLaunchKernelGGL(k_get<int>, grid, block, 0, c->stream, (int *)stage, (const int *)f->d, perm, n, L, pad);
+            else
+                hipLaunchKernelGGL(k_get<double>, grid, block, 0, c->stream, (double *)stage, (const double *)f->d, perm, n, L,
+                                   pad);
+        }
         HIPCHK(hipGetLastError());
-        // the staging buffer is reused by the next call
-        HIPCHK(hipStreamSynchronize(c->stream));
-    } else {
-        if (f->isInt)
-            hipLaunchKernelGGL(k_get<int>, grid, block, 0, c->stream, (int *)c->d_stage, (const int *)f->d, perm, n, L, pad);
-        else
-            hipLaunchKernelGGL(k_get<double>, grid, block, 0, c->stream, (double *)c->d_stage, (const double *)f->d, perm,
-                               n, L, pad);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(host, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
     }
+    if (!put)
+        for (int k = 0; k < nf; k++)
+            HIPCHK(hipMemcpyAsync(hosts[k], (char *)c->d_stage + off[k], counts[k] * (fs[k]->isInt ? 4 : 8),
+                                  hipMemcpyDeviceToHost, c->stream));
+    // the staging buffer is reused by the next call, and the caller owns the host arrays again
+    HIPCHK(hipStreamSynchronize(c->stream));
     return SIH_OK;
+}
+
+static int putget(sih_ctx *c, const char *name, void *host, size_t count, bool put)
+{
+    return putgetMany(c, 1, &name, &host, &count, put);
+}
+
+static void notePut(sih_ctx *c, const char *name)
+{
+    if (c->inited && (!strncmp(name, "basisGradient", 13) || !strncmp(name, "basisIntegrals", 14)))
+        c->sparseGrad = false;  // stale until sih_evp_static_changed()
 }
 
 extern "C" int sih_field_put(sih_ctx *c, const char *name, const void *host, size_t count)
@@ -491,14 +522,31 @@ extern "C" int sih_field_put(sih_ctx *c, const char *name, const void *host, siz
         return SIH_ERR_ARG;
     }
     int rc = putget(c, name, const_cast<void *>(host), count, true);
-    if (rc == SIH_OK && c->inited && (!strncmp(name, "basisGradient", 13) || !strncmp(name, "basisIntegrals", 14)))
-        c->sparseGrad = false;  // stale until sih_evp_static_changed()
+    if (rc == SIH_OK) notePut(c, name);
     return rc;
 }
 
 extern "C" int sih_field_get(sih_ctx *c, const char *name, void *host, size_t count)
 {
     return putget(c, name, host, count, false);
+}
+
+extern "C" int sih_fields_put(sih_ctx *c, int nFields, const char *const *names, const void *const *hosts,
+                              const size_t *counts)
+{
+    for (int k = 0; names && k < nFields; k++)
+        if (names[k] && names[k][0] == '_') {
+            sih_set_error("fields starting with '_' are library-internal");
+            return SIH_ERR_ARG;
+        }
+    int rc = putgetMany(c, nFields, names, const_cast<void *const *>(hosts), counts, true);
+    for (int k = 0; rc == SIH_OK && k < nFields; k++) notePut(c, names[k]);
+    return rc;
+}
+
+extern "C" int sih_fields_get(sih_ctx *c, int nFields, const char *const *names, void *const *hosts, const size_t *counts)
+{
+    return putgetMany(c, nFields, names, hosts, counts, false);
 }
 
 // ------------------------------------------------------------------------------------------ halo

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <map>
+#include <cstdint>
 #include <string>
 #include <vector>
 

@@ -69,6 +69,7 @@ EXPORTS = [
     "sih_evp_pre_subcycle", "sih_evp_subcycle", "sih_evp_post_subcycle", "sih_evp_run",
     "sih_evp_subcycle_timed", "sih_evp_subcycle_graph", "sih_halo_set_lists", "sih_halo_pack", "sih_halo_unpack", "sih_get_info",
     "sih_ir_init", "sih_ir_set_tracers", "sih_ir_run", "sih_ir_get_sums", "sih_ir_run_timed",
+    "sih_fields_put", "sih_fields_get",
 ]
 
 
@@ -101,6 +102,9 @@ def load():
     lib.sih_evp_static_changed.argtypes = [ctypes.c_void_p]
     lib.sih_field_put.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t]
     lib.sih_field_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t]
+    for fn in (lib.sih_fields_put, lib.sih_fields_get):
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
+                       ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
     lib.sih_evp_pre_subcycle.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.sih_evp_subcycle.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     lib.sih_evp_post_subcycle.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -209,6 +213,31 @@ class BlockContext:
         assert arr.flags["F_CONTIGUOUS"] or arr.flags["C_CONTIGUOUS"], name
         assert arr.size >= n, (name, arr.size, n)
         check(self._lib.sih_field_get(self.handle, name.encode(), _ptr(arr), n), f"sih_field_get({name})")
+
+    def _many(self, fn, what, items):
+        """items: iterable of (name, array); one library call for all of them."""
+        items = list(items)
+        if not items:
+            return
+        k = len(items)
+        names = (ctypes.c_char_p * k)()
+        hosts = (ctypes.c_void_p * k)()
+        counts = (ctypes.c_size_t * k)()
+        for i, (name, arr) in enumerate(items):
+            n, es = self.field_count(name)
+            if n == 0:
+                raise SeaiceHipError(f"unknown field {name}")
+            assert arr.dtype == (np.int32 if es == 4 else np.float64), (name, arr.dtype)
+            assert arr.flags["F_CONTIGUOUS"] or arr.flags["C_CONTIGUOUS"], name
+            assert arr.size >= n, (name, arr.size, n)
+            names[i], hosts[i], counts[i] = name.encode(), arr.ctypes.data, n
+        check(fn(self.handle, k, names, hosts, counts), what)
+
+    def put_many(self, items):
+        self._many(self._lib.sih_fields_put, "sih_fields_put", items)
+
+    def get_many(self, items):
+        self._many(self._lib.sih_fields_get, "sih_fields_get", items)
 
     def pre_subcycle(self, stage=-1):
         check(self._lib.sih_evp_pre_subcycle(self.handle, stage), "sih_evp_pre_subcycle")

@@ -153,22 +153,19 @@ def seaice_init_velocity_solver(domain):
 
 def _upload(domain, b):
     cfg = domain.configs
-    for pool, name in RUN_INPUTS:
-        b.ctx.put(name, b.structs[pool][name])
+    items = list(RUN_INPUTS)
     if cfg["config_use_surface_tilt"] and not cfg["config_geostrophic_surface_tilt"]:
-        b.ctx.put("seaSurfaceTiltU", b.structs["ocean_coupling"]["seaSurfaceTiltU"])
-        b.ctx.put("seaSurfaceTiltV", b.structs["ocean_coupling"]["seaSurfaceTiltV"])
+        items += [("ocean_coupling", "seaSurfaceTiltU"), ("ocean_coupling", "seaSurfaceTiltV")]
     if not cfg["config_calc_velocity_masks"]:
-        b.ctx.put("solveStress", b.structs["velocity_solver"]["solveStress"])
-        b.ctx.put("solveVelocity", b.structs["velocity_solver"]["solveVelocity"])
+        items += [("velocity_solver", "solveStress"), ("velocity_solver", "solveVelocity")]
+    b.ctx.put_many((name, b.structs[pool][name]) for pool, name in items)
 
 
 def _download(domain, b):
-    for pool, name in RUN_OUTPUTS:
-        b.ctx.get(name, b.structs[pool][name])
+    items = list(RUN_OUTPUTS)
     if domain.configs["config_use_column_package"]:
-        b.ctx.get("ridgeConvergence", b.structs["ridging"]["ridgeConvergence"])
-        b.ctx.get("ridgeShear", b.structs["ridging"]["ridgeShear"])
+        items += [("ridging", "ridgeConvergence"), ("ridging", "ridgeShear")]
+    b.ctx.get_many((name, b.structs[pool][name]) for pool, name in items)
 
 
 def velocity_solver_pre_subcycle(domain):

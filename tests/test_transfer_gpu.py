@@ -1,0 +1,59 @@
+"""Host <-> device field transfers through the C-ABI: batched put/get."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from mpas_seaice_amd import cases, lib as sihlib, velocity_solver as vs
+from util import get_mesh
+
+pytestmark = pytest.mark.gpu
+
+
+def _domain():
+    dom = cases.make_domain(get_mesh("QU480"), "analytic")
+    vs.seaice_mesh_pool_create(dom)
+    vs.seaice_init_velocity_solver(dom)
+    return dom
+
+
+def _same(ctx, name, a, b):
+    """the pools carry one spare element per location (index nCells+1 etc.) that never crosses the bus"""
+    n, _ = ctx.field_count(name)
+    return np.array_equal(a.ravel(order="F")[:n], b.ravel(order="F")[:n])
+
+
+def test_batched_put_get_matches_single_calls():
+    dom = _domain()
+    b = dom.blocklist[0]
+    rng = np.random.default_rng(11)
+    names = [("velocity_solver", "uVelocity"), ("velocity_variational", "stress11"),
+             ("tracers", "iceAreaCategory"), ("velocity_solver", "solveVelocity")]
+    src = {}
+    for pool, n in names:
+        a = b.structs[pool][n]
+        src[n] = (rng.integers(0, 2, a.shape).astype(np.int32) if a.dtype == np.int32
+                  else rng.standard_normal(a.shape)).copy(order="F")
+    b.ctx.put_many((n, src[n]) for _, n in names)
+    for _, n in names:  # batched put, single get
+        out = np.zeros_like(src[n])
+        b.ctx.get(n, out)
+        assert _same(b.ctx, n, out, src[n]), n
+    outs = {n: np.zeros_like(src[n]) for _, n in names}
+    b.ctx.get_many(outs.items())  # batched get
+    for _, n in names:
+        assert _same(b.ctx, n, outs[n], src[n]), n
+    # a wrong name anywhere in the batch moves nothing
+    before = np.zeros_like(src["uVelocity"])
+    b.ctx.get("uVelocity", before)
+    b.ctx.put_many([])  # an empty batch is a no-op
+    k = 2
+    nm = (ctypes.c_char_p * k)(b"uVelocity", b"noSuchField")
+    one = np.ones_like(before)
+    hs = (ctypes.c_void_p * k)(one.ctypes.data, one.ctypes.data)
+    ct = (ctypes.c_size_t * k)(one.size, one.size)
+    assert b.ctx._lib.sih_fields_put(b.ctx.handle, k, nm, hs, ct) == 1  # SIH_ERR_ARG
+    after = np.zeros_like(before)
+    b.ctx.get("uVelocity", after)
+    assert np.array_equal(before, after)
+    vs.seaice_mesh_pool_destroy(dom)
