@@ -197,7 +197,8 @@ def main():
         wall, pre_ms, post_ms, cell_ms, vert_ms, n_cells_total = (res[k] for k in (
             "wall", "pre_ms", "post_ms", "cell_ms", "vert_ms", "n_cells_total"))
         parallelism = (f"{world} MPAS blocks, one per GPU, {res['interval']} halo layers, RCCL exchange of "
-                       f"uVelocity/vVelocity/stress every {res['interval']} subcycles")
+                       f"uVelocity/vVelocity/stress every {res['interval']} subcycles"
+                       + (", transfer overlapped with interior work" if res.get("overlap") else ""))
         block_cells = res["n_block_cells"]
         if rank != 0:
             return

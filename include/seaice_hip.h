@@ -174,6 +174,29 @@ int sih_evp_subcycle(sih_ctx *ctx, int n, int last);
 /* the same n iterations (last = 0) replayed from a HIP graph captured on first use; asynchronous on the
  * context's stream.  For blocks so small that launch overhead dominates (many-GPU strong scaling). */
 int sih_evp_subcycle_graph(sih_ctx *ctx, int n);
+/* Pieces of one subcycle iteration (none the last of the dynamics step), for a host that overlaps the
+ * halo exchange the reference does after every iteration (velocity_solver.F:2543-2584) with work that
+ * needs no halo value.  sih_evp_overlap_setup derives four entity subsets from the lists given to
+ * sih_halo_set_lists (call it after them and after sih_evp_init):
+ *   interior cells : no vertex in the vertex receive list and not in the cell receive list
+ *   rim cells      : the others
+ *   send vertices  : updated vertices that are in the vertex send list
+ *   rest vertices  : the other vertices the vertex kernel updates
+ * sih_evp_subcycle_parts queues the given sequence of pieces on the context's stream (useGraph != 0:
+ * as one HIP graph, captured per distinct sequence on first use).  A typical sequence around an
+ * exchange is  CELLS_ALL, VERTICES_SEND | pack, start transfer | VERTICES_REST, CELLS_INTERIOR |
+ * wait, unpack | CELLS_RIM, VERTICES_ALL ...  Every entity is computed once per iteration from the
+ * same inputs as by sih_evp_subcycle, so the results are identical. */
+enum {
+    SIH_PART_CELLS_ALL = 0,
+    SIH_PART_CELLS_INTERIOR = 1,
+    SIH_PART_CELLS_RIM = 2,
+    SIH_PART_VERTICES_ALL = 3,
+    SIH_PART_VERTICES_SEND = 4,
+    SIH_PART_VERTICES_REST = 5
+};
+int sih_evp_overlap_setup(sih_ctx *ctx);
+int sih_evp_subcycle_parts(sih_ctx *ctx, int nParts, const int32_t *parts, int useGraph);
 /* velocity_solver_post_subcycle (velocity_solver.F:3360-3380):
  *   stage 0: final_divergence_shear, principal stresses, ocean stress on vertices -> halo oceanStressU/V
  *   stage 1: ocean stress vertex->cell, rescale;  stage -1: both */

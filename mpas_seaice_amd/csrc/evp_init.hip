@@ -504,7 +504,7 @@ extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
         return SIH_ERR_ARG;
     }
     if (c->graphExec) {
-        hipGraphExecDestroy(c->graphExec);
+        (void)hipGraphExecDestroy(c->graphExec);
         c->graphExec = nullptr;
         c->graphN = 0;
     }
@@ -521,7 +521,7 @@ extern "C" int sih_evp_static_changed(sih_ctx *c)
     InitArgs a = makeInitArgs(c);
     int rc = packStatic(c, a);
     if (c->graphExec) {
-        hipGraphExecDestroy(c->graphExec);
+        (void)hipGraphExecDestroy(c->graphExec);
         c->graphExec = nullptr;
         c->graphN = 0;
     }

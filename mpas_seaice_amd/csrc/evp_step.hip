@@ -342,10 +342,16 @@ __global__ void k_pre4_cells(SihDev d)
 // partial sums stressDivergenceUCell / VCell; the vertex kernel adds the three of them in
 // cellsOnVertex order exactly as the reference loop does (:1172-1173), so no rounding changes.
 template <int M, bool SPARSE, bool LAST>
-__global__ void __launch_bounds__(256) k_sub_cells(SihDev d)
+__global__ void __launch_bounds__(256) k_sub_cells(SihDev d, const int *__restrict__ list, int nList)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= d.nCells) return;
+    // list == nullptr: every cell; else the nList cells it names (ascending, so loads stay mostly coalesced)
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (list) {
+        if (c >= nList) return;
+        c = list[c];
+    } else if (c >= d.nCells) {
+        return;
+    }
     const int P = d.padC;
     if (d.solveStress[c] != 1) {
         if (LAST && d.relation == 1) {
@@ -497,10 +503,15 @@ __global__ void __launch_bounds__(256) k_sub_cells(SihDev d)
 // (variational.F:1139-1178), ocean_stress_coefficient (velocity_solver.F:2986-3082) and solve_velocity
 // (:3096-3208) or solve_velocity_revised (:3222-3342).
 template <bool LAST>
-__global__ void __launch_bounds__(256) k_sub_vertices(SihDev d)
+__global__ void __launch_bounds__(256) k_sub_vertices(SihDev d, const int *__restrict__ list, int nList)
 {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= d.nVertices) return;
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (list) {
+        if (v >= nList) return;
+        v = list[v];
+    } else if (v >= d.nVertices) {
+        return;
+    }
     if (d.haloVertices) {  // halo vertices with all three cells in the block are updated redundantly
         if (!d.vActive[v]) return;
     } else if (v >= d.nVerticesSolve) {
@@ -736,44 +747,51 @@ extern "C" int sih_evp_pre_subcycle(sih_ctx *c, int stage)
 }
 
 template <int M>
-static void launchCells(sih_ctx *c, bool last)
+static void launchCells(sih_ctx *c, bool last, const int *list, int nList)
 {
-    dim3 b(256), g = gridFor(c->nCells);
+    dim3 b(256), g = gridFor(list ? nList : c->nCells);
     const SihDev &d = c->dev;
     if (c->sparseGrad) {
         if (last)
-            hipLaunchKernelGGL((k_sub_cells<M, true, true>), g, b, 0, c->stream, d);
+            hipLaunchKernelGGL((k_sub_cells<M, true, true>), g, b, 0, c->stream, d, list, nList);
         else
-            hipLaunchKernelGGL((k_sub_cells<M, true, false>), g, b, 0, c->stream, d);
+            hipLaunchKernelGGL((k_sub_cells<M, true, false>), g, b, 0, c->stream, d, list, nList);
     } else {
         if (last)
-            hipLaunchKernelGGL((k_sub_cells<M, false, true>), g, b, 0, c->stream, d);
+            hipLaunchKernelGGL((k_sub_cells<M, false, true>), g, b, 0, c->stream, d, list, nList);
         else
-            hipLaunchKernelGGL((k_sub_cells<M, false, false>), g, b, 0, c->stream, d);
+            hipLaunchKernelGGL((k_sub_cells<M, false, false>), g, b, 0, c->stream, d, list, nList);
     }
 }
 
-static void launchCellKernel(sih_ctx *c, bool last)
+// subset >= 0: only the entities of c->d_part[subset] (nothing to do when that subset is empty)
+static void launchCellKernel(sih_ctx *c, bool last, int subset = -1)
 {
+    const int *list = subset >= 0 ? c->d_part[subset] : nullptr;
+    const int nList = subset >= 0 ? c->nPart[subset] : 0;
+    if (subset >= 0 && nList == 0) return;
     switch (c->M) {
-        case 3: launchCells<3>(c, last); break;
-        case 4: launchCells<4>(c, last); break;
-        case 5: launchCells<5>(c, last); break;
-        case 6: launchCells<6>(c, last); break;
-        case 7: launchCells<7>(c, last); break;
-        case 8: launchCells<8>(c, last); break;
-        case 9: launchCells<9>(c, last); break;
-        default: launchCells<10>(c, last); break;
+        case 3: launchCells<3>(c, last, list, nList); break;
+        case 4: launchCells<4>(c, last, list, nList); break;
+        case 5: launchCells<5>(c, last, list, nList); break;
+        case 6: launchCells<6>(c, last, list, nList); break;
+        case 7: launchCells<7>(c, last, list, nList); break;
+        case 8: launchCells<8>(c, last, list, nList); break;
+        case 9: launchCells<9>(c, last, list, nList); break;
+        default: launchCells<10>(c, last, list, nList); break;
     }
 }
 
-static void launchVertexKernel(sih_ctx *c, bool last)
+static void launchVertexKernel(sih_ctx *c, bool last, int subset = -1)
 {
-    dim3 b(256), g = gridFor(c->cfg.computeHaloVertices ? c->nVertices : c->nVerticesSolve);
+    const int *list = subset >= 0 ? c->d_part[subset] : nullptr;
+    const int nList = subset >= 0 ? c->nPart[subset] : 0;
+    if (subset >= 0 && nList == 0) return;
+    dim3 b(256), g = gridFor(list ? nList : (c->cfg.computeHaloVertices ? c->nVertices : c->nVerticesSolve));
     if (last)
-        hipLaunchKernelGGL(k_sub_vertices<true>, g, b, 0, c->stream, c->dev);
+        hipLaunchKernelGGL(k_sub_vertices<true>, g, b, 0, c->stream, c->dev, list, nList);
     else
-        hipLaunchKernelGGL(k_sub_vertices<false>, g, b, 0, c->stream, c->dev);
+        hipLaunchKernelGGL(k_sub_vertices<false>, g, b, 0, c->stream, c->dev, list, nList);
 }
 
 extern "C" int sih_evp_subcycle(sih_ctx *c, int n, int last)
@@ -847,7 +865,7 @@ extern "C" int sih_evp_subcycle_graph(sih_ctx *c, int n)
     }
     if (!c->graphExec || c->graphN != n) {
         if (c->graphExec) {
-            hipGraphExecDestroy(c->graphExec);
+            (void)hipGraphExecDestroy(c->graphExec);
             c->graphExec = nullptr;
         }
         hipGraph_t graph;
@@ -865,6 +883,120 @@ extern "C" int sih_evp_subcycle_graph(sih_ctx *c, int n)
     return SIH_OK;
 }
 
+// ---------------------------------------------------------------------------- exchange overlap
+// Subsets of one block's entities, so that a host can start the halo exchange of a subcycle as soon as
+// the vertices its neighbours need are done and keep the GPU busy with everything that needs no halo
+// value until the message has arrived.  The subsets partition what the full kernels cover, and every
+// entity is computed once per subcycle from the same inputs, so results do not change by a bit.
+extern "C" int sih_evp_overlap_setup(sih_ctx *c)
+{
+    int rc = checkInit(c, "sih_evp_overlap_setup");
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    const int nC = c->nCells, nV = c->nVertices;
+    std::vector<int> active(nV, 0);
+    if (c->cfg.computeHaloVertices) {
+        SihField *f = sih_find_field(c, "_vertexActive");
+        if (!f) {
+            sih_set_error("sih_evp_overlap_setup: internal field missing");
+            return SIH_ERR_STATE;
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpy(active.data(), f->d, sizeof(int) * nV, hipMemcpyDeviceToHost));
+    } else {
+        for (int v = 0; v < c->nVerticesSolve; v++) active[v] = 1;
+    }
+    std::vector<char> sendV(nV, 0), recvV(nV, 0), recvC(nC, 0);
+    for (int v : c->hSend[1]) sendV[v] = 1;
+    for (int v : c->hRecv[1]) recvV[v] = 1;
+    for (int x : c->hRecv[0]) recvC[x] = 1;
+    std::vector<int> part[4];
+    for (int i = 0; i < nC; i++) {
+        bool rim = recvC[i];
+        for (int s = 0; s < c->hNe[i] && !rim; s++) {
+            int v = c->hVoc[(size_t)s * c->padC + i];
+            if (v < nV && recvV[v]) rim = true;
+        }
+        part[rim ? 1 : 0].push_back(i);
+    }
+    for (int v = 0; v < nV; v++)
+        if (active[v]) part[sendV[v] ? 2 : 3].push_back(v);
+    for (int k = 0; k < 4; k++) {
+        if (c->d_part[k]) {
+            HIPCHK(hipFree(c->d_part[k]));
+            c->d_part[k] = nullptr;
+        }
+        c->nPart[k] = (int)part[k].size();
+        if (!part[k].empty()) {
+            HIPCHK(hipMalloc((void **)&c->d_part[k], sizeof(int) * part[k].size()));
+            HIPCHK(hipMemcpy(c->d_part[k], part[k].data(), sizeof(int) * part[k].size(), hipMemcpyHostToDevice));
+        }
+    }
+    for (auto &kv : c->partGraphs) (void)hipGraphExecDestroy(kv.second);
+    c->partGraphs.clear();
+    c->partsReady = true;
+    return SIH_OK;
+}
+
+static int launchPart(sih_ctx *c, int part)
+{
+    switch (part) {
+        case SIH_PART_CELLS_ALL: launchCellKernel(c, false); break;
+        case SIH_PART_CELLS_INTERIOR: launchCellKernel(c, false, 0); break;
+        case SIH_PART_CELLS_RIM: launchCellKernel(c, false, 1); break;
+        case SIH_PART_VERTICES_ALL: launchVertexKernel(c, false); break;
+        case SIH_PART_VERTICES_SEND: launchVertexKernel(c, false, 2); break;
+        case SIH_PART_VERTICES_REST: launchVertexKernel(c, false, 3); break;
+        default: sih_set_error("sih_evp_subcycle_parts: unknown part"); return SIH_ERR_ARG;
+    }
+    return SIH_OK;
+}
+
+extern "C" int sih_evp_subcycle_parts(sih_ctx *c, int nParts, const int32_t *parts, int useGraph)
+{
+    int rc = checkInit(c, "sih_evp_subcycle_parts");
+    if (rc) return rc;
+    if (nParts < 0 || (nParts && !parts)) {
+        sih_set_error("sih_evp_subcycle_parts: bad argument");
+        return SIH_ERR_ARG;
+    }
+    bool needSets = false;
+    for (int k = 0; k < nParts; k++) {
+        if (parts[k] < 0 || parts[k] > SIH_PART_VERTICES_REST) {
+            sih_set_error("sih_evp_subcycle_parts: unknown part");
+            return SIH_ERR_ARG;
+        }
+        if (parts[k] != SIH_PART_CELLS_ALL && parts[k] != SIH_PART_VERTICES_ALL) needSets = true;
+    }
+    if (needSets && !c->partsReady) {
+        sih_set_error("sih_evp_subcycle_parts: call sih_evp_overlap_setup after sih_halo_set_lists first");
+        return SIH_ERR_STATE;
+    }
+    if (nParts == 0) return SIH_OK;
+    HIPCHK(hipSetDevice(c->device));
+    if (!useGraph || nParts < 2) {
+        for (int k = 0; k < nParts; k++)
+            if ((rc = launchPart(c, parts[k]))) return rc;
+        HIPCHK(hipGetLastError());
+        return SIH_OK;
+    }
+    std::vector<int> key(parts, parts + nParts);
+    key.push_back(c->sparseGrad ? 1 : 0);
+    auto it = c->partGraphs.find(key);
+    if (it == c->partGraphs.end()) {
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+        HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        for (int k = 0; k < nParts; k++) launchPart(c, parts[k]);
+        HIPCHK(hipStreamEndCapture(c->stream, &graph));
+        HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        HIPCHK(hipGraphDestroy(graph));
+        it = c->partGraphs.emplace(key, exec).first;
+    }
+    HIPCHK(hipGraphLaunch(it->second, c->stream));
+    return SIH_OK;
+}
+
 extern "C" int sih_evp_subcycle_timed(sih_ctx *c, int n, int useGraph, int sampleEvery, double *totalMs, double *cellMs,
                                       double *vertexMs)
 {
@@ -879,7 +1011,7 @@ extern "C" int sih_evp_subcycle_timed(sih_ctx *c, int n, int useGraph, int sampl
     if (useGraph) {
         if (!c->graphExec || c->graphN != n) {
             if (c->graphExec) {
-                hipGraphExecDestroy(c->graphExec);
+                (void)hipGraphExecDestroy(c->graphExec);
                 c->graphExec = nullptr;
             }
             hipGraph_t graph;

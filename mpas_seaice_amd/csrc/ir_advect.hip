@@ -91,11 +91,11 @@ struct sih_ir_state {
 void sih_ir_destroy(sih_ctx *c)
 {
     if (!c->ir) return;
-    if (c->ir->d_tab) hipFree(c->ir->d_tab);
-    if (c->ir->d_planes) hipFree(c->ir->d_planes);
-    if (c->ir->d_sums) hipFree(c->ir->d_sums);
+    if (c->ir->d_tab) (void)hipFree(c->ir->d_tab);
+    if (c->ir->d_planes) (void)hipFree(c->ir->d_planes);
+    if (c->ir->d_sums) (void)hipFree(c->ir->d_sums);
     for (hipEvent_t e : c->ir->ev)
-        if (e) hipEventDestroy(e);
+        if (e) (void)hipEventDestroy(e);
     delete c->ir;
     c->ir = nullptr;
 }
@@ -1441,7 +1441,7 @@ static int irRun(sih_ctx *c, double dt, int checkConservation, bool timed, doubl
                    gV = (d.nVertices + 255) / 256;
     hipStream_t s = c->stream;
     auto mark = [&](int i) {
-        if (timed) hipEventRecord(ir->ev[i], s);
+        if (timed) (void)hipEventRecord(ir->ev[i], s);
     };
     mark(0);
     hipLaunchKernelGGL(k_ir_zero_flags, dim3(1), dim3(64), 0, s, c->d_flag);

@@ -357,6 +357,8 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
                 cov[(size_t)k * c->padV + i] = (cc >= 1 && cc <= nC) ? c->cellInv[cc - 1] : nC;
             }
         }
+        c->hVoc = voc;
+        c->hNe = ne;
         HIPCHK(hipMemcpyAsync(c->fields["_nEdgesOnCell"].d, ne.data(), ne.size() * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->fields["_voc"].d, voc.data(), voc.size() * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->fields["_coc"].d, coc.data(), coc.size() * 4, hipMemcpyHostToDevice, c->stream));
@@ -383,28 +385,31 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
 extern "C" int sih_block_destroy(sih_ctx *c)
 {
     if (!c) return SIH_OK;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
-    if (c->graphExec) hipGraphExecDestroy(c->graphExec);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->graphExec) (void)hipGraphExecDestroy(c->graphExec);
     sih_ir_destroy(c);
-    for (hipEvent_t e : c->events) hipEventDestroy(e);
-    for (void *p : c->allocs) hipFree(p);
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    for (void *p : c->allocs) (void)hipFree(p);
     for (int k = 0; k < 2; k++) {
-        if (c->d_send[k]) hipFree(c->d_send[k]);
-        if (c->d_recv[k]) hipFree(c->d_recv[k]);
+        if (c->d_send[k]) (void)hipFree(c->d_send[k]);
+        if (c->d_recv[k]) (void)hipFree(c->d_recv[k]);
         for (int j = 0; j < 2; j++) {
-            if (c->d_segStart[k][j]) hipFree(c->d_segStart[k][j]);
-            if (c->d_segCnt[k][j]) hipFree(c->d_segCnt[k][j]);
+            if (c->d_segStart[k][j]) (void)hipFree(c->d_segStart[k][j]);
+            if (c->d_segCnt[k][j]) (void)hipFree(c->d_segCnt[k][j]);
         }
     }
-    if (c->d_stage) hipFree(c->d_stage);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    for (int k = 0; k < 4; k++)
+        if (c->d_part[k]) (void)hipFree(c->d_part[k]);
+    for (auto &kv : c->partGraphs) (void)hipGraphExecDestroy(kv.second);
     for (auto &kv : c->haloTables) {
-        if (kv.second.d_planes) hipFree(kv.second.d_planes);
+        if (kv.second.d_planes) (void)hipFree(kv.second.d_planes);
         for (int a = 0; a < 2; a++)
             for (int b = 0; b < 2; b++)
-                if (kv.second.d_base[a][b]) hipFree(kv.second.d_base[a][b]);
+                if (kv.second.d_base[a][b]) (void)hipFree(kv.second.d_base[a][b]);
     }
-    if (c->ownStream) hipStreamDestroy(c->ownStream);
+    if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
     return SIH_OK;
 }
@@ -415,10 +420,12 @@ extern "C" int sih_set_stream(sih_ctx *c, void *s)
     HIPCHK(hipStreamSynchronize(c->stream));
     c->stream = s ? (hipStream_t)s : c->ownStream;
     if (c->graphExec) {  // a captured graph is tied to nothing stream-specific, but rebuild to be safe
-        hipGraphExecDestroy(c->graphExec);
+        (void)hipGraphExecDestroy(c->graphExec);
         c->graphExec = nullptr;
         c->graphN = 0;
     }
+    for (auto &kv : c->partGraphs) (void)hipGraphExecDestroy(kv.second);
+    c->partGraphs.clear();
     return SIH_OK;
 }
 
@@ -631,12 +638,15 @@ extern "C" int sih_halo_set_lists(sih_ctx *c, int location, int nSend, const int
         c->hRecvCounts[location].assign(1, nRecv);
     }
     for (auto &kv : c->haloTables) {  // tables built for the previous lists are stale
-        if (kv.second.d_planes) hipFree(kv.second.d_planes);
+        if (kv.second.d_planes) (void)hipFree(kv.second.d_planes);
         for (int a = 0; a < 2; a++)
             for (int b = 0; b < 2; b++)
-                if (kv.second.d_base[a][b]) hipFree(kv.second.d_base[a][b]);
+                if (kv.second.d_base[a][b]) (void)hipFree(kv.second.d_base[a][b]);
     }
     c->haloTables.clear();
+    c->hSend[location] = s;
+    c->hRecv[location] = r;
+    c->partsReady = false;  // subsets derived from the previous lists are stale
     int rc;
     if ((rc = uploadInts(&c->d_send[location], s))) return rc;
     if ((rc = uploadInts(&c->d_recv[location], r))) return rc;

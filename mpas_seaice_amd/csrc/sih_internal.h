@@ -88,6 +88,15 @@ struct sih_ctx {
         int *d_base[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [location][send / recv]
     };
     std::vector<int> hSendCounts[2], hRecvCounts[2];  // per neighbour, as given to sih_halo_set_lists
+    std::vector<int> hSend[2], hRecv[2];              // the lists themselves, internal numbering
+    std::vector<int> hVoc, hNe;                       // verticesOnCell (SoA, padC stride) / nEdgesOnCell, internal
+    // entity subsets that let the halo exchange overlap with subcycle work (sih_evp_overlap_setup):
+    // [0] cells whose strain needs no halo value, [1] the other cells, [2] vertices a neighbour needs
+    // (send list), [3] the other vertices the vertex kernel updates
+    int *d_part[4] = {nullptr, nullptr, nullptr, nullptr};
+    int nPart[4] = {0, 0, 0, 0};
+    bool partsReady = false;
+    std::map<std::vector<int>, hipGraphExec_t> partGraphs;
     std::map<std::string, HaloTable> haloTables;  // plane-pointer tables of the field groups exchanged so far
     hipGraphExec_t graphExec = nullptr;
     int graphN = 0;

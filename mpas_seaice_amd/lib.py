@@ -69,7 +69,7 @@ EXPORTS = [
     "sih_evp_pre_subcycle", "sih_evp_subcycle", "sih_evp_post_subcycle", "sih_evp_run",
     "sih_evp_subcycle_timed", "sih_evp_subcycle_graph", "sih_halo_set_lists", "sih_halo_pack", "sih_halo_unpack", "sih_get_info",
     "sih_ir_init", "sih_ir_set_tracers", "sih_ir_run", "sih_ir_get_sums", "sih_ir_run_timed",
-    "sih_fields_put", "sih_fields_get",
+    "sih_fields_put", "sih_fields_get", "sih_evp_overlap_setup", "sih_evp_subcycle_parts",
 ]
 
 
@@ -109,6 +109,9 @@ def load():
     lib.sih_evp_subcycle.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     lib.sih_evp_post_subcycle.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.sih_evp_subcycle_graph.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.sih_evp_overlap_setup.argtypes = [ctypes.c_void_p]
+    lib.sih_evp_subcycle_parts.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int32),
+                                           ctypes.c_int]
     lib.sih_evp_run.argtypes = [ctypes.c_void_p]
     lib.sih_evp_subcycle_timed.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
@@ -247,6 +250,14 @@ class BlockContext:
 
     def subcycle_graph(self, n):
         check(self._lib.sih_evp_subcycle_graph(self.handle, int(n)), "sih_evp_subcycle_graph")
+
+    def overlap_setup(self):
+        check(self._lib.sih_evp_overlap_setup(self.handle), "sih_evp_overlap_setup")
+
+    def subcycle_parts(self, parts, use_graph=False):
+        arr = (ctypes.c_int32 * len(parts))(*parts)
+        check(self._lib.sih_evp_subcycle_parts(self.handle, len(parts), arr, int(bool(use_graph))),
+              "sih_evp_subcycle_parts")
 
     def post_subcycle(self, stage=-1):
         check(self._lib.sih_evp_post_subcycle(self.handle, stage), "sih_evp_post_subcycle")

@@ -131,6 +131,17 @@ class CommBase:
             tot += 1 if a.ndim == 1 else int(np.prod(a.shape[:-1]))
         return tot
 
+    def halo_exchange(self, domain, names):
+        for _ in self._steps(domain, names):
+            pass
+
+    def start_exchange(self, domain, names):
+        """Pack and start the transfer; work queued on the blocks' streams before ``finish()`` of the
+        returned object runs while the messages travel and must not touch the receive lists' entities."""
+        gen = self._steps(domain, names)
+        next(gen, None)
+        return _Pending(gen)
+
     def _torch_buf(self, key, n, is_int, device):
         import torch
         k = (key, is_int)
@@ -139,6 +150,19 @@ class CommBase:
             t = torch.empty(max(n, 1), dtype=torch.int32 if is_int else torch.float64, device=device)
             self._bufs[k] = t
         return t
+
+
+class _Pending:
+    """An exchange whose messages are packed and on their way; ``finish()`` waits for them and unpacks."""
+
+    def __init__(self, gen):
+        self._gen = gen
+
+    def finish(self):
+        if self._gen is not None:
+            for _ in self._gen:
+                pass
+            self._gen = None
 
 
 def _combined(names):
@@ -156,7 +180,7 @@ class LocalComm(CommBase):
     def allreduce_sum(self, a):
         return a
 
-    def _exchange_combined(self, domain, names):
+    def _steps_combined(self, domain, names):
         import torch
         g = _group(names)
         nsC, nsV = g[("cell", False)], g[("vertex", False)]
@@ -175,6 +199,7 @@ class LocalComm(CommBase):
             b.ctx.halo_pack(2, ordered, s.data_ptr())
             sends.append(s)
             recvs.append(r)
+        yield
         for b in domain.blocklist:
             b.ctx.sync()
         for i in range(self.nblocks):
@@ -187,10 +212,13 @@ class LocalComm(CommBase):
         for i, b in enumerate(domain.blocklist):
             b.ctx.halo_unpack(2, ordered, recvs[i].data_ptr())
 
-    def halo_exchange(self, domain, names):
+    def _steps(self, domain, names):
+        """Generator: everything up to the first ``yield`` packs, the rest transfers and unpacks."""
         if self.device and _combined(names):
-            return self._exchange_combined(domain, names)
-        for (loc, is_int), ns in _group(names).items():
+            yield from self._steps_combined(domain, names)
+            return
+        groups = list(_group(names).items())
+        for gi, ((loc, is_int), ns) in enumerate(groups):
             nf = self.n_planes(domain, ns)
             if self.device:
                 import torch
@@ -203,6 +231,8 @@ class LocalComm(CommBase):
                     b.ctx.halo_pack(LOC_ID[loc], ns, s.data_ptr())
                     sends.append(s)
                     recvs.append(r)
+                if gi == len(groups) - 1:
+                    yield
                 for b in domain.blocklist:
                     b.ctx.sync()
                 for i in range(self.nblocks):
@@ -240,6 +270,10 @@ class DistComm(CommBase):
         self.rank = rank
         self.dist = dist
         super().__init__(domain, [halo], nblocks)
+        if self.device and dist.get_backend() == "nccl":
+            # RCCL orders its transfers against torch's current stream: the block must work on it too
+            import torch
+            domain.blocklist[0].ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def allreduce_min(self, x):
         import torch
@@ -258,6 +292,7 @@ class DistComm(CommBase):
         return t.cpu().numpy()
 
     def _a2a(self, r, s, nr_tot, ns_tot, recv_split, send_split, b):
+        """Start the transfer; returns a callable that completes it (device buffers)."""
         import torch
         if self.dist.get_backend() == "gloo":
             # gloo moves host memory only: stage through the host with synchronous copies
@@ -265,12 +300,19 @@ class DistComm(CommBase):
             sh = s[:ns_tot].cpu()
             rh = torch.empty(nr_tot, dtype=sh.dtype)
             self.dist.all_to_all_single(rh, sh, recv_split, send_split)
-            r[:nr_tot].copy_(rh)
-            torch.cuda.synchronize()
-        else:
-            self.dist.all_to_all_single(r[:nr_tot], s[:ns_tot], recv_split, send_split)
 
-    def halo_exchange(self, domain, names):
+            def done():
+                r[:nr_tot].copy_(rh)
+                torch.cuda.synchronize()
+            return done
+        # RCCL runs the transfer on its own stream, ordered after what is queued on the current stream
+        # so far; wait() makes the current stream wait for it without blocking the host
+        work = self.dist.all_to_all_single(r[:nr_tot], s[:ns_tot], recv_split, send_split, async_op=True)
+        return work.wait
+
+    def _steps(self, domain, names):
+        """Generator: everything up to the first ``yield`` packs and starts the transfer, the rest
+        waits for it and unpacks."""
         import torch
         b = domain.blocklist[0]
         if self.device and _combined(names):
@@ -291,10 +333,13 @@ class DistComm(CommBase):
             s = self._torch_buf(("s2",), ns_tot, False, dev)
             r = self._torch_buf(("r2",), nr_tot, False, dev)
             b.ctx.halo_pack(2, ordered, s.data_ptr())
-            self._a2a(r, s, nr_tot, ns_tot, recv_split, send_split, b)
+            done = self._a2a(r, s, nr_tot, ns_tot, recv_split, send_split, b)
+            yield
+            done()
             b.ctx.halo_unpack(2, ordered, r.data_ptr())
             return
-        for (loc, is_int), ns in _group(names).items():
+        groups = list(_group(names).items())
+        for gi, ((loc, is_int), ns) in enumerate(groups):
             L = self.lists[0][loc]
             nf = self.n_planes(domain, ns)
             send_split = [c * nf for c in L.send_counts]
@@ -305,7 +350,10 @@ class DistComm(CommBase):
                 s = self._torch_buf(("s", loc), ns_tot, is_int, dev)
                 r = self._torch_buf(("r", loc), nr_tot, is_int, dev)
                 b.ctx.halo_pack(LOC_ID[loc], ns, s.data_ptr())
-                self._a2a(r, s, nr_tot, ns_tot, recv_split, send_split, b)
+                done = self._a2a(r, s, nr_tot, ns_tot, recv_split, send_split, b)
+                if gi == len(groups) - 1:
+                    yield
+                done()
                 b.ctx.halo_unpack(LOC_ID[loc], ns, r.data_ptr())
             else:
                 hf = HostFields(b)
@@ -372,8 +420,9 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
         dist.all_reduce(t, op=op)
         return float(t.item())
     rank, world = dist.get_rank(), dist.get_world_size()
+    overlap = os.environ.get("SIH_OVERLAP", "1") != "0"
     cfg = {"config_elastic_subcycle_number": nsub, "config_num_halos": max(2, interval),
-           "config_halo_exchange_interval": interval}
+           "config_halo_exchange_interval": interval, "config_overlap_halo_exchange": overlap}
     dom, halo, _ = make_partitioned_domain(mesh, name, world, configs=cfg, only_block=rank)
     vs.seaice_mesh_pool_create(dom, device=local_rank, renumber=renumber)
     ctx = dom.blocklist[0].ctx
@@ -392,6 +441,9 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
                                                                "stress12"]
 
     def step():
+        if overlap:
+            vs.subcycle_overlapped(dom, dom.comm, nsub, interval, names, use_graph=use_graph)
+            return
         done = 0
         while done < nsub:
             m = min(interval, nsub - done)
@@ -430,4 +482,4 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
     dist.barrier()
     dist.destroy_process_group()
     return {"wall": wall, "pre_ms": pre_ms, "post_ms": post_ms, "cell_ms": cell_ms, "vert_ms": vert_ms,
-            "n_cells_total": int(mesh.nCells), "n_block_cells": int(n_block_cells), "interval": interval}
+            "n_cells_total": int(mesh.nCells), "n_block_cells": int(n_block_cells), "interval": interval, "overlap": overlap}

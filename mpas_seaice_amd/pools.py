@@ -51,6 +51,10 @@ DEFAULT_CONFIGS = {
     # config_num_halos >= k halo layers; the solver then also updates halo vertices/cells redundantly and
     # exchanges uVelocity, vVelocity and stress11/22/12 every k subcycles (results identical to k = 1)
     "config_halo_exchange_interval": 1,
+    # not reference options: hide each of those exchanges behind the subcycle work that needs no halo value
+    # (same results), and replay the kernel sequences between exchanges from HIP graphs
+    "config_overlap_halo_exchange": False,
+    "config_subcycle_graph": False,
     "config_use_advection": True,
     "config_advection_type": "incremental_remap",
     "config_conservation_check": False,

@@ -149,6 +149,9 @@ def seaice_init_velocity_solver(domain):
         comm.halo_exchange(domain, ["interiorVertex"])
         for b in domain.blocklist:
             b.ctx.get("interiorVertex", b.structs["boundary"]["interiorVertex"])
+        if cfg["config_use_velocity_solver"] and cfg.get("config_overlap_halo_exchange", False):
+            for b in domain.blocklist:
+                b.ctx.overlap_setup()
 
 
 def _upload(domain, b):
@@ -198,6 +201,13 @@ def subcycle_velocity_solver(domain, clock=None):
         return
     k = int(domain.configs.get("config_halo_exchange_interval", 1))
     names = ["uVelocity", "vVelocity"] if k == 1 else ["uVelocity", "vVelocity", "stress11", "stress22", "stress12"]
+    if domain.configs.get("config_overlap_halo_exchange", False) and hasattr(comm, "start_exchange"):
+        subcycle_overlapped(domain, comm, n - 1, k, names,
+                            use_graph=bool(domain.configs.get("config_subcycle_graph", False)))
+        for b in domain.blocklist:
+            b.ctx.subcycle(1, last=True)
+        comm.halo_exchange(domain, names)
+        return
     done = 0
     while done < n:
         m = min(k, n - done)
@@ -205,6 +215,37 @@ def subcycle_velocity_solver(domain, clock=None):
             b.ctx.subcycle(m, last=(done + m == n))
         done += m
         comm.halo_exchange(domain, names)
+
+
+def subcycle_overlapped(domain, comm, n, k, names, use_graph=False):
+    """n iterations (none the last of the dynamics step), exchanging every k of them, with every
+    exchange hidden behind work that needs no halo value.
+
+    Around an exchange the iteration is cut into pieces (sih_evp_subcycle_parts): the vertices the
+    neighbours need are updated first and the messages start; while they travel the block finishes its
+    other vertices and runs the next iteration's strain/stress on the cells that touch no halo vertex;
+    after the wait and the unpack it completes that iteration on the remaining cells.  The reference
+    exchanges after every iteration with nothing overlapped (velocity_solver.F:2543-2584); the values
+    are the same."""
+    CA, CI, CR, VA, VS, VR = range(6)
+    blocks = domain.blocklist
+    pending, done = None, 0
+    while done < n:
+        m = min(k, n - done)
+        if pending is None:
+            parts = [CA, VA] * (m - 1) + [CA, VS]
+        else:
+            pending.finish()  # the first iteration of this chunk already has its interior cells
+            parts = [CR, VS] if m == 1 else [CR, VA] + [CA, VA] * (m - 2) + [CA, VS]
+        for b in blocks:
+            b.ctx.subcycle_parts(parts, use_graph)
+        pending = comm.start_exchange(domain, names)
+        done += m
+        more = done < n
+        for b in blocks:
+            b.ctx.subcycle_parts([VR, CI] if more else [VR], use_graph)
+    if pending is not None:
+        pending.finish()
 
 
 def velocity_solver_post_subcycle(domain):

@@ -31,6 +31,8 @@ def main():
     ora.set_num_threads(2)
     mesh = get_mesh(meshname)
     cfg = {"config_elastic_subcycle_number": 12, "config_dt": 7200.0}
+    if "overlap" in sys.argv[3:]:  # exchange hidden behind interior work; only the device path has it
+        cfg["config_overlap_halo_exchange"] = True
     ref = cases.make_domain(mesh, None, configs=cfg, open_water_band=(-0.2, 0.3))
     ora.seaice_init_velocity_solver(ref)
     ira.seaice_init_advection(ref)

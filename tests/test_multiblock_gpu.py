@@ -46,15 +46,66 @@ def test_blocks_on_one_gpu_match_single_block_oracle(oracle, nblocks, interval):
         assert err <= TOL, (name, err)
 
 
-def test_two_ranks_sharing_the_gpu_over_gloo():
+@pytest.mark.parametrize("extra", [[], ["overlap"]])
+def test_two_ranks_sharing_the_gpu_over_gloo(extra):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "tests", "dist_worker.py"), "gpu", "geo8"]
+           os.path.join(ROOT, "tests", "dist_worker.py"), "gpu", "geo8"] + extra
     env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.count(": ok") == 2, out.stdout
+
+
+@pytest.mark.parametrize("nblocks,interval,graph", [(2, 1, False), (4, 1, True), (3, 3, False), (4, 4, True)])
+def test_overlapped_exchange_is_bit_identical(nblocks, interval, graph):
+    """The exchange hidden behind interior work (send vertices first, interior cells of the next iteration
+    while the messages travel, rim cells after the unpack) must not change a bit."""
+    mesh = get_mesh("QU480")
+    res = []
+    for overlap in (False, True):
+        pcfg = {"config_elastic_subcycle_number": 25, "config_num_halos": max(2, interval),
+                "config_halo_exchange_interval": interval, "config_overlap_halo_exchange": overlap,
+                "config_subcycle_graph": graph}
+        dom, halos, _ = parallel.make_partitioned_domain(mesh, "QU480", nblocks, configs=pcfg,
+                                                         open_water_band=(-0.2, 0.3))
+        vs.seaice_mesh_pool_create(dom, device=0)
+        try:
+            dom.comm = parallel.LocalComm(dom, halos, nblocks)
+            vs.seaice_init_velocity_solver(dom)
+            vs.seaice_run_velocity_solver(dom)
+        finally:
+            vs.seaice_mesh_pool_destroy(dom)
+        res.append({(pool, name): parallel.gather_global(dom.blocklist, halos, pool, name, n, loc)
+                    for pool, name, loc, n in (("velocity_solver", "uVelocity", "vertex", mesh.nVertices),
+                                               ("velocity_solver", "vVelocity", "vertex", mesh.nVertices),
+                                               ("velocity_variational", "stress11", "cell", mesh.nCells),
+                                               ("velocity_variational", "stress22", "cell", mesh.nCells),
+                                               ("velocity_variational", "stress12", "cell", mesh.nCells),
+                                               ("velocity_solver", "shear", "cell", mesh.nCells))})
+    assert np.abs(res[0][("velocity_solver", "uVelocity")]).max() > 0
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+
+
+def test_subcycle_parts_error_paths():
+    from mpas_seaice_amd import lib as sihlib
+    dom = cases.make_domain(get_mesh("QU480"), "QU480")
+    vs.seaice_mesh_pool_create(dom)
+    try:
+        vs.seaice_init_velocity_solver(dom)
+        ctx = dom.blocklist[0].ctx
+        ctx.subcycle_parts([0, 3])  # whole-block pieces need no subsets
+        with pytest.raises(sihlib.SeaiceHipError):
+            ctx.subcycle_parts([1])  # subsets not set up
+        with pytest.raises(sihlib.SeaiceHipError):
+            ctx.subcycle_parts([9])
+        ctx.overlap_setup()  # no halo lists: everything is interior / rest
+        ctx.subcycle_parts([1, 2, 4, 5], True)
+        ctx.sync()
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
