@@ -39,6 +39,8 @@ module seaice_hip_interface
      integer(c_int32_t) :: calcVelocityMasks, useColumnPackage, nCategories
      real(c_double)     :: minEdgeLengthGlobal
      integer(c_int32_t) :: computeHaloVertices
+     integer(c_int32_t) :: averageVariationalStrain = 0
+     integer(c_int32_t) :: useSpecialBoundariesVelocity = 0, useSpecialBoundariesVelocityMasks = 0
   end type sih_evp_config
 
   !> struct sih_ir_desc
@@ -94,6 +96,32 @@ module seaice_hip_interface
        type(c_ptr), value :: ctx
        integer(c_int) :: ierr
      end function sih_evp_static_changed
+
+     ! arrays of the special_boundaries pool (c_loc; c_null_ptr for a part that is switched off)
+     function sih_evp_set_special_boundaries(ctx, vertexBoundaryType, vertexBoundarySourceLocal, &
+          solveVelocitySpecialBoundaries, solveStressSpecialBoundaries) &
+          bind(C, name="sih_evp_set_special_boundaries") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       type(c_ptr), value :: vertexBoundaryType, vertexBoundarySourceLocal
+       type(c_ptr), value :: solveVelocitySpecialBoundaries, solveStressSpecialBoundaries
+       integer(c_int) :: ierr
+     end function sih_evp_set_special_boundaries
+
+     function sih_evp_overlap_setup(ctx) bind(C, name="sih_evp_overlap_setup") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int) :: ierr
+     end function sih_evp_overlap_setup
+
+     function sih_evp_subcycle_parts(ctx, nParts, parts, useGraph) bind(C, name="sih_evp_subcycle_parts") result(ierr)
+       import :: c_int, c_ptr, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nParts
+       integer(c_int32_t), dimension(*), intent(in) :: parts
+       integer(c_int), value :: useGraph
+       integer(c_int) :: ierr
+     end function sih_evp_subcycle_parts
 
      function sih_field_put(ctx, name, host, count) bind(C, name="sih_field_put") result(ierr)
        import :: c_int, c_ptr, c_char, c_size_t

@@ -99,6 +99,9 @@ typedef struct sih_evp_config {
                                          vertex whose three cells are inside the block; the values equal the
                                          owner's bit for bit and let a block with H halo layers run H
                                          subcycles between exchanges of uVelocity, vVelocity and stress11/22/12 */
+    int32_t averageVariationalStrain; /* config_average_variational_strain (velocity_solver.F:2756-2766) */
+    int32_t useSpecialBoundariesVelocity;      /* config_use_special_boundaries_velocity */
+    int32_t useSpecialBoundariesVelocityMasks; /* config_use_special_boundaries_velocity_masks */
 } sih_evp_config;
 
 /* ---- life cycle ----------------------------------------------------------------------------- */
@@ -120,6 +123,18 @@ int sih_evp_init(sih_ctx *ctx, const sih_evp_config *cfg);
 /* re-pack the static basis after the host replaced basisGradient* / basisIntegrals* with its own
  * (e.g. the piecewise-linear basis computed by the host model) */
 int sih_evp_static_changed(sih_ctx *ctx);
+
+/* Special boundaries of idealised domains (special_boundaries.F:253-401): before the first and after
+ * every subcycle iteration uVelocity/vVelocity of the marked vertices are replaced by those of a source
+ * vertex (type 1 periodic: copy, 2 reverse: negated) or by zero (type 3), and solveVelocity / solveStress
+ * by the given masks.  Arrays in the reference layout (nVertices / nCells entries, sources 1-based local
+ * indices = vertexBoundarySourceLocal); the reference's loop is sequential and in place, and a source that
+ * is itself a boundary vertex is resolved the same way here.  A NULL pair leaves that part off; which
+ * parts are used is set by sih_evp_config.useSpecialBoundaries*.  Call after sih_evp_init. */
+int sih_evp_set_special_boundaries(sih_ctx *ctx, const int32_t *vertexBoundaryType,
+                                   const int32_t *vertexBoundarySourceLocal,
+                                   const int32_t *solveVelocitySpecialBoundaries,
+                                   const int32_t *solveStressSpecialBoundaries);
 
 /* ---- fields --------------------------------------------------------------------------------- */
 /* Copy a named field host -> device (put) or device -> host (get) in the reference layout.

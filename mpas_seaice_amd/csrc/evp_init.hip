@@ -459,6 +459,11 @@ extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
         sih_set_error("Unknown variational denominator type");
         return SIH_ERR_ARG;
     }
+    if (cfg->computeHaloVertices && (cfg->averageVariationalStrain || cfg->useSpecialBoundariesVelocity)) {
+        sih_set_error("computeHaloVertices: not together with strain averaging or special boundaries "
+                      "(their loops cover owned or source vertices only)");
+        return SIH_ERR_UNSUPPORTED;
+    }
     if (cfg->dynamicsSubcycleNumber < 1 || cfg->elasticSubcycleNumber < 1 || !(cfg->dt > 0.0) || cfg->nCategories < 1) {
         sih_set_error("sih_evp_init: dt, subcycle numbers and nCategories must be positive");
         return SIH_ERR_ARG;

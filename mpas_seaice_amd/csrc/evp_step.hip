@@ -341,7 +341,10 @@ __global__ void k_pre4_cells(SihDev d)
 // seaice_stress_divergence_variational (variational.F:1151-1170).  The latter are the per-(cell, corner)
 // partial sums stressDivergenceUCell / VCell; the vertex kernel adds the three of them in
 // cellsOnVertex order exactly as the reference loop does (:1172-1173), so no rounding changes.
-template <int M, bool SPARSE, bool LAST>
+// MODE 0: all of it in one pass.  With config_average_variational_strain the strains must pass through
+// memory and a vertex loop in between (seaice_average_strains_on_vertex): MODE 1 stops after storing the
+// strains, MODE 2 starts from the stored (averaged) strains.
+template <int M, bool SPARSE, bool LAST, int MODE>
 __global__ void __launch_bounds__(256) k_sub_cells(SihDev d, const int *__restrict__ list, int nList)
 {
     // list == nullptr: every cell; else the nList cells it names (ascending, so loads stay mostly coalesced)
@@ -354,7 +357,7 @@ __global__ void __launch_bounds__(256) k_sub_cells(SihDev d, const int *__restri
     }
     const int P = d.padC;
     if (d.solveStress[c] != 1) {
-        if (LAST && d.relation == 1) {
+        if (LAST && MODE != 1 && d.relation == 1) {
 #pragma unroll
             for (int s = 0; s < M; s++) d.Prep[(size_t)s * P + c] = 0.0;
         }
@@ -391,7 +394,12 @@ __global__ void __launch_bounds__(256) k_sub_cells(SihDev d, const int *__restri
         s12[g] = 0.0;
         if (g < E) {
             double e11 = 0.0, e22 = 0.0, e12 = 0.0;
-            if (SPARSE) {
+            const size_t k = (size_t)g * P + c;
+            if (MODE == 2) {
+                e11 = d.strain11[k];
+                e22 = d.strain22[k];
+                e12 = d.strain12[k];
+            } else if (SPARSE) {
                 // the three non-zero basis gradients of corner g, met in ascending basis-vertex order
                 double x0u, x1u, x2u, x0v, x1v, x2v;
                 const bool isLast = (g == E - 1);
@@ -432,14 +440,16 @@ __global__ void __launch_bounds__(256) k_sub_cells(SihDev d, const int *__restri
                     }
                 }
             }
-            e11 = e11 - v[g] * t[g];
-            e12 = e12 + u[g] * t[g] * 0.5;
-            const size_t k = (size_t)g * P + c;
-            if (LAST) {
+            if (MODE != 2) {
+                e11 = e11 - v[g] * t[g];
+                e12 = e12 + u[g] * t[g] * 0.5;
+            }
+            if ((LAST && MODE == 0) || MODE == 1) {
                 d.strain11[k] = e11;
                 d.strain22[k] = e22;
                 d.strain12[k] = e12;
             }
+            if (MODE == 1) continue;
             double a11, a22, a12;
             if (d.relation == 3) {
                 a11 = 1.0 * e11;
@@ -474,10 +484,11 @@ __global__ void __launch_bounds__(256) k_sub_cells(SihDev d, const int *__restri
             s11[g] = a11;
             s22[g] = a22;
             s12[g] = a12;
-        } else if (LAST && d.relation == 1) {
+        } else if (LAST && MODE != 1 && d.relation == 1) {
             d.Prep[(size_t)g * P + c] = 0.0;
         }
     }
+    if (MODE == 1) return;
     // per-corner partial sums of the stress divergence
 #pragma unroll
     for (int j = 0; j < M; j++) {
@@ -497,6 +508,80 @@ __global__ void __launch_bounds__(256) k_sub_cells(SihDev d, const int *__restri
             d.partV[(size_t)j * P + c] = cv;
         }
     }
+}
+
+// seaice_average_strains_on_vertex (variational.F:684-763): area-weighted mean of the (up to) three corner
+// strains that meet at a vertex, written back to those corners.  A (corner, cell) entry belongs to exactly
+// one vertex, so threads do not collide; sums run in cellsOnVertex order like the reference's.
+__global__ void __launch_bounds__(256) k_avg_strain_vertices(SihDev d)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= d.nVerticesSolve) return;
+    const int PV = d.padV;
+    double a11 = 0.0, a22 = 0.0, a12 = 0.0, den = 0.0;
+    int g[3];
+    bool ok[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int c = d.cov[k * PV + v];
+        ok[k] = c < d.nCells;
+        g[k] = d.gidx[k * PV + v];
+        if (ok[k]) {
+            const double area = d.areaCell[c];
+            a11 = a11 + d.strain11[g[k]] * area;
+            a22 = a22 + d.strain22[g[k]] * area;
+            a12 = a12 + d.strain12[g[k]] * area;
+            den = den + area;
+        }
+    }
+    a11 = a11 / den;
+    a22 = a22 / den;
+    a12 = a12 / den;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        if (ok[k]) {
+            d.strain11[g[k]] = a11;
+            d.strain22[g[k]] = a22;
+            d.strain12[g[k]] = a12;
+        }
+}
+
+// seaice_set_special_boundaries_velocity (special_boundaries.F:253-331) in two steps, so that every
+// marked vertex sees the value its (resolved) source had before the call
+__global__ void k_sb_gather(int n, const int *__restrict__ origin, const int *__restrict__ sign,
+                            const double *__restrict__ u, const double *__restrict__ v, double *__restrict__ tmp)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int sg = sign[i];
+    double uu = 0.0, vv = 0.0;
+    if (sg != 0) {
+        uu = u[origin[i]];
+        vv = v[origin[i]];
+        if (sg < 0) {
+            uu = -uu;
+            vv = -vv;
+        }
+    }
+    tmp[i] = uu;
+    tmp[n + i] = vv;
+}
+
+__global__ void k_sb_scatter(int n, const int *__restrict__ idx, const double *__restrict__ tmp, double *__restrict__ u,
+                             double *__restrict__ v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u[idx[i]] = tmp[i];
+    v[idx[i]] = tmp[n + i];
+}
+
+// seaice_set_special_boundaries_velocity_masks (special_boundaries.F:345-401)
+__global__ void k_sb_masks(SihDev d, const int *__restrict__ maskV, const int *__restrict__ maskC)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d.nVertices) d.solveVelocity[i] = maskV[i];
+    if (i < d.nCells) d.solveStress[i] = maskC[i];
 }
 
 // Fused vertex kernel: outer sum and division of seaice_stress_divergence_variational
@@ -742,25 +827,47 @@ extern "C" int sih_evp_pre_subcycle(sih_ctx *c, int stage)
         hipLaunchKernelGGL(k_pre4_vertices, gv, b, 0, s, d);
         hipLaunchKernelGGL(k_pre4_cells, gc, b, 0, s, d);
     }
+    if (stage == -1 || stage == 4) c->sbPending = c->sbVelocity || c->sbMasks;
     HIPCHK(hipGetLastError());
     return SIH_OK;
 }
 
 template <int M>
-static void launchCells(sih_ctx *c, bool last, const int *list, int nList)
+static void launchCells(sih_ctx *c, bool last, const int *list, int nList, int mode)
 {
     dim3 b(256), g = gridFor(list ? nList : c->nCells);
     const SihDev &d = c->dev;
-    if (c->sparseGrad) {
+    if (mode == 1) {
+        hipLaunchKernelGGL((k_sub_cells<M, false, false, 1>), g, b, 0, c->stream, d, list, nList);
+    } else if (mode == 2) {
         if (last)
-            hipLaunchKernelGGL((k_sub_cells<M, true, true>), g, b, 0, c->stream, d, list, nList);
+            hipLaunchKernelGGL((k_sub_cells<M, false, true, 2>), g, b, 0, c->stream, d, list, nList);
         else
-            hipLaunchKernelGGL((k_sub_cells<M, true, false>), g, b, 0, c->stream, d, list, nList);
+            hipLaunchKernelGGL((k_sub_cells<M, false, false, 2>), g, b, 0, c->stream, d, list, nList);
+    } else if (c->sparseGrad) {
+        if (last)
+            hipLaunchKernelGGL((k_sub_cells<M, true, true, 0>), g, b, 0, c->stream, d, list, nList);
+        else
+            hipLaunchKernelGGL((k_sub_cells<M, true, false, 0>), g, b, 0, c->stream, d, list, nList);
     } else {
         if (last)
-            hipLaunchKernelGGL((k_sub_cells<M, false, true>), g, b, 0, c->stream, d, list, nList);
+            hipLaunchKernelGGL((k_sub_cells<M, false, true, 0>), g, b, 0, c->stream, d, list, nList);
         else
-            hipLaunchKernelGGL((k_sub_cells<M, false, false>), g, b, 0, c->stream, d, list, nList);
+            hipLaunchKernelGGL((k_sub_cells<M, false, false, 0>), g, b, 0, c->stream, d, list, nList);
+    }
+}
+
+static void launchCellsM(sih_ctx *c, bool last, const int *list, int nList, int mode)
+{
+    switch (c->M) {
+        case 3: launchCells<3>(c, last, list, nList, mode); break;
+        case 4: launchCells<4>(c, last, list, nList, mode); break;
+        case 5: launchCells<5>(c, last, list, nList, mode); break;
+        case 6: launchCells<6>(c, last, list, nList, mode); break;
+        case 7: launchCells<7>(c, last, list, nList, mode); break;
+        case 8: launchCells<8>(c, last, list, nList, mode); break;
+        case 9: launchCells<9>(c, last, list, nList, mode); break;
+        default: launchCells<10>(c, last, list, nList, mode); break;
     }
 }
 
@@ -770,16 +877,33 @@ static void launchCellKernel(sih_ctx *c, bool last, int subset = -1)
     const int *list = subset >= 0 ? c->d_part[subset] : nullptr;
     const int nList = subset >= 0 ? c->nPart[subset] : 0;
     if (subset >= 0 && nList == 0) return;
-    switch (c->M) {
-        case 3: launchCells<3>(c, last, list, nList); break;
-        case 4: launchCells<4>(c, last, list, nList); break;
-        case 5: launchCells<5>(c, last, list, nList); break;
-        case 6: launchCells<6>(c, last, list, nList); break;
-        case 7: launchCells<7>(c, last, list, nList); break;
-        case 8: launchCells<8>(c, last, list, nList); break;
-        case 9: launchCells<9>(c, last, list, nList); break;
-        default: launchCells<10>(c, last, list, nList); break;
+    if (c->cfg.averageVariationalStrain) {  // whole block only (checked where subsets are set up)
+        launchCellsM(c, last, nullptr, 0, 1);
+        hipLaunchKernelGGL(k_avg_strain_vertices, gridFor(c->nVerticesSolve), dim3(256), 0, c->stream, c->dev);
+        launchCellsM(c, last, nullptr, 0, 2);
+        return;
     }
+    launchCellsM(c, last, list, nList, 0);
+}
+
+static void applySpecialBoundaryVelocity(sih_ctx *c)
+{
+    if (!c->sbVelocity || c->nSb == 0) return;
+    dim3 g = gridFor(c->nSb), b(256);
+    hipLaunchKernelGGL(k_sb_gather, g, b, 0, c->stream, c->nSb, c->d_sbOrigin, c->d_sbSign, c->dev.u, c->dev.v, c->d_sbTmp);
+    hipLaunchKernelGGL(k_sb_scatter, g, b, 0, c->stream, c->nSb, c->d_sbIdx, c->d_sbTmp, c->dev.u, c->dev.v);
+}
+
+// what subcycle_velocity_solver does before its loop (velocity_solver.F:2441-2443); the masks do not change
+// during the loop, so setting them once equals the reference's repetition after every iteration
+static void beginSubcycles(sih_ctx *c)
+{
+    if (!c->sbPending) return;
+    c->sbPending = false;
+    applySpecialBoundaryVelocity(c);
+    if (c->sbMasks)
+        hipLaunchKernelGGL(k_sb_masks, gridFor(std::max(c->nCells, c->nVertices)), dim3(256), 0, c->stream, c->dev,
+                           c->d_sbMaskV, c->d_sbMaskC);
 }
 
 static void launchVertexKernel(sih_ctx *c, bool last, int subset = -1)
@@ -792,6 +916,7 @@ static void launchVertexKernel(sih_ctx *c, bool last, int subset = -1)
         hipLaunchKernelGGL(k_sub_vertices<true>, g, b, 0, c->stream, c->dev, list, nList);
     else
         hipLaunchKernelGGL(k_sub_vertices<false>, g, b, 0, c->stream, c->dev, list, nList);
+    applySpecialBoundaryVelocity(c);  // velocity_solver.F:2454-2456
 }
 
 extern "C" int sih_evp_subcycle(sih_ctx *c, int n, int last)
@@ -802,6 +927,7 @@ extern "C" int sih_evp_subcycle(sih_ctx *c, int n, int last)
         sih_set_error("sih_evp_subcycle: n must be >= 0");
         return SIH_ERR_ARG;
     }
+    beginSubcycles(c);
     for (int it = 0; it < n; it++) {
         bool l = last && it == n - 1;
         launchCellKernel(c, l);
@@ -863,6 +989,7 @@ extern "C" int sih_evp_subcycle_graph(sih_ctx *c, int n)
         sih_set_error("sih_evp_subcycle_graph: n must be >= 1");
         return SIH_ERR_ARG;
     }
+    beginSubcycles(c);
     if (!c->graphExec || c->graphN != n) {
         if (c->graphExec) {
             (void)hipGraphExecDestroy(c->graphExec);
@@ -883,6 +1010,97 @@ extern "C" int sih_evp_subcycle_graph(sih_ctx *c, int n)
     return SIH_OK;
 }
 
+// ---------------------------------------------------------------------------- special boundaries
+static int uploadIntVec(int **dst, const std::vector<int> &v)
+{
+    if (*dst) {
+        HIPCHK(hipFree(*dst));
+        *dst = nullptr;
+    }
+    if (!v.empty()) {
+        HIPCHK(hipMalloc((void **)dst, sizeof(int) * v.size()));
+        HIPCHK(hipMemcpy(*dst, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice));
+    }
+    return SIH_OK;
+}
+
+extern "C" int sih_evp_set_special_boundaries(sih_ctx *c, const int32_t *type, const int32_t *source,
+                                              const int32_t *maskV, const int32_t *maskC)
+{
+    int rc = checkInit(c, "sih_evp_set_special_boundaries");
+    if (rc) return rc;
+    const bool wantVel = c->cfg.useSpecialBoundariesVelocity != 0, wantMask = c->cfg.useSpecialBoundariesVelocityMasks != 0;
+    if ((wantVel && (!type || !source)) || (wantMask && (!maskV || !maskC))) {
+        sih_set_error("sih_evp_set_special_boundaries: an array the configuration asks for is missing");
+        return SIH_ERR_ARG;
+    }
+    if (wantVel && c->partsReady) {
+        sih_set_error("sih_evp_set_special_boundaries: not together with the exchange-overlap subsets");
+        return SIH_ERR_UNSUPPORTED;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const int nV = c->nVertices, nC = c->nCells;
+    c->sbVelocity = false;
+    c->sbMasks = false;
+    if (wantVel) {
+        // the reference loop in its own (host) order, carried out on (sign, origin) pairs instead of values
+        std::vector<int> org(nV), sg(nV, 1);
+        for (int h = 0; h < nV; h++) org[h] = h;
+        std::vector<int> marked;
+        for (int h = 0; h < nV; h++) {
+            const int t = type[h];
+            if (t == 1 || t == 2) {
+                const int s = source[h];
+                if (s < 1 || s > nV) {
+                    sih_set_error("sih_evp_set_special_boundaries: vertexBoundarySourceLocal out of range");
+                    return SIH_ERR_ARG;
+                }
+                org[h] = org[s - 1];
+                sg[h] = (t == 1) ? sg[s - 1] : -sg[s - 1];
+                marked.push_back(h);
+            } else if (t == 3) {
+                sg[h] = 0;
+                marked.push_back(h);
+            } else if (t != 0) {
+                sih_set_error("sih_evp_set_special_boundaries: unknown vertexBoundaryType");
+                return SIH_ERR_ARG;
+            }
+        }
+        std::vector<int> idx, origin, sign;
+        for (int h : marked) {
+            idx.push_back(c->vertInv[h]);
+            origin.push_back(c->vertInv[org[h]]);
+            sign.push_back(sg[h]);
+        }
+        if ((rc = uploadIntVec(&c->d_sbIdx, idx))) return rc;
+        if ((rc = uploadIntVec(&c->d_sbOrigin, origin))) return rc;
+        if ((rc = uploadIntVec(&c->d_sbSign, sign))) return rc;
+        if (c->d_sbTmp) {
+            HIPCHK(hipFree(c->d_sbTmp));
+            c->d_sbTmp = nullptr;
+        }
+        c->nSb = (int)idx.size();
+        if (c->nSb) HIPCHK(hipMalloc((void **)&c->d_sbTmp, sizeof(double) * 2 * c->nSb));
+        c->sbVelocity = true;
+    }
+    if (wantMask) {
+        std::vector<int> mv(nV), mc(nC);
+        for (int i = 0; i < nV; i++) mv[i] = maskV[c->vertPerm[i]];
+        for (int i = 0; i < nC; i++) mc[i] = maskC[c->cellPerm[i]];
+        if ((rc = uploadIntVec(&c->d_sbMaskV, mv))) return rc;
+        if ((rc = uploadIntVec(&c->d_sbMaskC, mc))) return rc;
+        c->sbMasks = true;
+    }
+    // a captured graph would not hold the extra launches
+    if (c->graphExec) {
+        (void)hipGraphExecDestroy(c->graphExec);
+        c->graphExec = nullptr;
+        c->graphN = 0;
+    }
+    return SIH_OK;
+}
+
 // ---------------------------------------------------------------------------- exchange overlap
 // Subsets of one block's entities, so that a host can start the halo exchange of a subcycle as soon as
 // the vertices its neighbours need are done and keep the GPU busy with everything that needs no halo
@@ -892,6 +1110,10 @@ extern "C" int sih_evp_overlap_setup(sih_ctx *c)
 {
     int rc = checkInit(c, "sih_evp_overlap_setup");
     if (rc) return rc;
+    if (c->cfg.averageVariationalStrain || c->sbVelocity) {
+        sih_set_error("sih_evp_overlap_setup: strain averaging and special boundaries need whole-block loops");
+        return SIH_ERR_UNSUPPORTED;
+    }
     HIPCHK(hipSetDevice(c->device));
     const int nC = c->nCells, nV = c->nVertices;
     std::vector<int> active(nV, 0);
@@ -974,6 +1196,7 @@ extern "C" int sih_evp_subcycle_parts(sih_ctx *c, int nParts, const int32_t *par
     }
     if (nParts == 0) return SIH_OK;
     HIPCHK(hipSetDevice(c->device));
+    beginSubcycles(c);
     if (!useGraph || nParts < 2) {
         for (int k = 0; k < nParts; k++)
             if ((rc = launchPart(c, parts[k]))) return rc;
@@ -1008,6 +1231,7 @@ extern "C" int sih_evp_subcycle_timed(sih_ctx *c, int n, int useGraph, int sampl
     }
     if (cellMs) *cellMs = 0.0;
     if (vertexMs) *vertexMs = 0.0;
+    beginSubcycles(c);
     if (useGraph) {
         if (!c->graphExec || c->graphN != n) {
             if (c->graphExec) {

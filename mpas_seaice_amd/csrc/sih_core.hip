@@ -402,6 +402,9 @@ extern "C" int sih_block_destroy(sih_ctx *c)
     if (c->d_stage) (void)hipFree(c->d_stage);
     for (int k = 0; k < 4; k++)
         if (c->d_part[k]) (void)hipFree(c->d_part[k]);
+    for (void *p : {(void *)c->d_sbIdx, (void *)c->d_sbOrigin, (void *)c->d_sbSign, (void *)c->d_sbMaskV,
+                    (void *)c->d_sbMaskC, (void *)c->d_sbTmp})
+        if (p) (void)hipFree(p);
     for (auto &kv : c->partGraphs) (void)hipGraphExecDestroy(kv.second);
     for (auto &kv : c->haloTables) {
         if (kv.second.d_planes) (void)hipFree(kv.second.d_planes);

@@ -96,6 +96,12 @@ struct sih_ctx {
     int *d_part[4] = {nullptr, nullptr, nullptr, nullptr};
     int nPart[4] = {0, 0, 0, 0};
     bool partsReady = false;
+    // special boundaries (sih_evp_set_special_boundaries): marked vertices, where their value comes from
+    // (internal numbering) with sign +1 / -1 / 0, staging for the gather, replacement masks
+    int nSb = 0;
+    int *d_sbIdx = nullptr, *d_sbOrigin = nullptr, *d_sbSign = nullptr, *d_sbMaskV = nullptr, *d_sbMaskC = nullptr;
+    double *d_sbTmp = nullptr;
+    bool sbVelocity = false, sbMasks = false, sbPending = false;
     std::map<std::vector<int>, hipGraphExec_t> partGraphs;
     std::map<std::string, HaloTable> haloTables;  // plane-pointer tables of the field groups exchanged so far
     hipGraphExec_t graphExec = nullptr;

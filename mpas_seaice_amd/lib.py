@@ -49,7 +49,8 @@ class EvpConfig(ctypes.Structure):
         ("oceanStressType", ctypes.c_int32), ("surfaceTilt", ctypes.c_int32),
         ("calcVelocityMasks", ctypes.c_int32), ("useColumnPackage", ctypes.c_int32),
         ("nCategories", ctypes.c_int32), ("minEdgeLengthGlobal", ctypes.c_double),
-        ("computeHaloVertices", ctypes.c_int32),
+        ("computeHaloVertices", ctypes.c_int32), ("averageVariationalStrain", ctypes.c_int32),
+        ("useSpecialBoundariesVelocity", ctypes.c_int32), ("useSpecialBoundariesVelocityMasks", ctypes.c_int32),
     ]
 
 
@@ -70,6 +71,7 @@ EXPORTS = [
     "sih_evp_subcycle_timed", "sih_evp_subcycle_graph", "sih_halo_set_lists", "sih_halo_pack", "sih_halo_unpack", "sih_get_info",
     "sih_ir_init", "sih_ir_set_tracers", "sih_ir_run", "sih_ir_get_sums", "sih_ir_run_timed",
     "sih_fields_put", "sih_fields_get", "sih_evp_overlap_setup", "sih_evp_subcycle_parts",
+    "sih_evp_set_special_boundaries",
 ]
 
 
@@ -109,6 +111,7 @@ def load():
     lib.sih_evp_subcycle.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     lib.sih_evp_post_subcycle.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.sih_evp_subcycle_graph.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.sih_evp_set_special_boundaries.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4
     lib.sih_evp_overlap_setup.argtypes = [ctypes.c_void_p]
     lib.sih_evp_subcycle_parts.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int32),
                                            ctypes.c_int]
@@ -250,6 +253,15 @@ class BlockContext:
 
     def subcycle_graph(self, n):
         check(self._lib.sih_evp_subcycle_graph(self.handle, int(n)), "sih_evp_subcycle_graph")
+
+    def set_special_boundaries(self, vertexBoundaryType=None, vertexBoundarySourceLocal=None,
+                               solveVelocitySpecialBoundaries=None, solveStressSpecialBoundaries=None):
+        arrs = (vertexBoundaryType, vertexBoundarySourceLocal, solveVelocitySpecialBoundaries,
+                solveStressSpecialBoundaries)
+        for a in arrs:
+            assert a is None or (a.dtype == np.int32 and a.ndim == 1), "int32 vectors expected"
+        check(self._lib.sih_evp_set_special_boundaries(self.handle, *[_ptr(a) for a in arrs]),
+              "sih_evp_set_special_boundaries")
 
     def overlap_setup(self):
         check(self._lib.sih_evp_overlap_setup(self.handle), "sih_evp_overlap_setup")

@@ -136,6 +136,8 @@ def partition_mesh(mesh: Mesh, nblocks: int, num_halos: int = 2, cell_owner=None
             m["coeffs_reconstruct"] = np.asfortranarray(mesh["coeffs_reconstruct"][:, :, cells])
         for k in ("xEdge", "yEdge", "zEdge", "latEdge", "lonEdge", "dcEdge", "dvEdge", "fEdge"):
             m[k] = np.ascontiguousarray(mesh[k][edges])
+        m["indexToCellID"] = (cells + 1).astype(np.int32)
+        m["indexToVertexID"] = (verts + 1).astype(np.int32)
         meshes.append(m)
 
         h = BlockHalo()

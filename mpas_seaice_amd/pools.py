@@ -124,7 +124,16 @@ class Block:
         # mpas_seaice_advection_incremental_remap.F:744-746); supplied with the mesh here
         if "coeffs_reconstruct" in mesh:
             meshp["coeffs_reconstruct"] = pad1(np.asarray(mesh["coeffs_reconstruct"], dtype=np.float64), 0.0)
+        # global ids (mesh pool, Registry.xml indexToCellID / indexToVertexID); identity for an unpartitioned mesh
+        meshp["indexToCellID"] = pad1(np.asarray(mesh["indexToCellID"], dtype=np.int32) if "indexToCellID" in mesh
+                                      else np.arange(1, nC + 1, dtype=np.int32), 0)
+        meshp["indexToVertexID"] = pad1(np.asarray(mesh["indexToVertexID"], dtype=np.int32)
+                                        if "indexToVertexID" in mesh else np.arange(1, nV + 1, dtype=np.int32), 0)
         self.structs["mesh"] = meshp
+        # special_boundaries pool (mpas_seaice_special_boundaries.F:121-126, 382-383)
+        self.structs["special_boundaries"] = {
+            "vertexBoundaryType": iv(), "vertexBoundarySource": iv(), "vertexBoundarySourceLocal": iv(),
+            "solveVelocitySpecialBoundaries": iv(), "solveStressSpecialBoundaries": ic()}
 
         self.structs["boundary"] = {"interiorVertex": iv(), "interiorCell": ic(),
                                     "interiorEdge": np.zeros(nE + 1, dtype=np.int32)}

@@ -1,0 +1,45 @@
+"""Host mirror of the reference's special-boundaries module for the velocity solver
+(/root/reference/src/shared/mpas_seaice_special_boundaries.F).
+
+``seaice_init_special_boundaries`` turns the global source ids of the ``special_boundaries`` pool into
+local ones (init_special_boundaries_velocity, :84-155) and, for blocks that live on the device, hands
+the lists and replacement masks to the library, whose subcycle loop then applies them before the first
+and after every iteration (seaice_set_special_boundaries_velocity :253-331, ..._velocity_masks :345-401,
+called from mpas_seaice_velocity_solver.F:2441-2456).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+VELOCITY_BOUNDARY_NONE, VELOCITY_BOUNDARY_PERIODIC, VELOCITY_BOUNDARY_REVERSE, VELOCITY_BOUNDARY_ZERO = 0, 1, 2, 3
+
+
+def seaice_init_special_boundaries(domain):
+    cfg = domain.configs
+    use_vel = bool(cfg["config_use_special_boundaries_velocity"])
+    use_masks = bool(cfg["config_use_special_boundaries_velocity_masks"])
+    if use_vel and getattr(domain, "comm", None) is not None and any(
+            getattr(b, "ctx", None) is not None for b in domain.blocklist):
+        # the reference applies them after the halo update of every iteration; the library applies them right
+        # after its vertex loop, which is the same thing only when no halo update lies in between
+        from .lib import SeaiceHipError
+        raise SeaiceHipError("special velocity boundaries are implemented for single-block domains only")
+    for b in domain.blocklist:
+        sb = b.structs["special_boundaries"]
+        nV = b.dimensions["nVertices"]
+        if use_vel:
+            ids = b.structs["mesh"]["indexToVertexID"][:nV]
+            g2l = np.zeros(int(ids.max()) + 1, dtype=np.int64)
+            g2l[ids] = np.arange(1, nV + 1)
+            typ = sb["vertexBoundaryType"][:nV]
+            marked = typ != VELOCITY_BOUNDARY_NONE
+            src = sb["vertexBoundarySource"][:nV]
+            sb["vertexBoundarySourceLocal"][:nV][marked] = g2l[np.clip(src[marked], 0, g2l.size - 1)]
+        ctx = getattr(b, "ctx", None)
+        if ctx is not None and (use_vel or use_masks):
+            nC = b.dimensions["nCells"]
+            ctx.set_special_boundaries(
+                np.ascontiguousarray(sb["vertexBoundaryType"][:nV]) if use_vel else None,
+                np.ascontiguousarray(sb["vertexBoundarySourceLocal"][:nV]) if use_vel else None,
+                np.ascontiguousarray(sb["solveVelocitySpecialBoundaries"][:nV]) if use_masks else None,
+                np.ascontiguousarray(sb["solveStressSpecialBoundaries"][:nC]) if use_masks else None)

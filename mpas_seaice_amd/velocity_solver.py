@@ -70,8 +70,9 @@ def _evp_config(domain, block):
     c.constitutiveRelation = RELATION[rel]
     if cfg["config_strain_scheme"] != "variational" or cfg["config_stress_divergence_scheme"] != "variational":
         raise _lib.SeaiceHipError("only the variational strain / stress-divergence schemes are implemented")
-    if cfg["config_average_variational_strain"]:
-        raise _lib.SeaiceHipError("config_average_variational_strain is not implemented")
+    c.averageVariationalStrain = int(bool(cfg["config_average_variational_strain"]))
+    c.useSpecialBoundariesVelocity = int(bool(cfg["config_use_special_boundaries_velocity"]))
+    c.useSpecialBoundariesVelocityMasks = int(bool(cfg["config_use_special_boundaries_velocity_masks"]))
     basis = cfg["config_variational_basis"]
     if basis == "wachspress":
         if cfg["config_wachspress_integration_type"] != "dunavant":
@@ -145,6 +146,11 @@ def seaice_init_velocity_solver(domain):
             b.ctx.static_changed()
         for pool, name in STATIC_OUTPUTS:
             b.ctx.get(name, b.structs[pool][name])
+    if cfg["config_use_velocity_solver"]:
+        # seaice_init calls this before the solver's init (mpas_seaice_initialize.F:91); the device lists need
+        # the initialised context, so it runs here
+        from .special_boundaries import seaice_init_special_boundaries
+        seaice_init_special_boundaries(domain)
     if comm is not None:
         comm.halo_exchange(domain, ["interiorVertex"])
         for b in domain.blocklist:

@@ -88,6 +88,8 @@ def seaice_init_velocity_solver(domain):
     cfg = domain.configs
     st = domain.solver_state
     seaice_init_mesh_boundary(domain)
+    from mpas_seaice_amd.special_boundaries import seaice_init_special_boundaries
+    seaice_init_special_boundaries(domain)  # host-side index translation only (blocks have no device context)
     for b in domain.blocklist:
         vs = b.structs["velocity_solver"]
         vs["dynamicsTimeStep"][0] = cfg["config_dt"] / float(cfg["config_dynamics_subcycle_number"])
@@ -248,12 +250,37 @@ def _subcycle_args(domain, b):
             vs["stressDivergenceV"], vs["oceanStressCoeff"], float(vs["elasticTimeStep"][0]),
             float(vs["dynamicsTimeStep"][0]), float(st["dampingTimescale"]),
             float(st["numericalInertiaCoefficient"]), RELATION[cfg["config_constitutive_relation_type"]],
-            bool(cfg["config_use_ocean_stress"]), cfg["config_ocean_stress_type"] == "quadratic")
+            bool(cfg["config_use_ocean_stress"]), cfg["config_ocean_stress_type"] == "quadratic",
+            bool(cfg["config_average_variational_strain"]), m["areaCell"])
+
+
+def _set_special_boundaries(domain):
+    """seaice_set_special_boundaries_velocity / _velocity_masks, special_boundaries.F:253-401"""
+    cfg = domain.configs
+    for b in domain.blocklist:
+        sb, vs = b.structs["special_boundaries"], b.structs["velocity_solver"]
+        nV, nC = b.dimensions["nVertices"], b.dimensions["nCells"]
+        if cfg["config_use_special_boundaries_velocity"]:
+            call("ora_set_special_boundaries_velocity", nV, sb["vertexBoundaryType"], sb["vertexBoundarySourceLocal"],
+                 vs["uVelocity"], vs["vVelocity"])
+        if cfg["config_use_special_boundaries_velocity_masks"]:
+            vs["solveVelocity"][:nV] = sb["solveVelocitySpecialBoundaries"][:nV]
+            vs["solveStress"][:nC] = sb["solveStressSpecialBoundaries"][:nC]
 
 
 def subcycle_velocity_solver(domain, n_subcycles=None):
     cfg = domain.configs
     n = cfg["config_elastic_subcycle_number"] if n_subcycles is None else n_subcycles
+    if cfg["config_use_special_boundaries_velocity"] or cfg["config_use_special_boundaries_velocity_masks"]:
+        # velocity_solver.F:2441-2458: before the loop and after every iteration (after its halo update)
+        _set_special_boundaries(domain)
+        for _ in range(n):
+            for b in domain.blocklist:
+                call("ora_evp_subcycle_loop", 1, *_subcycle_args(domain, b))
+            if halo_needed(domain):
+                domain.halo(domain, "velocity_solver", ["uVelocity", "vVelocity"])
+            _set_special_boundaries(domain)
+        return
     if not halo_needed(domain):
         for b in domain.blocklist:
             call("ora_evp_subcycle_loop", n, *_subcycle_args(domain, b))

@@ -697,6 +697,62 @@ void ora_strain_tensor_variational(int nCells, int maxEdges, const int *nEdgesOn
     }
 }
 
+/* seaice_average_strains_on_vertex, variational.F:684-763 (serial in the reference).  Every (corner,
+ * cell) entry belongs to exactly one vertex, so the vertex loop can run in any order. */
+void ora_average_strains_on_vertex(int nCells, int nVerticesSolve, int vertexDegree, int maxEdges,
+                                   const int *cellsOnVertex, const int *cellVerticesAtVertex, const double *areaCell,
+                                   double *strain11, double *strain22, double *strain12)
+{
+    for (int v = 1; v <= nVerticesSolve; v++) {
+        double a11 = 0.0, a22 = 0.0, a12 = 0.0, den = 0.0;
+        for (int k = 1; k <= vertexDegree; k++) {
+            int c = cellsOnVertex[IX2(k, v, vertexDegree)];
+            if (c <= nCells) {
+                int j = cellVerticesAtVertex[IX2(k, v, vertexDegree)];
+                a11 = a11 + strain11[IX2(j, c, maxEdges)] * areaCell[c - 1];
+                a22 = a22 + strain22[IX2(j, c, maxEdges)] * areaCell[c - 1];
+                a12 = a12 + strain12[IX2(j, c, maxEdges)] * areaCell[c - 1];
+                den = den + areaCell[c - 1];
+            }
+        }
+        a11 = a11 / den;
+        a22 = a22 / den;
+        a12 = a12 / den;
+        for (int k = 1; k <= vertexDegree; k++) {
+            int c = cellsOnVertex[IX2(k, v, vertexDegree)];
+            if (c <= nCells) {
+                int j = cellVerticesAtVertex[IX2(k, v, vertexDegree)];
+                strain11[IX2(j, c, maxEdges)] = a11;
+                strain22[IX2(j, c, maxEdges)] = a22;
+                strain12[IX2(j, c, maxEdges)] = a12;
+            }
+        }
+    }
+}
+
+/* seaice_set_special_boundaries_velocity, special_boundaries.F:253-331: sequential and in place, so a
+ * source that is itself a boundary vertex with a lower index has already been replaced when it is read.
+ * Types: 0 none, 1 periodic, 2 reverse, 3 zero (special_boundaries.F:35-39). */
+void ora_set_special_boundaries_velocity(int nVertices, const int *vertexBoundaryType,
+                                         const int *vertexBoundarySourceLocal, double *uVelocity, double *vVelocity)
+{
+    for (int v = 1; v <= nVertices; v++) {
+        int t = vertexBoundaryType[v - 1];
+        if (t == 1) {
+            int s = vertexBoundarySourceLocal[v - 1];
+            uVelocity[v - 1] = uVelocity[s - 1];
+            vVelocity[v - 1] = vVelocity[s - 1];
+        } else if (t == 2) {
+            int s = vertexBoundarySourceLocal[v - 1];
+            uVelocity[v - 1] = -uVelocity[s - 1];
+            vVelocity[v - 1] = -vVelocity[s - 1];
+        } else if (t == 3) {
+            uVelocity[v - 1] = 0.0;
+            vVelocity[v - 1] = 0.0;
+        }
+    }
+}
+
 /* constitutive_relation.F:178-248 */
 static void evp_constitutive_relation(double *stress11, double *stress22, double *stress12, double strain11,
                                       double strain22, double strain12, double icePressure,
@@ -1038,12 +1094,15 @@ void ora_evp_subcycle_loop(int nSubcycles, int nCells, int nVerticesSolve, int n
                            double *stressDivergenceU, double *stressDivergenceV, double *oceanStressCoeff,
                            double elasticTimeStep, double dynamicsTimeStep, double dampingTimescale,
                            double numericalInertiaCoefficient, int relation, int useOceanStress,
-                           int quadraticOceanStress)
+                           int quadraticOceanStress, int averageVariationalStrains, const double *areaCell)
 {
     for (int it = 0; it < nSubcycles; it++) {
         ora_strain_tensor_variational(nCells, maxEdges, nEdgesOnCell, verticesOnCell, strain11, strain22, strain12,
                                       uVelocity, vVelocity, basisGradientU, basisGradientV,
                                       tanLatVertexRotatedOverRadius, solveStress);
+        if (averageVariationalStrains) /* velocity_solver.F:2756-2766 */
+            ora_average_strains_on_vertex(nCells, nVerticesSolve, vertexDegree, maxEdges, cellsOnVertex,
+                                          cellVerticesAtVertex, areaCell, strain11, strain22, strain12);
         ora_stress_tensor_variational(nCells, maxEdges, nEdgesOnCell, stress11, stress22, stress12, strain11,
                                       strain22, strain12, icePressure, replacementPressure, solveStress,
                                       elasticTimeStep, dampingTimescale, relation);

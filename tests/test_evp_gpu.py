@@ -107,3 +107,89 @@ def test_no_renumber_gives_same_answer(oracle):
             vs.seaice_mesh_pool_destroy(dom)
     # renumbering only permutes storage: results are bit-identical
     compare_domains(a, b, RUN_OUTPUTS, 0.0)
+
+
+def _run_both(oracle, mesh_name, configs, prepare=None, open_water_band=(-0.2, 0.3)):
+    mesh = get_mesh(mesh_name)
+    doms = []
+    for _ in range(2):
+        dom = cases.make_domain(mesh, mesh_name if mesh_name.startswith("QU") else None, configs=configs,
+                                open_water_band=open_water_band)
+        if prepare is not None:
+            prepare(dom)
+        doms.append(dom)
+    ref, dev = doms
+    oracle.seaice_init_velocity_solver(ref)
+    oracle.seaice_run_velocity_solver(ref)
+    vs.seaice_mesh_pool_create(dev)
+    try:
+        vs.seaice_init_velocity_solver(dev)
+        vs.seaice_run_velocity_solver(dev)
+    finally:
+        vs.seaice_mesh_pool_destroy(dev)
+    return ref, dev
+
+
+STATE = [("velocity_solver", "uVelocity"), ("velocity_solver", "vVelocity"),
+         ("velocity_variational", "stress11"), ("velocity_variational", "stress22"),
+         ("velocity_variational", "stress12"), ("velocity_variational", "strain11"),
+         ("velocity_variational", "strain22"), ("velocity_variational", "strain12"),
+         ("velocity_solver", "divergence"), ("velocity_solver", "shear"),
+         ("velocity_solver", "solveVelocity"), ("velocity_solver", "solveStress")]
+
+
+@pytest.mark.parametrize("mesh_name", ["QU480", "hex_24_20"])
+def test_average_variational_strain(oracle, mesh_name):
+    """config_average_variational_strain: strains pass through seaice_average_strains_on_vertex every
+    iteration (three launches for the cell part instead of one)."""
+    cfg = {"config_elastic_subcycle_number": 30, "config_average_variational_strain": True}
+    ref, dev = _run_both(oracle, mesh_name, cfg)
+    worst = compare_domains(dev, ref, STATE, 1e-10)
+    # and the option does something: the averaged solution differs from the default one
+    base = cases.make_domain(get_mesh(mesh_name), mesh_name if mesh_name.startswith("QU") else None,
+                             configs={"config_elastic_subcycle_number": 30}, open_water_band=(-0.2, 0.3))
+    oracle.seaice_init_velocity_solver(base)
+    oracle.seaice_run_velocity_solver(base)
+    du = np.abs(base.blocklist[0].structs["velocity_solver"]["uVelocity"]
+                - ref.blocklist[0].structs["velocity_solver"]["uVelocity"]).max()
+    assert du > 1e-8, du
+    assert worst <= 1e-10
+
+
+def _mark_special_boundaries(dom):
+    """rim vertices: zero; a strip of vertices copies / negates interior sources, including one source that
+    is itself a marked vertex with a lower index (the reference's in-place loop sees it already replaced)"""
+    b = dom.blocklist[0]
+    nV, nC = b.dimensions["nVertices"], b.dimensions["nCells"]
+    m, sb = b.structs["mesh"], b.structs["special_boundaries"]
+    cov = m["cellsOnVertex"][:, :nV]
+    rim = (cov > nC).any(axis=0)
+    typ, src = sb["vertexBoundaryType"], sb["vertexBoundarySource"]
+    typ[:nV][rim] = 3
+    inner = np.flatnonzero(~rim)
+    rng = np.random.default_rng(5)
+    pick = rng.choice(inner, size=60, replace=False)
+    for k, v in enumerate(pick[:40]):
+        typ[v] = 1 if k % 2 == 0 else 2
+        src[v] = int(inner[(k * 37 + 11) % inner.size]) + 1
+    lo, hi = sorted(pick[40:42])
+    typ[lo], src[lo] = 2, int(inner[5]) + 1
+    typ[hi], src[hi] = 1, int(lo) + 1     # chained: source already replaced
+    a, c = sorted(pick[42:44])
+    typ[a], src[a] = 1, int(c) + 1        # source marked but later in the loop: its old value is read
+    typ[c], src[c] = 2, int(inner[9]) + 1
+    mv, mc = sb["solveVelocitySpecialBoundaries"], sb["solveStressSpecialBoundaries"]
+    mv[:nV] = 1
+    mv[:nV][rim] = 0
+    mc[:nC] = 1
+    mc[:nC][::17] = 0
+
+
+def test_special_boundaries(oracle):
+    cfg = {"config_elastic_subcycle_number": 20, "config_use_special_boundaries_velocity": True,
+           "config_use_special_boundaries_velocity_masks": True}
+    ref, dev = _run_both(oracle, "hex_24_20", cfg, prepare=_mark_special_boundaries, open_water_band=None)
+    compare_domains(dev, ref, STATE, 1e-10)
+    u = ref.blocklist[0].structs["velocity_solver"]["uVelocity"]
+    typ = ref.blocklist[0].structs["special_boundaries"]["vertexBoundaryType"]
+    assert np.abs(u).max() > 0 and np.all(u[typ == 3] == 0.0)

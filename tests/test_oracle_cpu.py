@@ -126,3 +126,50 @@ def test_full_step_is_finite_and_deterministic(oracle):
         out.append(dom.blocklist[0].structs["velocity_solver"]["uVelocity"].copy())
     assert np.isfinite(out[0]).all() and np.abs(out[0]).max() > 1e-3
     assert np.array_equal(out[0], out[1])
+
+
+def test_average_strains_on_vertex_properties(oracle):
+    """seaice_average_strains_on_vertex (variational.F:684-763): a corner strain that is the same around a
+    vertex stays put; otherwise every corner at the vertex gets the area-weighted mean."""
+    mesh = get_mesh("hex_8_6")
+    dom = cases.make_domain(mesh, None)
+    oracle.seaice_init_velocity_solver(dom)
+    b = dom.blocklist[0]
+    d, m, vv = b.dimensions, b.structs["mesh"], b.structs["velocity_variational"]
+    nC, nV, M = d["nCells"], d["nVertices"], d["maxEdges"]
+    rng = np.random.default_rng(3)
+    s = [np.asfortranarray(rng.standard_normal((M, nC + 1))) for _ in range(3)]
+    s0 = [a.copy() for a in s]
+    oracle.call("ora_average_strains_on_vertex", nC, d["nVerticesSolve"], 3, M, m["cellsOnVertex"],
+                vv["cellVerticesAtVertex"], m["areaCell"], *s)
+    cov, cva, area = m["cellsOnVertex"], vv["cellVerticesAtVertex"], m["areaCell"]
+    for v in range(nV):
+        cs = [(cov[k, v] - 1, cva[k, v] - 1) for k in range(3) if cov[k, v] <= nC]
+        for a0, a1 in zip(s0, s):
+            mean = sum(a0[j, c] * area[c] for c, j in cs) / sum(area[c] for c, _ in cs)
+            for c, j in cs:
+                assert abs(a1[j, c] - mean) <= 1e-15 * max(1.0, abs(mean))
+    again = [a.copy(order="F") for a in s]
+    oracle.call("ora_average_strains_on_vertex", nC, d["nVerticesSolve"], 3, M, m["cellsOnVertex"],
+                vv["cellVerticesAtVertex"], m["areaCell"], *again)
+    for a1, a2 in zip(s, again):  # idempotent up to rounding of the mean of equal numbers
+        assert np.abs(a1 - a2).max() <= 4e-16 * np.abs(a1).max()
+
+
+def test_special_boundaries_velocity_is_the_sequential_in_place_loop(oracle):
+    """special_boundaries.F:301-324 restated in plain Python on random types and sources (chains included)"""
+    rng = np.random.default_rng(9)
+    n = 200
+    typ = rng.choice([0, 0, 1, 2, 3], size=n).astype(np.int32)
+    src = rng.integers(1, n + 1, size=n).astype(np.int32)
+    u, v = rng.standard_normal(n), rng.standard_normal(n)
+    eu, ev = u.copy(), v.copy()
+    for i in range(n):
+        if typ[i] == 1:
+            eu[i], ev[i] = eu[src[i] - 1], ev[src[i] - 1]
+        elif typ[i] == 2:
+            eu[i], ev[i] = -eu[src[i] - 1], -ev[src[i] - 1]
+        elif typ[i] == 3:
+            eu[i], ev[i] = 0.0, 0.0
+    oracle.call("ora_set_special_boundaries_velocity", n, typ, src, u, v)
+    assert np.array_equal(u, eu) and np.array_equal(v, ev)
