@@ -280,9 +280,20 @@ int sih_ir_set_tracers(sih_ctx *ctx, int nTracers, const char *const *names, con
  * thickness, incremental_remap_block with time step dt (uVelocity / vVelocity and the tracer fields are
  * read on the device; halos must be current), thickness -> volume.  Returns SIH_ERR_IR where the
  * reference aborts ("IR negative reconstructed ice area", "IR: Negative mass in IR", parallel basis
- * vectors).  checkConservation != 0 also evaluates sum_tracers (:7998) before and after the update. */
-int sih_ir_run(sih_ctx *ctx, double dt, int checkConservation);
-/* sum_tracers results of the last sih_ir_run(…, 1): nLayers*nCategories values each */
+ * vectors).  `checks` is a bit set: 1 (config_conservation_check) also evaluates sum_tracers (:7998)
+ * before and after the update; 2 (config_monotonicity_check) records the local minima and maxima of the
+ * old values (tracer_local_min_max :8268) in the fields <tracer>LocalMin / <tracer>LocalMax and leaves
+ * the thickness -> volume conversion to sih_ir_check_monotonicity, which must be called next. */
+enum { SIH_IR_CHECK_CONSERVATION = 1, SIH_IR_CHECK_MONOTONICITY = 2 };
+int sih_ir_run(sih_ctx *ctx, double dt, int checks);
+/* check_tracer_monotonicity (:8416-8749) after sih_ir_run(.., checks & 2): extends the local minima and
+ * maxima by one layer of neighbours exactly as the reference's in-place loop does, compares every new
+ * tracer value that had a meaningful old value against them (tolerance 1e-11 * max(1, |bound|)), then
+ * converts thickness back to volume.  A multi-block host exchanges the halos of the LocalMin / LocalMax
+ * fields of every tracer with a parent between the two calls (:8495-8496).  Returns SIH_ERR_IR with
+ * "IR advection, monotonicity violation" where the reference aborts. */
+int sih_ir_check_monotonicity(sih_ctx *ctx);
+/* sum_tracers results of the last sih_ir_run(.., checks & 1): nLayers*nCategories values each */
 int sih_ir_get_sums(sih_ctx *ctx, const char *tracer, double *initSums, double *finalSums);
 /* sih_ir_run bracketed by HIP events on the context's stream: total and per-phase durations in ms
  * (phases: 0 conversion+masks, 1 reconstruction, 2 departure triangles, 3 fluxes, 4 update+zap) */

@@ -27,6 +27,14 @@ def seaice_init_advection(domain):
     if getattr(domain, "comm", None) is not None and int(cfg.get("config_num_halos", 2)) < 2:
         raise SeaiceHipError("IR requires at least two halo layers (config_num_halos)")
     tracersHead = trc.seaice_add_tracers_to_linked_list(domain)
+    if cfg["config_monotonicity_check"]:
+        # the reference's tracer_monotonicity pool (incremental_remap_tracers.F:1045-1110)
+        for b in domain.blocklist:
+            pool = b.structs.setdefault("tracer_monotonicity", {})
+            for t in tracersHead:
+                shape = (t.nLayers, b.dimensions["nCategories"], b.dimensions["nCells"] + 1)
+                pool[t.tracerName + "LocalMin"] = np.zeros(shape, order="F")
+                pool[t.tracerName + "LocalMax"] = np.zeros(shape, order="F")
     for b in domain.blocklist:
         if getattr(b, "ctx", None) is None:
             raise SeaiceHipError("seaice_init_advection: seaice_mesh_pool_create must run first")
@@ -66,9 +74,10 @@ def seaice_run_advection(domain, updateHaloInit=True, updateHaloFinal=False, upl
         comm.halo_exchange(domain, ["uVelocity", "vVelocity"])
         comm.halo_exchange(domain, names)
     check = bool(cfg["config_conservation_check"])
+    mono = bool(cfg["config_monotonicity_check"])
     for b in domain.blocklist:
         dt = float(b.structs["velocity_solver"]["dynamicsTimeStep"][0])
-        b.ctx.ir_run(dt, check)
+        b.ctx.ir_run(dt, check, mono)
     if check:  # check_tracer_conservation, :8126-8253 (global sums over blocks and ranks)
         nCat = domain.blocklist[0].dimensions["nCategories"]
         for t in tracersHead:
@@ -85,8 +94,20 @@ def seaice_run_advection(domain, updateHaloInit=True, updateHaloFinal=False, upl
             if (np.abs(ratio) > 1.0e-11).any():
                 raise SeaiceHipError("IR: Tracer conservation error: tracer = " + t.tracerName)
             domain.solver_state.setdefault("ir_sums", {})[t.tracerName] = (init, fin)
-    if cfg["config_monotonicity_check"]:
-        raise SeaiceHipError("config_monotonicity_check is not implemented on the device")
+    if mono:  # check_tracer_monotonicity :8416-8749, outside the block loop because of its halo update
+        if comm is not None and cfg["config_use_halo_exch"]:
+            for t in tracersHead:
+                if t.parent is not None:
+                    comm.halo_exchange(domain, [t.tracerName + "LocalMin", t.tracerName + "LocalMax"])
+        try:
+            for b in domain.blocklist:
+                b.ctx.ir_check_monotonicity()
+        finally:
+            if download:  # the extended bounds, as the reference leaves them in its pool
+                for b in domain.blocklist:
+                    pool = b.structs["tracer_monotonicity"]
+                    b.ctx.get_many((n, pool[n]) for t in tracersHead if t.parent is not None
+                                   for n in (t.tracerName + "LocalMin", t.tracerName + "LocalMax"))
     if updateHaloFinal and comm is not None:
         comm.halo_exchange(domain, names)
     if download:

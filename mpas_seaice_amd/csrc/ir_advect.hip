@@ -43,6 +43,7 @@
 #define FLAG_PARALLEL 8
 #define FLAG_NEGAREA 16
 #define FLAG_NEGMASS 32
+#define FLAG_MONO 64
 
 struct IrDev {
     int nCells, nCellsSolve, nVertices, nEdges, M, nCat, padC, padV, padE, onSphere, rotate;
@@ -71,6 +72,10 @@ struct IrTracer {
     double *val = nullptr, *center = nullptr, *gx = nullptr, *gy = nullptr, *xB = nullptr, *yB = nullptr,
            *prod = nullptr, *flux = nullptr;
     std::vector<double> sumInit, sumFinal;
+    // monotonicity check: min / max of the old values in the neighbourhood, whether the old parent value
+    // exceeded 1e-11 (allocated on first use)
+    double *lmin = nullptr, *lmax = nullptr;
+    int *mask11 = nullptr;
 };
 
 struct sih_ir_state {
@@ -85,6 +90,8 @@ struct sih_ir_state {
     double *d_sums = nullptr;
     int iVol = -1, iSnow = -1;
     int cflWarnings = 0;
+    bool monoReady = false, monoPending = false;
+    double *monoTmp[4] = {nullptr, nullptr, nullptr, nullptr};  // ping-pong buffers of the extension sweeps
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -463,6 +470,79 @@ __global__ void k_ir_mask_cell(IrDev d, const double *mass)
     double s = 0.0;
     for (int cat = 0; cat < d.nCat; cat++) s = s + mass[(size_t)cat * d.padC + c];
     d.maskCell[c] = s > 0.0 ? 1 : 0;
+}
+
+// ---- monotonicity check (optional diagnostic) ----------------------------------------------------
+// tracer_local_min_max :8268-8392 with the masks of make_masks(threshold 0) :2999-3021, and the mask of
+// make_masks(threshold 1e-11) :3023-3029 kept for the check after the update.  Thread (cell, plane).
+__global__ void k_ir_mono_init(IrDev d, const double *__restrict__ val, const double *__restrict__ parentVal, int L,
+                               int Lp, double *__restrict__ lmin, double *__restrict__ lmax, int *__restrict__ mask11)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nCells) return;
+    const int p = blockIdx.y, cat = p / L, layer = p % L;
+    const size_t pc = d.padC, k = (size_t)p * pc + c;
+    const size_t kp = (size_t)(Lp == 1 ? cat : cat * Lp + layer) * pc;
+    const double pv = parentVal[kp + c];
+    mask11[k] = pv > EPS11 ? 1 : 0;
+    double lo = 0.0, hi = 0.0;
+    if (c < d.nCellsSolve) {
+        if (pv > 0.0) lo = hi = val[k];
+        const int n = d.nEdgesOnCell[c];
+        for (int ie = 0; ie < n; ie++) {
+            const int nb = d.coc[(size_t)ie * pc + c];
+            if (nb < d.nCells && parentVal[kp + nb] > 0.0) {
+                const double x = val[(size_t)p * pc + nb];
+                if (x < lo) lo = x;
+                if (x > hi) hi = x;
+            }
+        }
+    }
+    lmin[k] = lo;
+    lmax[k] = hi;
+}
+
+// One sweep of the extension by a layer of neighbours (check_tracer_monotonicity :8506-8535).  The
+// reference extends in place with cells in ascending (host) order, so a neighbour with a lower index
+// contributes its extended value, one with a higher index (or a halo cell) its original one.  Sweeps are
+// repeated until nothing changes, which reproduces that order exactly.
+__global__ void k_ir_mono_extend(IrDev d, const int *__restrict__ hostIndex, const int *__restrict__ mask11,
+                                 const double *__restrict__ lmin0, const double *__restrict__ lmax0,
+                                 const double *__restrict__ inMin, const double *__restrict__ inMax,
+                                 double *__restrict__ outMin, double *__restrict__ outMax, int *changed)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nCells) return;
+    const size_t pc = d.padC, base = (size_t)blockIdx.y * pc, k = base + c;
+    double lo = lmin0[k], hi = lmax0[k];
+    if (c < d.nCellsSolve && mask11[k] == 1) {
+        const int hc = hostIndex[c], n = d.nEdgesOnCell[c];
+        for (int ie = 0; ie < n; ie++) {
+            const int nb = d.coc[(size_t)ie * pc + c];
+            if (nb < d.nCells && mask11[base + nb] == 1) {
+                const bool earlier = nb < d.nCellsSolve && hostIndex[nb] < hc;
+                const double a = earlier ? inMin[base + nb] : lmin0[base + nb];
+                const double b = earlier ? inMax[base + nb] : lmax0[base + nb];
+                if (a < lo) lo = a;
+                if (b > hi) hi = b;
+            }
+        }
+    }
+    if (lo != inMin[k] || hi != inMax[k]) *changed = 1;
+    outMin[k] = lo;
+    outMax[k] = hi;
+}
+
+// the comparison itself :8552-8601 / :8682-8736
+__global__ void k_ir_mono_check(IrDev d, const double *__restrict__ val, const int *__restrict__ mask11,
+                                const double *__restrict__ emin, const double *__restrict__ emax)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nCellsSolve) return;
+    const size_t k = (size_t)blockIdx.y * d.padC + c;
+    if (mask11[k] != 1) return;
+    const double tolMin = EPS11 * fmax(1.0, fabs(emin[k])), tolMax = EPS11 * fmax(1.0, fabs(emax[k]));
+    if (val[k] < emin[k] - tolMin || val[k] > emax[k] + tolMax) atomicOr(d.flag, FLAG_MONO);
 }
 
 // All tracers of one (cell, category): compute_gradient :4204/:4429, limit_tracer_gradient :4802/:4999,
@@ -1063,6 +1143,11 @@ __global__ void k_ir_zero_flags(int *p)
     if (threadIdx.x < 16) p[threadIdx.x] = 0;
 }
 
+__global__ void k_ir_zero_one(int *p)
+{
+    if (threadIdx.x == 0) *p = 0;
+}
+
 // ------------------------------------------------------------------------------------------ host side
 static int uploadPlaneInts(sih_ctx *c, int *dst, const std::vector<int> &v)
 {
@@ -1426,12 +1511,58 @@ static int irSums(sih_ctx *c, bool init)
     return SIH_OK;
 }
 
-static int irRun(sih_ctx *c, double dt, int checkConservation, bool timed, double *totalMs, double *phaseMs)
+// fields of the monotonicity check, created when it is first asked for: <tracer>LocalMin / LocalMax (the
+// reference's tracer_monotonicity pool; a multi-block host exchanges their halos between sih_ir_run and
+// sih_ir_check_monotonicity), the 1e-11 mask of the old values, and the sweep buffers
+static int monoSetup(sih_ctx *c)
+{
+    sih_ir_state *ir = c->ir;
+    if (ir->monoReady) return SIH_OK;
+    int rc, maxLead = 0;
+    for (IrTracer &t : ir->tracers) {
+        if (t.parent < 0) continue;
+        const int lead = t.L * ir->nCat;
+        maxLead = std::max(maxLead, lead);
+        const std::string a = t.name + "LocalMin", b = t.name + "LocalMax", m = "_" + t.name + "Mask11";
+        if ((rc = sih_add_field(c, a.c_str(), LOC_CELL, lead, false))) return rc;
+        if ((rc = sih_add_field(c, b.c_str(), LOC_CELL, lead, false))) return rc;
+        if ((rc = sih_add_field(c, m.c_str(), LOC_CELL, lead, true))) return rc;
+        t.lmin = (double *)sih_find_field(c, a.c_str())->d;
+        t.lmax = (double *)sih_find_field(c, b.c_str())->d;
+        t.mask11 = (int *)sih_find_field(c, m.c_str())->d;
+    }
+    for (int k = 0; k < 4 && maxLead > 0; k++) {
+        const std::string n = "_monoSweep" + std::to_string(k);
+        if ((rc = sih_add_field(c, n.c_str(), LOC_CELL, maxLead, false))) return rc;
+        ir->monoTmp[k] = (double *)sih_find_field(c, n.c_str())->d;
+    }
+    ir->monoReady = true;
+    return SIH_OK;
+}
+
+// thickness -> volume :2608-2650
+static void irToVolume(sih_ctx *c)
+{
+    sih_ir_state *ir = c->ir;
+    const IrDev &d = ir->d;
+    for (int i : {ir->iVol, ir->iSnow})
+        if (i >= 0)
+            hipLaunchKernelGGL(k_ir_convert, dim3((d.nCells + 255) / 256, d.nCat), dim3(256), 0, c->stream, d,
+                               ir->tracers[0].val, ir->tracers[i].val, 0);
+}
+
+static int irRun(sih_ctx *c, double dt, int checks, bool timed, double *totalMs, double *phaseMs)
 {
     if (!c || !c->ir || !c->ir->inited || c->ir->tracers.empty()) {
         sih_set_error("sih_ir_run: call sih_ir_init and sih_ir_set_tracers first");
         return SIH_ERR_STATE;
     }
+    if (c->ir->monoPending) {
+        sih_set_error("sih_ir_run: the previous step asked for the monotonicity check; call sih_ir_check_monotonicity");
+        return SIH_ERR_STATE;
+    }
+    const int checkConservation = checks & 1;
+    const bool monotonicity = (checks & 2) != 0;
     HIPCHK(hipSetDevice(c->device));
     sih_ir_state *ir = c->ir;
     IrDev &d = ir->d;
@@ -1450,6 +1581,14 @@ static int irRun(sih_ctx *c, double dt, int checkConservation, bool timed, doubl
     for (int i : {ir->iVol, ir->iSnow})
         if (i >= 0)
             hipLaunchKernelGGL(k_ir_convert, dim3(gC, d.nCat), blk, 0, s, d, area, ir->tracers[i].val, 1);
+    if (monotonicity) {
+        int rcm = monoSetup(c);
+        if (rcm) return rcm;
+        for (IrTracer &t : ir->tracers)
+            if (t.parent >= 0)
+                hipLaunchKernelGGL(k_ir_mono_init, dim3(gC, t.L * d.nCat), blk, 0, s, d, t.val,
+                                   ir->tracers[t.parent].val, t.L, ir->tracers[t.parent].L, t.lmin, t.lmax, t.mask11);
+    }
     hipLaunchKernelGGL(k_ir_mask_cell, dim3(gC), blk, 0, s, d, area);
     mark(1);
     // construct_linear_tracer_fields :3580-4189, compute_mass_tracer_products :6982
@@ -1469,10 +1608,9 @@ static int irRun(sih_ctx *c, double dt, int checkConservation, bool timed, doubl
     launchCells(ir, s, true);
     if (checkConservation && (rc = irSums(c, false))) return rc;
     hipLaunchKernelGGL(k_ir_zap, dim3(gCs, d.nCat), blk, 0, s, d, ir->d_tab, nT);
-    // thickness -> volume :2608-2650
-    for (int i : {ir->iVol, ir->iSnow})
-        if (i >= 0)
-            hipLaunchKernelGGL(k_ir_convert, dim3(gC, d.nCat), blk, 0, s, d, area, ir->tracers[i].val, 0);
+    // thickness -> volume :2608-2650 (after the monotonicity check, which compares thicknesses)
+    ir->monoPending = monotonicity;
+    if (!monotonicity) irToVolume(c);
     mark(5);
     HIPCHK(hipGetLastError());
     int flags[2] = {0, 0};
@@ -1503,9 +1641,71 @@ static int irRun(sih_ctx *c, double dt, int checkConservation, bool timed, doubl
     return SIH_OK;
 }
 
-extern "C" int sih_ir_run(sih_ctx *c, double dt, int checkConservation)
+extern "C" int sih_ir_run(sih_ctx *c, double dt, int checks)
 {
-    return irRun(c, dt, checkConservation, false, nullptr, nullptr);
+    return irRun(c, dt, checks, false, nullptr, nullptr);
+}
+
+// check_tracer_monotonicity :8416-8749 and the thickness -> volume conversion that follows it
+extern "C" int sih_ir_check_monotonicity(sih_ctx *c)
+{
+    if (!c || !c->ir || !c->ir->monoPending) {
+        sih_set_error("sih_ir_check_monotonicity: no step with the monotonicity check is pending");
+        return SIH_ERR_STATE;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    sih_ir_state *ir = c->ir;
+    const IrDev &d = ir->d;
+    hipStream_t s = c->stream;
+    const dim3 blk(256);
+    const unsigned gC = (d.nCells + 255) / 256, gCs = (d.nCellsSolve + 255) / 256;
+    hipLaunchKernelGGL(k_ir_zero_flags, dim3(1), dim3(64), 0, s, c->d_flag);
+    std::string failed;
+    for (IrTracer &t : ir->tracers) {
+        if (t.parent < 0) continue;  // monotonicity holds for tracers, not for the mass-like field
+        const int lead = t.L * d.nCat;
+        const size_t bytes = sizeof(double) * (size_t)lead * d.padC;
+        // sweep 0 reads the unextended values
+        HIPCHK(hipMemcpyAsync(ir->monoTmp[0], t.lmin, bytes, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(ir->monoTmp[1], t.lmax, bytes, hipMemcpyDeviceToDevice, s));
+        int cur = 0, sweeps = 0;
+        for (;;) {
+            double *inMin = ir->monoTmp[2 * cur], *inMax = ir->monoTmp[2 * cur + 1];
+            double *outMin = ir->monoTmp[2 * (1 - cur)], *outMax = ir->monoTmp[2 * (1 - cur) + 1];
+            hipLaunchKernelGGL(k_ir_zero_one, dim3(1), dim3(64), 0, s, c->d_flag + 2);
+            hipLaunchKernelGGL(k_ir_mono_extend, dim3(gC, lead), blk, 0, s, d, c->d_cellPerm, t.mask11, t.lmin, t.lmax,
+                               inMin, inMax, outMin, outMax, c->d_flag + 2);
+            int changed = 0;
+            HIPCHK(hipMemcpyAsync(&changed, c->d_flag + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            cur = 1 - cur;
+            if (!changed) break;
+            if (++sweeps > d.nCells + 1) {  // cannot happen: every sweep settles at least the next cell in order
+                sih_set_error("sih_ir_check_monotonicity: extension did not settle");
+                return SIH_ERR_IR;
+            }
+        }
+        // the extended values replace the fields, as the reference's in-place loop leaves them
+        HIPCHK(hipMemcpyAsync(t.lmin, ir->monoTmp[2 * cur], bytes, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(t.lmax, ir->monoTmp[2 * cur + 1], bytes, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_ir_mono_check, dim3(gCs, lead), blk, 0, s, d, t.val, t.mask11, t.lmin, t.lmax);
+        int flag = 0;
+        HIPCHK(hipMemcpyAsync(&flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (flag & FLAG_MONO) {
+            failed = t.name;
+            break;  // the reference returns at the first violation
+        }
+    }
+    irToVolume(c);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    ir->monoPending = false;
+    if (!failed.empty()) {
+        sih_set_error("IR advection, monotonicity violation: tracer = " + failed);
+        return SIH_ERR_IR;
+    }
+    return SIH_OK;
 }
 
 extern "C" int sih_ir_run_timed(sih_ctx *c, double dt, double *totalMs, double *phaseMs5)

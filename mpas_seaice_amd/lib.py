@@ -71,7 +71,7 @@ EXPORTS = [
     "sih_evp_subcycle_timed", "sih_evp_subcycle_graph", "sih_halo_set_lists", "sih_halo_pack", "sih_halo_unpack", "sih_get_info",
     "sih_ir_init", "sih_ir_set_tracers", "sih_ir_run", "sih_ir_get_sums", "sih_ir_run_timed",
     "sih_fields_put", "sih_fields_get", "sih_evp_overlap_setup", "sih_evp_subcycle_parts",
-    "sih_evp_set_special_boundaries",
+    "sih_evp_set_special_boundaries", "sih_ir_check_monotonicity",
 ]
 
 
@@ -130,6 +130,7 @@ def load():
     lib.sih_ir_set_tracers.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
                                        ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
     lib.sih_ir_run.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int]
+    lib.sih_ir_check_monotonicity.argtypes = [ctypes.c_void_p]
     lib.sih_ir_get_sums.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.sih_ir_run_timed.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
                                      ctypes.c_void_p]
@@ -342,8 +343,12 @@ class BlockContext:
         check(self._lib.sih_ir_set_tracers(self.handle, len(names), self._names(names), self._names(parents),
                                            _ptr(nl)), "sih_ir_set_tracers")
 
-    def ir_run(self, dt, check_conservation=False):
-        check(self._lib.sih_ir_run(self.handle, float(dt), int(bool(check_conservation))), "sih_ir_run")
+    def ir_run(self, dt, check_conservation=False, check_monotonicity=False):
+        checks = (1 if check_conservation else 0) | (2 if check_monotonicity else 0)
+        check(self._lib.sih_ir_run(self.handle, float(dt), checks), "sih_ir_run")
+
+    def ir_check_monotonicity(self):
+        check(self._lib.sih_ir_check_monotonicity(self.handle), "sih_ir_check_monotonicity")
 
     def ir_get_sums(self, name, n):
         a = np.zeros(n)

@@ -42,6 +42,8 @@ def field_loc(name):
 
 
 def field_pool(name):
+    if name.endswith("LocalMin") or name.endswith("LocalMax"):
+        return "tracer_monotonicity"  # bounds of the advection's monotonicity check, one pair per tracer
     return FIELD_POOL.get(name, "tracers")
 
 

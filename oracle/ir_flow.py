@@ -131,10 +131,30 @@ def seaice_run_advection(domain, updateHaloInit=True, updateHaloFinal=False, dia
             ratio = np.where(big, (fin - init) / np.where(big, init, 1.0), 0.0)
             if (np.abs(ratio) > 1.0e-11).any():
                 raise IRError("IR: Tracer conservation error: tracer = " + t.tracerName)
+    if domain.configs["config_monotonicity_check"]:
+        check_tracer_monotonicity(domain, tracersHead)
     for b in domain.blocklist:
         _convert(b, tracersHead, "ira_thickness_to_volume")
     if updateHaloFinal and halo is not None:
         halo(domain, "tracers", [t.tracerName for t in tracersHead])
+
+
+def check_tracer_monotonicity(domain, tracersHead):
+    """check_tracer_monotonicity :8416-8749 (thicknesses, not volumes, are compared)"""
+    halo = getattr(domain, "halo", None)
+    for t in tracersHead:
+        if t.nParents == 0:
+            continue  # monotonicity holds for tracers but not for the mass-like field
+        if halo is not None:
+            halo(domain, "tracer_monotonicity", [t.tracerName + "LocalMin", t.tracerName + "LocalMax"])
+        for b in domain.blocklist:
+            d, m = b.dimensions, b.structs["mesh"]
+            mono = b.structs["tracer_monotonicity"]
+            bad = calli("ira_check_monotonicity", d["nCells"], d["nCellsSolve"], d["maxEdges"], t.nLayers,
+                        d["nCategories"], m["nEdgesOnCell"], m["cellsOnCell"], b.structs["tracers"][t.tracerName],
+                        b._ir_masks[t.tracerName], mono[t.tracerName + "LocalMin"], mono[t.tracerName + "LocalMax"])
+            if bad:
+                raise IRError("IR advection, monotonicity violation: tracer = " + t.tracerName)
 
 
 def _convert(b, tracersHead, routine):
@@ -159,6 +179,18 @@ def incremental_remap_block(domain, b, dt, tracersHead, diagnostics=None):
     rot = bool(cfg["config_rotate_cartesian_grid"])
     W = {t.tracerName: _Work(t, nCat, nC, nE) for t in tracersHead}
     maskCell = np.zeros(nC + 1, dtype=np.int32)
+
+    # local mins and maxes of the old values for the monotonicity check :2999-3021
+    if cfg["config_monotonicity_check"]:
+        mono = b.structs.setdefault("tracer_monotonicity", {})
+        for t in tracersHead:
+            w = W[t.tracerName]
+            call_masks(nC, t, nCat, tp, t.parent, 0.0, w.mask, maskCell)
+            lo = np.zeros((t.nLayers, nCat, nC + 1), order="F")
+            hi = np.zeros((t.nLayers, nCat, nC + 1), order="F")
+            call("ira_local_min_max", nC, nCs, M, t.nLayers, nCat, m["nEdgesOnCell"], m["cellsOnCell"],
+                 tp[t.tracerName], w.mask, lo, hi)
+            mono[t.tracerName + "LocalMin"], mono[t.tracerName + "LocalMax"] = lo, hi
 
     # make_masks :3023-3029
     for t in tracersHead:
@@ -273,6 +305,7 @@ def incremental_remap_block(domain, b, dt, tracersHead, diagnostics=None):
     if diagnostics is not None:
         diagnostics["work"] = W
         diagnostics["maskCell"] = maskCell
+    b._ir_masks = {t.tracerName: W[t.tracerName].mask for t in tracersHead}  # from the old values, threshold 1e-11
 
 
 def call_masks(nC, t, nCat, tp, parent, threshold, mask, maskCell):

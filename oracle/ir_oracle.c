@@ -1027,3 +1027,73 @@ void ira_sum_tracer(int nCellsSolve, int L, int nCat, const double *areaCell, co
     for (int c = 1; c <= nCellsSolve; c++)
         for (size_t p = 0; p < np; p++) sums[p] = sums[p] + areaCell[c - 1] * prod[((size_t)c - 1) * np + p];
 }
+
+/* tracer_local_min_max :8268-8392 for one tracer: min and max of the old values over a cell and its edge
+ * neighbours, counting only entries whose mask (made with threshold 0) is 1; zero elsewhere. */
+void ira_local_min_max(int nCells, int nCellsSolve, int M, int L, int nCat, const int *nEdgesOnCell,
+                       const int *cellsOnCell, const double *array, const int *mask, double *localMin,
+                       double *localMax)
+{
+    memset(localMin, 0, sizeof(double) * (size_t)L * nCat * ((size_t)nCells + 1));
+    memset(localMax, 0, sizeof(double) * (size_t)L * nCat * ((size_t)nCells + 1));
+    for (int c = 1; c <= nCellsSolve; c++)
+        for (int cat = 1; cat <= nCat; cat++)
+            for (int l = 1; l <= L; l++) {
+                size_t k = F3(l, cat, c, L, nCat);
+                if (mask[k] == 1) {
+                    localMin[k] = array[k];
+                    localMax[k] = array[k];
+                }
+                for (int ie = 1; ie <= nEdgesOnCell[c - 1]; ie++) {
+                    int nb = cellsOnCell[I2(ie, c, M)];
+                    if (nb >= 1 && nb <= nCells) {
+                        size_t kn = F3(l, cat, nb, L, nCat);
+                        if (mask[kn] == 1) {
+                            if (array[kn] < localMin[k]) localMin[k] = array[kn];
+                            if (array[kn] > localMax[k]) localMax[k] = array[kn];
+                        }
+                    }
+                }
+            }
+}
+
+/* check_tracer_monotonicity :8416-8749 for one tracer with a parent, after the halo update of localMin /
+ * localMax: extend both by one layer of neighbours (in place, cells in ascending order, so a neighbour with
+ * a lower index contributes its already extended value), then compare the new values.  `mask` is the one
+ * made from the old values with threshold 1e-11.  Returns the number of violations; the reference stops at
+ * the first one. */
+int ira_check_monotonicity(int nCells, int nCellsSolve, int M, int L, int nCat, const int *nEdgesOnCell,
+                           const int *cellsOnCell, const double *array, const int *mask, double *localMin,
+                           double *localMax)
+{
+    for (int c = 1; c <= nCellsSolve; c++)
+        for (int cat = 1; cat <= nCat; cat++)
+            for (int l = 1; l <= L; l++) {
+                size_t k = F3(l, cat, c, L, nCat);
+                if (mask[k] != 1) continue;
+                for (int ie = 1; ie <= nEdgesOnCell[c - 1]; ie++) {
+                    int nb = cellsOnCell[I2(ie, c, M)];
+                    if (nb >= 1 && nb <= nCells) {
+                        size_t kn = F3(l, cat, nb, L, nCat);
+                        if (mask[kn] == 1) {
+                            if (localMin[kn] < localMin[k]) localMin[k] = localMin[kn];
+                            if (localMax[kn] > localMax[k]) localMax[k] = localMax[kn];
+                        }
+                    }
+                }
+            }
+    int bad = 0;
+    for (int c = 1; c <= nCellsSolve; c++)
+        for (int cat = 1; cat <= nCat; cat++)
+            for (int l = 1; l <= L; l++) {
+                size_t k = F3(l, cat, c, L, nCat);
+                if (mask[k] != 1) continue;
+                double tolMin = eps11 * fmax(1.0, fabs(localMin[k]));
+                double tolMax = eps11 * fmax(1.0, fabs(localMax[k]));
+                if (array[k] < localMin[k] - tolMin)
+                    bad++;
+                else if (array[k] > localMax[k] + tolMax)
+                    bad++;
+            }
+    return bad;
+}

@@ -201,3 +201,29 @@ def test_open_water_and_small_mass(oracle):
     a = tp["iceAreaCategory"][0, :, :nC]
     assert (a >= 0.0).all() and (a == 0.0).any() and np.isfinite(a).all()
     assert (tp["iceVolumeCategory"][0, :, :nC][a == 0.0] == 0.0).all()
+
+
+def test_reference_monotonicity_check_passes_and_catches_a_violation(oracle):
+    """check_tracer_monotonicity (:8416-8749) as restated: a normal step passes; a new value pushed out of
+    the old neighbourhood range is caught; the mass-like field is exempt."""
+    ir = _ir()
+    dom = _setup(oracle, "QU480", "QU480", configs={"config_monotonicity_check": True}, open_water_band=(-0.3, 0.4))
+    oracle.seaice_run_velocity_solver(dom)
+    ir.seaice_run_advection(dom)  # raises IRError on a violation
+    b = dom.blocklist[0]
+    heads = dom.solver_state["tracersHead"]
+    pool = b.structs["tracer_monotonicity"]
+    lo, hi = pool["surfaceTemperatureLocalMin"], pool["surfaceTemperatureLocalMax"]
+    assert (lo <= hi).all() and np.abs(hi).max() > 0
+    # tamper with the (already advected) state and run the check alone; it compares thicknesses
+    ir._convert(b, heads, "ira_volume_to_thickness")
+    ir.check_tracer_monotonicity(dom, heads)
+    T = b.structs["tracers"]["surfaceTemperature"]
+    m = b._ir_masks["surfaceTemperature"]
+    l, cat, c = (int(x[0]) for x in np.nonzero(m[..., :b.dimensions["nCellsSolve"]]))
+    T[l, cat, c] = hi[l, cat, c] + 1.0
+    with pytest.raises(ir.IRError, match="monotonicity violation: tracer = surfaceTemperature"):
+        ir.check_tracer_monotonicity(dom, heads)
+    T[l, cat, c] = hi[l, cat, c]
+    b.structs["tracers"]["iceAreaCategory"][0, cat, c] = 7.0  # no bounds apply to the mass-like field
+    ir.check_tracer_monotonicity(dom, heads)

@@ -174,7 +174,7 @@ def test_multiblock_advection_matches_single_block_oracle(oracle, nblocks):
     unpack path: owned cells of every block equal the single-block oracle."""
     ir = _ir()
     mesh = get_mesh("QU480")
-    cfg = {"config_elastic_subcycle_number": 30}
+    cfg = {"config_elastic_subcycle_number": 30, "config_monotonicity_check": nblocks == 4}
     ref = cases.make_domain(mesh, "QU480", configs=cfg)
     oracle.seaice_init_velocity_solver(ref)
     ir.seaice_init_advection(ref)
@@ -218,5 +218,65 @@ def test_unsupported_and_error_paths():
         b.structs["tracers"]["iceAreaCategory"][0, 0, 100:140] = -0.5
         with pytest.raises(SeaiceHipError):
             adv.seaice_run_advection(dom)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+
+
+@pytest.mark.parametrize("meshname,name,cfg", [
+    ("QU480", "QU480", {}),
+    ("hex_24_20", None, {"config_dt": 600.0, "config_elastic_subcycle_number": 60}),
+    ("var12", None, {"config_dt": 1800.0, "config_elastic_subcycle_number": 60}),
+])
+def test_monotonicity_check_matches_oracle(oracle, meshname, name, cfg):
+    """config_monotonicity_check: the bounds (local min / max of the old values, extended by a layer in the
+    reference's in-place order) are the oracle's bit for bit, and the step passes the check."""
+    ir = _ir()
+    cfg = dict(cfg, config_monotonicity_check=True)
+    dom, ref = make_pair(oracle, meshname, name, configs=cfg, open_water_band=(-0.3, 0.4))
+    try:
+        oracle.seaice_run_velocity_solver(ref)
+        copy_velocity(ref, dom)
+        ir.seaice_run_advection(ref)
+        adv.seaice_run_advection(dom)
+        compare_tracers(dom, ref)
+        nCs = dom.blocklist[0].dimensions["nCellsSolve"]
+        pd, pr = (x.blocklist[0].structs["tracer_monotonicity"] for x in (dom, ref))
+        seen = 0
+        for n in TRACERS[1:]:
+            for suffix in ("LocalMin", "LocalMax"):
+                a, b = pd[n + suffix][..., :nCs], pr[n + suffix][..., :nCs]
+                assert np.array_equal(a, b), (n + suffix, np.abs(a - b).max())
+                seen += int(np.abs(b).max() > 0)
+        assert seen >= 10
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+
+
+def test_monotonicity_violation_is_reported(oracle):
+    from mpas_seaice_amd.lib import SeaiceHipError
+    cfg = {"config_monotonicity_check": True}
+    dom, ref = make_pair(oracle, "QU480", "QU480", configs=cfg)
+    try:
+        oracle.seaice_run_velocity_solver(ref)
+        copy_velocity(ref, dom)
+        b = dom.blocklist[0]
+        ctx, tp = b.ctx, b.structs["tracers"]
+        ctx.put_many([("uVelocity", b.structs["velocity_solver"]["uVelocity"]),
+                      ("vVelocity", b.structs["velocity_solver"]["vVelocity"])] + [(n, tp[n]) for n in TRACERS])
+        dt = float(b.structs["velocity_solver"]["dynamicsTimeStep"][0])
+        ctx.ir_run(dt, False, True)
+        with pytest.raises(SeaiceHipError, match="call sih_ir_check_monotonicity"):
+            ctx.ir_run(dt, False, True)
+        # push one new value far outside the old neighbourhood range
+        T = np.zeros_like(tp["surfaceTemperature"])
+        ctx.get("surfaceTemperature", T)
+        cell = int(np.argmax(tp["iceAreaCategory"][0, 2, :-1] > 0.05))
+        T[0, 2, cell] += 50.0
+        ctx.put("surfaceTemperature", T)
+        with pytest.raises(SeaiceHipError, match="monotonicity violation: tracer = surfaceTemperature"):
+            ctx.ir_check_monotonicity()
+        with pytest.raises(SeaiceHipError, match="no step with the monotonicity check is pending"):
+            ctx.ir_check_monotonicity()
+        ctx.ir_run(dt, False, False)  # the context is usable again
     finally:
         vs.seaice_mesh_pool_destroy(dom)
