@@ -259,13 +259,21 @@ module seaice_hip_interface
        integer(c_int) :: ierr
      end function sih_ir_set_tracers
 
-     function sih_ir_run(ctx, dt, checkConservation) bind(C, name="sih_ir_run") result(ierr)
+     ! checks: 1 = config_conservation_check, 2 = config_monotonicity_check (then sih_ir_check_monotonicity
+     ! must follow), 3 = both
+     function sih_ir_run(ctx, dt, checks) bind(C, name="sih_ir_run") result(ierr)
        import :: c_int, c_ptr, c_double
        type(c_ptr), value :: ctx
        real(c_double), value :: dt
-       integer(c_int), value :: checkConservation
+       integer(c_int), value :: checks
        integer(c_int) :: ierr
      end function sih_ir_run
+
+     function sih_ir_check_monotonicity(ctx) bind(C, name="sih_ir_check_monotonicity") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int) :: ierr
+     end function sih_ir_check_monotonicity
 
      function sih_ir_get_sums(ctx, tracer, initSums, finalSums) bind(C, name="sih_ir_get_sums") result(ierr)
        import :: c_int, c_ptr, c_char
