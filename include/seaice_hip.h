@@ -80,7 +80,7 @@ typedef struct sih_evp_config {
     int32_t dynamicsSubcycleNumber;   /* config_dynamics_subcycle_number */
     int32_t elasticSubcycleNumber;    /* config_elastic_subcycle_number */
     int32_t constitutiveRelation;     /* 1 evp, 2 evp_revised, 3 linear */
-    int32_t variationalBasis;         /* 1 wachspress (computed on device), 0 none (host supplies it) */
+    int32_t variationalBasis;         /* 1 wachspress, 2 pwl (both computed on device), 0 none (host supplies it) */
     int32_t variationalDenominator;   /* 0 original, 1 alternate */
     int32_t wachspressIntegrationOrder; /* dunavant rule order; 8 is the reference default */
     int32_t rotateCartesianGrid;

@@ -32,6 +32,7 @@ struct InitArgs {
     double R;
     const int *nEdgesOnCell, *voc, *cov;
     const double *xCell, *yCell, *zCell, *xVertex, *yVertex, *zVertex, *areaTriangle;
+    const double *areaCell, *dvOnCell;  // dvOnCell: dvEdge(edgesOnCell(s, c)), null if the mesh came without edges
     int *cvav, *gidx, *interiorVertex, *vActive;
     double *tanLat, *varDenom;
     double *gradU, *gradV, *SU, *SV, *SM, *gradU3, *gradV3;
@@ -299,6 +300,165 @@ __global__ void k_wach_integrals(InitArgs a)
     }
 }
 
+// ---- piecewise-linear basis (mpas_seaice_velocity_solver_pwl.F:44-373) ----------------------------
+// seaice_solve_linear_basis_system (mpas_seaice_numerics.F:44-212) for the 3x3 systems of the sub-triangles:
+// LU decomposition with implicitly scaled partial pivoting, then back substitution
+__device__ void solveLinearBasisSystem(const double L[3][3], const double rhs[3], double sol[3])
+{
+    const int n = 3;
+    double a[3][3], b[3], maxa[3];
+    int indices[3];
+    for (int i = 0; i < n; i++) {
+        b[i] = rhs[i];
+        for (int j = 0; j < n; j++) a[i][j] = L[i][j];
+    }
+    for (int i = 0; i < n; i++) {
+        double m = 0.0;
+        for (int j = 0; j < n; j++) m = fmax(m, fabs(a[i][j]));
+        maxa[i] = 1.0 / m;
+    }
+    for (int j = 0; j < n; j++) {
+        int jmax = j;
+        double best = maxa[j] * fabs(a[j][j]);
+        for (int i = j + 1; i < n; i++) {
+            double v = maxa[i] * fabs(a[i][j]);
+            if (v > best) {
+                best = v;
+                jmax = i;
+            }
+        }
+        if (j != jmax) {
+            for (int k = 0; k < n; k++) {
+                double t = a[jmax][k];
+                a[jmax][k] = a[j][k];
+                a[j][k] = t;
+            }
+            maxa[jmax] = maxa[j];
+        }
+        indices[j] = jmax;
+        if (a[j][j] == 0.0) a[j][j] = 1.0e-20;
+        for (int i = j + 1; i < n; i++) a[i][j] = a[i][j] / a[j][j];
+        for (int i = j + 1; i < n; i++)
+            for (int k = j + 1; k < n; k++) a[i][k] = a[i][k] - a[i][j] * a[j][k];
+    }
+    int jj = -1;
+    for (int i = 0; i < n; i++) {
+        int k = indices[i];
+        double sums = b[k];
+        b[k] = b[i];
+        if (jj >= 0) {
+            double dp = 0.0;
+            for (int q = jj; q <= i - 1; q++) dp = dp + a[i][q] * b[q];
+            sums = sums - dp;
+        } else if (sums != 0.0) {
+            jj = i;
+        }
+        b[i] = sums;
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double dp = 0.0;
+        for (int q = i + 1; q < n; q++) dp = dp + a[i][q] * b[q];
+        b[i] = (b[i] - dp) / a[i][i];
+    }
+    for (int i = 0; i < n; i++) sol[i] = b[i];
+}
+
+// one thread per cell: sub-triangle areas (Heron, rescaled to areaCell), the linear basis on every
+// sub-triangle, the PWL gradients at the corners and the three integral matrices
+__global__ void k_pwl_basis(InitArgs a)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.nCells) return;
+    const int M = a.M;
+    const size_t pc = a.padC;
+    for (int k = 0; k < M * M; k++) {
+        a.gradU[(size_t)k * pc + c] = 0.0;
+        a.gradV[(size_t)k * pc + c] = 0.0;
+        a.SU[(size_t)k * pc + c] = 0.0;
+        a.SV[(size_t)k * pc + c] = 0.0;
+        a.SM[(size_t)k * pc + c] = 0.0;
+    }
+    WachCell w;  // only its local coordinates are used (seaice_calc_local_coords)
+    wachSetup(w, a, c);
+    const int n = w.n;
+    if (n < 3) return;
+    const double alpha = 1.0 / (double)n;
+    double xc = 0.0, yc = 0.0;
+    for (int i = 0; i < n; i++) {
+        xc = xc + alpha * w.x[i];
+        yc = yc + alpha * w.y[i];
+    }
+    double subArea[SIH_MAXE], subGU[SIH_MAXE][3], subGV[SIH_MAXE][3];
+    double areaSum = 0.0;
+    for (int s = 0; s < n; s++) {
+        const int i2 = wrapIdx(s + 1, n);
+        const double cc = a.dvOnCell[(size_t)s * pc + c];
+        const double dx1 = w.x[s] - xc, dy1 = w.y[s] - yc, dx2 = w.x[i2] - xc, dy2 = w.y[i2] - yc;
+        const double aa = sqrt(dx1 * dx1 + dy1 * dy1), bb = sqrt(dx2 * dx2 + dy2 * dy2);
+        const double sp = (aa + bb + cc) * 0.5;
+        subArea[s] = sqrt(sp * (sp - aa) * (sp - bb) * (sp - cc));
+        areaSum = areaSum + subArea[s];
+    }
+    const double scale = a.areaCell[c] / areaSum;
+    for (int s = 0; s < n; s++) subArea[s] = subArea[s] * scale;
+    for (int s = 0; s < n; s++) {
+        const int i2 = wrapIdx(s + 1, n);
+        const double L[3][3] = {{w.x[s] - xc, w.y[s] - yc, 1.0}, {w.x[i2] - xc, w.y[i2] - yc, 1.0}, {0.0, 0.0, 1.0}};
+        const double r1[3] = {1.0, 0.0, 0.0}, r2[3] = {0.0, 1.0, 0.0};
+        double sol[3];
+        solveLinearBasisSystem(L, r1, sol);
+        subGU[s][0] = sol[0];
+        subGV[s][0] = sol[1];
+        solveLinearBasisSystem(L, r2, sol);
+        subGU[s][1] = sol[0];
+        subGV[s][1] = sol[1];
+        subGU[s][2] = -subGU[s][0] - subGU[s][1];
+        subGV[s][2] = -subGV[s][0] - subGV[s][1];
+    }
+    // gradient of basis function ib on sub-triangle s (subCellGradientU/V(iBasisVertex, iSubCell))
+    auto cellG = [&](const double (*g)[3], int ib, int s) {
+        double v = g[s][2] * alpha;
+        if (s == ib)
+            v = v + g[s][0];
+        else if (s == wrapIdx(ib - 1, n))
+            v = v + g[s][1];
+        return v;
+    };
+    for (int ib = 0; ib < n; ib++)
+        for (int g = 0; g < n; g++) {
+            const int s2 = wrapIdx(g - 1, n);
+            a.gradU[(size_t)(g * M + ib) * pc + c] = 0.5 * (cellG(subGU, ib, g) + cellG(subGU, ib, s2));
+            a.gradV[(size_t)(g * M + ib) * pc + c] = 0.5 * (cellG(subGV, ib, g) + cellG(subGV, ib, s2));
+        }
+    for (int is = 0; is < n; is++)
+        for (int iv = 0; iv < n; iv++) {
+            double su = 0.0, sv = 0.0, sm = 0.0;
+            for (int s = 0; s < n; s++) {
+                const bool nearS = (s == is) || (s == wrapIdx(is - 1, n));
+                const double bi = nearS ? ((alpha + 1) * subArea[s]) / 3.0 : (alpha * subArea[s]) / 3.0;
+                su = su + cellG(subGU, iv, s) * bi;
+                sv = sv + cellG(subGV, iv, s) * bi;
+                const int ts = (s == is) ? 1 : (s == wrapIdx(is - 1, n) ? 2 : 3);
+                const int tv = (s == iv) ? 1 : (s == wrapIdx(iv - 1, n) ? 2 : 3);
+                double m;
+                if ((ts == 1 && tv == 1) || (ts == 2 && tv == 2))
+                    m = 2.0 * (alpha * alpha) + 2.0 * alpha + 2.0;
+                else if ((ts == 1 && tv == 2) || (ts == 2 && tv == 1))
+                    m = 2.0 * (alpha * alpha) + 2.0 * alpha + 1.0;
+                else if (ts == 3 && tv == 3)
+                    m = 2.0 * (alpha * alpha);
+                else
+                    m = 2.0 * (alpha * alpha) + alpha;
+                m = m * subArea[s] / 12.0;
+                sm = sm + m;
+            }
+            const size_t k = (size_t)(iv * M + is) * pc + c;
+            a.SU[k] = su;
+            a.SV[k] = sv;
+            a.SM[k] = sm;
+        }
+}
+
 // Compact form of the basis gradients.  The Wachspress gradient matrix (iBasis, iGradient) is
 // non-zero only for iBasis in {iGradient-1, iGradient, iGradient+1} (cyclic; wachspress.F:1178-1191),
 // so corner g needs three coefficients.  They are stored in ascending-iBasis order, the order in
@@ -403,6 +563,8 @@ static InitArgs makeInitArgs(sih_ctx *c)
     a.yVertex = fd("yVertex");
     a.zVertex = fd("zVertex");
     a.areaTriangle = fd("areaTriangle");
+    a.areaCell = fd("areaCell");
+    a.dvOnCell = sih_find_field(c, "_dvEdgeOnCell") ? fd("_dvEdgeOnCell") : nullptr;
     a.cvav = fi("cellVerticesAtVertex");
     a.gidx = fi("_gidx");
     a.interiorVertex = fi("interiorVertex");
@@ -447,9 +609,13 @@ extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
         sih_set_error("config_ocean_stress_type unknown");
         return SIH_ERR_ARG;
     }
-    if (cfg->variationalBasis != 0 && cfg->variationalBasis != 1) {
-        sih_set_error("Unknown variational basis type (the library computes 'wachspress'; pass 0 and upload others)");
-        return SIH_ERR_UNSUPPORTED;
+    if (cfg->variationalBasis < 0 || cfg->variationalBasis > 2) {
+        sih_set_error("Unknown variational basis type");
+        return SIH_ERR_ARG;
+    }
+    if (cfg->variationalBasis == 2 && !sih_find_field(c, "_dvEdgeOnCell")) {
+        sih_set_error("the 'pwl' basis needs edgesOnCell and dvEdge in the mesh description");
+        return SIH_ERR_ARG;
     }
     if (cfg->variationalBasis == 1 && cfg->wachspressIntegrationOrder != 8) {
         sih_set_error("only the dunavant order-8 rule (the reference default) is implemented on the device");
@@ -488,6 +654,8 @@ extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
         long tot = (long)c->nCells * c->M;
         hipLaunchKernelGGL(k_wach_gradients, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, c->stream, a);
         hipLaunchKernelGGL(k_wach_integrals, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, c->stream, a);
+    } else if (cfg->variationalBasis == 2) {
+        hipLaunchKernelGGL(k_pwl_basis, dim3((c->nCells + 63) / 64), dim3(64), 0, c->stream, a);
     }
     hipLaunchKernelGGL(k_var_denominator, dim3((c->nVertices + 255) / 256), block, 0, c->stream, a);
     HIPCHK(hipGetLastError());

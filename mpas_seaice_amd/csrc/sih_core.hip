@@ -359,6 +359,23 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
         }
         c->hVoc = voc;
         c->hNe = ne;
+        // dvEdge of edgesOnCell(s, cell) per cell and slot s; the
+        // piecewise-linear basis needs it (velocity_solver_pwl.F:163-167)
+        if (m->edgesOnCell && m->dvEdge && m->nEdges > 0) {
+            int rc2 = addField(c, "_dvEdgeOnCell", LOC_CELL, M, false);
+            if (rc2) return rc2;
+            std::vector<double> dvoc((size_t)M * c->padC, 0.0);
+            for (int i = 0; i < nC; i++) {
+                int h = c->cellPerm[i];
+                for (int s = 0; s < m->nEdgesOnCell[h]; s++) {
+                    int e = m->edgesOnCell[(size_t)h * M + s];
+                    if (e >= 1 && e <= m->nEdges) dvoc[(size_t)s * c->padC + i] = m->dvEdge[e - 1];
+                }
+            }
+            HIPCHK(hipMemcpyAsync(c->fields["_dvEdgeOnCell"].d, dvoc.data(), dvoc.size() * 8, hipMemcpyHostToDevice,
+                                  c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
         HIPCHK(hipMemcpyAsync(c->fields["_nEdgesOnCell"].d, ne.data(), ne.size() * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->fields["_voc"].d, voc.data(), voc.size() * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->fields["_coc"].d, coc.data(), coc.size() * 4, hipMemcpyHostToDevice, c->stream));

@@ -78,6 +78,8 @@ def _evp_config(domain, block):
         if cfg["config_wachspress_integration_type"] != "dunavant":
             raise _lib.SeaiceHipError("only dunavant integration is implemented")
         c.variationalBasis = 1
+    elif basis == "pwl":
+        c.variationalBasis = 2
     elif basis == "none":
         c.variationalBasis = 0
     else:

@@ -119,10 +119,16 @@ def seaice_init_velocity_solver(domain):
         yl = np.zeros((M, nC), order="F")
         call("ora_calc_local_coords", xl, yl, nC, M, m["nEdgesOnCell"], m["verticesOnCell"], m["xVertex"],
              m["yVertex"], m["zVertex"], m["xCell"], m["yCell"], m["zCell"], rot, bool(m["on_a_sphere"]))
-        assert cfg["config_variational_basis"] == "wachspress"
-        assert cfg["config_wachspress_integration_type"] == "dunavant" and cfg["config_wachspress_integration_order"] == 8
-        call("ora_wachspress_init", nC, M, m["nEdgesOnCell"], xl, yl, vv["basisGradientU"], vv["basisGradientV"],
-             vv["basisIntegralsU"], vv["basisIntegralsV"], vv["basisIntegralsMetric"])
+        if cfg["config_variational_basis"] == "pwl":  # variational.F:296-312
+            call("ora_pwl_init", nC, M, m["nEdgesOnCell"], m["edgesOnCell"], m["dvEdge"], m["areaCell"], xl, yl,
+                 vv["basisGradientU"], vv["basisGradientV"], vv["basisIntegralsMetric"], vv["basisIntegralsU"],
+                 vv["basisIntegralsV"])
+        else:
+            assert cfg["config_variational_basis"] == "wachspress"
+            assert (cfg["config_wachspress_integration_type"] == "dunavant"
+                    and cfg["config_wachspress_integration_order"] == 8)
+            call("ora_wachspress_init", nC, M, m["nEdgesOnCell"], xl, yl, vv["basisGradientU"], vv["basisGradientV"],
+                 vv["basisIntegralsU"], vv["basisIntegralsV"], vv["basisIntegralsMetric"])
         call("ora_variational_denominator", vv["variationalDenominator"], nV, D, M, m["nEdgesOnCell"],
              m["areaTriangle"], m["cellsOnVertex"], vv["cellVerticesAtVertex"], vv["basisIntegralsMetric"],
              cfg["config_variational_denominator_type"] == "alternate")

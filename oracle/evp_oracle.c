@@ -399,6 +399,176 @@ void ora_wachspress_init(int nCells, int maxEdges, const int *nEdgesOnCell, cons
     }
 }
 
+
+/* ------------------------------------------------------------------ piecewise-linear basis */
+
+/* seaice_solve_linear_basis_system, mpas_seaice_numerics.F:44-212: LU decomposition with implicitly
+ * scaled partial pivoting and back substitution, n = 3 here */
+static void solve_linear_basis_system(const double L[3][3], const double rhs[3], double sol[3])
+{
+    const int n = 3;
+    double a[3][3], b[3], maxa[3];
+    int indices[3];
+    for (int i = 0; i < n; i++) {
+        b[i] = rhs[i];
+        for (int j = 0; j < n; j++) a[i][j] = L[i][j];
+    }
+    for (int i = 0; i < n; i++) {
+        double m = 0.0;
+        for (int j = 0; j < n; j++) m = fmax(m, fabs(a[i][j]));
+        maxa[i] = 1.0 / m;
+    }
+    for (int j = 0; j < n; j++) {
+        int jmax = j; /* maxloc: first maximum */
+        double best = maxa[j] * fabs(a[j][j]);
+        for (int i = j + 1; i < n; i++) {
+            double v = maxa[i] * fabs(a[i][j]);
+            if (v > best) {
+                best = v;
+                jmax = i;
+            }
+        }
+        if (j != jmax) {
+            for (int k = 0; k < n; k++) {
+                double t = a[jmax][k];
+                a[jmax][k] = a[j][k];
+                a[j][k] = t;
+            }
+            maxa[jmax] = maxa[j];
+        }
+        indices[j] = jmax;
+        if (a[j][j] == 0.0) a[j][j] = 1.0e-20;
+        for (int i = j + 1; i < n; i++) a[i][j] = a[i][j] / a[j][j];
+        for (int i = j + 1; i < n; i++)
+            for (int k = j + 1; k < n; k++) a[i][k] = a[i][k] - a[i][j] * a[j][k];
+    }
+    int jj = -1;
+    for (int i = 0; i < n; i++) {
+        int k = indices[i];
+        double sums = b[k];
+        b[k] = b[i];
+        if (jj >= 0) {
+            double dp = 0.0;
+            for (int q = jj; q <= i - 1; q++) dp = dp + a[i][q] * b[q];
+            sums = sums - dp;
+        } else if (sums != 0.0) {
+            jj = i;
+        }
+        b[i] = sums;
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double dp = 0.0;
+        for (int q = i + 1; q < n; q++) dp = dp + a[i][q] * b[q];
+        b[i] = (b[i] - dp) / a[i][i];
+    }
+    for (int i = 0; i < n; i++) sol[i] = b[i];
+}
+
+/* seaice_init_velocity_solver_pwl, mpas_seaice_velocity_solver_pwl.F:44-373 */
+void ora_pwl_init(int nCells, int maxEdges, const int *nEdgesOnCell, const int *edgesOnCell, const double *dvEdge,
+                  const double *areaCell, const double *xLocal, const double *yLocal, double *basisGradientU,
+                  double *basisGradientV, double *basisIntegralsMetric, double *basisIntegralsU,
+                  double *basisIntegralsV)
+{
+    for (int c = 1; c <= nCells; c++) {
+        const int n = nEdgesOnCell[c - 1];
+        double subGU[MAXE + 1][4], subGV[MAXE + 1][4], subC[MAXE + 1][4];
+        double cellGU[MAXE + 1][MAXE + 1], cellGV[MAXE + 1][MAXE + 1], subArea[MAXE + 1];
+        const double alpha = 1.0 / (double)n;
+        double xc = 0.0, yc = 0.0;
+        for (int i = 1; i <= n; i++) {
+            xc = xc + alpha * xLocal[IX2(i, c, maxEdges)];
+            yc = yc + alpha * yLocal[IX2(i, c, maxEdges)];
+        }
+        double areaSum = 0.0;
+        for (int s = 1; s <= n; s++) {
+            int e = edgesOnCell[IX2(s, c, maxEdges)];
+            int i1 = s, i2 = wrapped_index(s + 1, n);
+            double cc = dvEdge[e - 1];
+            double dx1 = xLocal[IX2(i1, c, maxEdges)] - xc, dy1 = yLocal[IX2(i1, c, maxEdges)] - yc;
+            double dx2 = xLocal[IX2(i2, c, maxEdges)] - xc, dy2 = yLocal[IX2(i2, c, maxEdges)] - yc;
+            double a = sqrt(dx1 * dx1 + dy1 * dy1);
+            double b = sqrt(dx2 * dx2 + dy2 * dy2);
+            double sp = (a + b + cc) * 0.5;
+            subArea[s] = sqrt(sp * (sp - a) * (sp - b) * (sp - cc)); /* Heron */
+            areaSum = areaSum + subArea[s];
+        }
+        const double scale = areaCell[c - 1] / areaSum;
+        for (int s = 1; s <= n; s++) subArea[s] = subArea[s] * scale;
+        for (int s = 1; s <= n; s++) {
+            int i1 = s, i2 = wrapped_index(s + 1, n);
+            double L[3][3] = {{xLocal[IX2(i1, c, maxEdges)] - xc, yLocal[IX2(i1, c, maxEdges)] - yc, 1.0},
+                              {xLocal[IX2(i2, c, maxEdges)] - xc, yLocal[IX2(i2, c, maxEdges)] - yc, 1.0},
+                              {0.0, 0.0, 1.0}};
+            double r1[3] = {1.0, 0.0, 0.0}, r2[3] = {0.0, 1.0, 0.0}, sol[3];
+            solve_linear_basis_system(L, r1, sol);
+            subGU[s][1] = sol[0];
+            subGV[s][1] = sol[1];
+            subC[s][1] = sol[2];
+            solve_linear_basis_system(L, r2, sol);
+            subGU[s][2] = sol[0];
+            subGV[s][2] = sol[1];
+            subC[s][2] = sol[2];
+            subGU[s][3] = -subGU[s][1] - subGU[s][2];
+            subGV[s][3] = -subGV[s][1] - subGV[s][2];
+            subC[s][3] = 1.0 - subC[s][1] - subC[s][2];
+        }
+        for (int ib = 1; ib <= n; ib++)
+            for (int s = 1; s <= n; s++) {
+                cellGU[ib][s] = subGU[s][3] * alpha;
+                cellGV[ib][s] = subGV[s][3] * alpha;
+                if (s == ib) {
+                    cellGU[ib][s] = cellGU[ib][s] + subGU[s][1];
+                    cellGV[ib][s] = cellGV[ib][s] + subGV[s][1];
+                } else if (s == wrapped_index(ib - 1, n)) {
+                    cellGU[ib][s] = cellGU[ib][s] + subGU[s][2];
+                    cellGV[ib][s] = cellGV[ib][s] + subGV[s][2];
+                }
+            }
+        for (int ib = 1; ib <= n; ib++)
+            for (int g = 1; g <= n; g++) {
+                int s1 = g, s2 = wrapped_index(g - 1, n);
+                basisGradientU[IX3(ib, g, c, maxEdges)] = 0.5 * (cellGU[ib][s1] + cellGU[ib][s2]);
+                basisGradientV[IX3(ib, g, c, maxEdges)] = 0.5 * (cellGV[ib][s1] + cellGV[ib][s2]);
+            }
+        for (int is = 1; is <= n; is++)
+            for (int iv = 1; iv <= n; iv++) {
+                double su = 0.0, sv = 0.0;
+                for (int s = 1; s <= n; s++) {
+                    double bi;
+                    if (s == is || s == wrapped_index(is - 1, n))
+                        bi = ((alpha + 1) * subArea[s]) / 3.0;
+                    else
+                        bi = (alpha * subArea[s]) / 3.0;
+                    su = su + cellGU[iv][s] * bi;
+                    sv = sv + cellGV[iv][s] * bi;
+                }
+                basisIntegralsU[IX3(is, iv, c, maxEdges)] = su;
+                basisIntegralsV[IX3(is, iv, c, maxEdges)] = sv;
+            }
+        for (int is = 1; is <= n; is++)
+            for (int iv = 1; iv <= n; iv++) {
+                double sm = 0.0;
+                for (int s = 1; s <= n; s++) {
+                    int ts = (s == is) ? 1 : (s == wrapped_index(is - 1, n) ? 2 : 3);
+                    int tv = (s == iv) ? 1 : (s == wrapped_index(iv - 1, n) ? 2 : 3);
+                    double m = 0.0;
+                    if ((ts == 1 && tv == 1) || (ts == 2 && tv == 2))
+                        m = 2.0 * (alpha * alpha) + 2.0 * alpha + 2.0;
+                    else if ((ts == 1 && tv == 2) || (ts == 2 && tv == 1))
+                        m = 2.0 * (alpha * alpha) + 2.0 * alpha + 1.0;
+                    else if (ts == 3 && tv == 3)
+                        m = 2.0 * (alpha * alpha);
+                    else
+                        m = 2.0 * (alpha * alpha) + alpha;
+                    m = m * subArea[s] / 12.0;
+                    sm = sm + m;
+                }
+                basisIntegralsMetric[IX3(is, iv, c, maxEdges)] = sm;
+            }
+    }
+}
+
 /* variational.F:358-445 */
 void ora_variational_denominator(double *variationalDenominator, int nVertices, int vertexDegree, int maxEdges,
                                  const int *nEdgesOnCell, const double *areaTriangle, const int *cellsOnVertex,

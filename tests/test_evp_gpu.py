@@ -193,3 +193,17 @@ def test_special_boundaries(oracle):
     u = ref.blocklist[0].structs["velocity_solver"]["uVelocity"]
     typ = ref.blocklist[0].structs["special_boundaries"]["vertexBoundaryType"]
     assert np.abs(u).max() > 0 and np.all(u[typ == 3] == 0.0)
+
+
+@pytest.mark.parametrize("mesh_name", ["QU480", "hex_24_20", "var12"])
+def test_pwl_basis(oracle, mesh_name):
+    """config_variational_basis = 'pwl' (mpas_seaice_velocity_solver_pwl.F): a dense gradient matrix, so the
+    strain uses the general kernel; basis arrays to 1e-13, the step to 1e-10."""
+    cfg = {"config_elastic_subcycle_number": 30, "config_variational_basis": "pwl"}
+    if mesh_name == "var12":
+        cfg["config_dt"] = 1800.0
+    ref, dev = _run_both(oracle, mesh_name, cfg)
+    compare_domains(dev, ref, STATIC_OUTPUTS, 1e-13)
+    compare_domains(dev, ref, STATE, 1e-10)
+    gu = ref.blocklist[0].structs["velocity_variational"]["basisGradientU"]
+    assert (gu[:, :, 0] != 0.0).sum() > 3 * 6  # dense: more than three basis functions per corner

@@ -173,3 +173,32 @@ def test_special_boundaries_velocity_is_the_sequential_in_place_loop(oracle):
             eu[i], ev[i] = 0.0, 0.0
     oracle.call("ora_set_special_boundaries_velocity", n, typ, src, u, v)
     assert np.array_equal(u, eu) and np.array_equal(v, ev)
+
+
+@pytest.mark.parametrize("mesh_name", ["QU480", "hex_8_6", "var12"])
+def test_pwl_basis_invariants(oracle, mesh_name):
+    """Piecewise-linear basis (velocity_solver_pwl.F:44-373): the basis functions sum to one, so their
+    gradients sum to zero at every corner and the strain of a linear velocity field is exact; the
+    metric integrals sum to the cell area; the U / V integrals of each basis function sum (over stress
+    corners) to the integral of its gradient, sum_s grad(s) * subArea(s)."""
+    mesh = get_mesh(mesh_name)
+    dom = cases.make_domain(mesh, mesh_name if mesh_name.startswith("QU") else None,
+                            configs={"config_variational_basis": "pwl"})
+    oracle.seaice_init_velocity_solver(dom)
+    b = dom.blocklist[0]
+    vv, m = b.structs["velocity_variational"], b.structs["mesh"]
+    nC, M = b.dimensions["nCells"], b.dimensions["maxEdges"]
+    gu, gv = vv["basisGradientU"][:, :, :nC], vv["basisGradientV"][:, :, :nC]
+    scale = np.abs(gu).max()
+    assert np.abs(gu.sum(axis=0)).max() <= 1e-13 * scale and np.abs(gv.sum(axis=0)).max() <= 1e-13 * scale
+    sm = vv["basisIntegralsMetric"][:, :, :nC].sum(axis=(0, 1))
+    assert np.abs(sm / m["areaCell"][:nC] - 1.0).max() <= 1e-13
+    # linear field u = a x + b y in the local frame of each cell: du/dx = a, du/dy = b at every corner
+    xl, yl = b._xLocal, b._yLocal
+    ne = m["nEdgesOnCell"][:nC]
+    for c in range(0, nC, max(1, nC // 50)):
+        n = ne[c]
+        u = 0.3 * xl[:n, c] - 1.7 * yl[:n, c] + 4.0
+        for g in range(n):
+            assert abs((u * gu[:n, g, c]).sum() - 0.3) <= 1e-10
+            assert abs((u * gv[:n, g, c]).sum() + 1.7) <= 1e-10
