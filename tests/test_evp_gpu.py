@@ -207,3 +207,14 @@ def test_pwl_basis(oracle, mesh_name):
     compare_domains(dev, ref, STATE, 1e-10)
     gu = ref.blocklist[0].structs["velocity_variational"]["basisGradientU"]
     assert (gu[:, :, 0] != 0.0).sum() > 3 * 6  # dense: more than three basis functions per corner
+
+
+def test_variable_resolution_960_subcycles(oracle):
+    """The long-subcycling regime of refined meshes: 960 EVP subcycles on a variable-resolution sphere mesh
+    with 5-, 6- and 7-sided cells; velocities and stresses still within 1e-10 of the oracle."""
+    mesh = get_mesh("var16")
+    assert int(mesh.maxEdges) == 7
+    cfg = {"config_elastic_subcycle_number": 960, "config_dt": 1800.0}
+    ref, dev = _run_both(oracle, "var16", cfg)
+    worst = compare_domains(dev, ref, STATE, 1e-10)
+    print("var16", mesh.nCells, "cells, 960 subcycles, worst rel err", worst)
