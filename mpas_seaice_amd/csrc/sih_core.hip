@@ -159,6 +159,8 @@ static uint64_t mortonKey(double x, double y, double z)
     return spread(q(x)) | (spread(q(y)) << 1) | (spread(q(z)) << 2);
 }
 
+extern "C" int sih_block_destroy(sih_ctx *c);
+
 extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **out)
 {
     if (!m || !out) {
@@ -170,13 +172,20 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
         return SIH_ERR_UNSUPPORTED;
     }
     if (m->nCells < 1 || m->nVertices < 1 || m->nCellsSolve > m->nCells || m->nVerticesSolve > m->nVertices ||
-        !m->nEdgesOnCell || !m->verticesOnCell || !m->cellsOnCell || !m->cellsOnVertex || !m->xCell || !m->xVertex ||
-        !m->areaCell || !m->areaTriangle || !m->fVertex) {
+        !m->nEdgesOnCell || !m->verticesOnCell || !m->cellsOnCell || !m->cellsOnVertex || !m->xCell || !m->yCell ||
+        !m->zCell || !m->xVertex || !m->yVertex || !m->zVertex || !m->areaCell || !m->areaTriangle || !m->fVertex) {
         sih_set_error("sih_block_create: inconsistent mesh description");
         return SIH_ERR_ARG;
     }
     HIPCHK(hipSetDevice(device));
     sih_ctx *c = new sih_ctx();
+    struct Guard {  // any early return below releases what has been created so far
+        sih_ctx *c;
+        ~Guard()
+        {
+            if (c) sih_block_destroy(c);
+        }
+    } guard{c};
     c->device = device;
     HIPCHK(hipStreamCreate(&c->ownStream));
     c->stream = c->ownStream;
@@ -201,7 +210,6 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
         int E = m->nEdgesOnCell[i];
         if (E < 3 || E > M) {
             sih_set_error("sih_block_create: nEdgesOnCell out of range");
-            delete c;
             return SIH_ERR_ARG;
         }
         for (int s = 0; s < E; s++) {
@@ -209,8 +217,7 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
             int nb = m->cellsOnCell[(size_t)i * M + s];
             if (v < 1 || v > nV + 1 || nb < 0 || nb > nC + 1) {
                 sih_set_error("sih_block_create: verticesOnCell / cellsOnCell index out of range");
-                delete c;
-                return SIH_ERR_ARG;
+                    return SIH_ERR_ARG;
             }
         }
     }
@@ -218,7 +225,6 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
         int cc = m->cellsOnVertex[k];
         if (cc < 0 || cc > nC + 1) {
             sih_set_error("sih_block_create: cellsOnVertex index out of range");
-            delete c;
             return SIH_ERR_ARG;
         }
     }
@@ -382,7 +388,7 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
         HIPCHK(hipMemcpyAsync(c->fields["_cov"].d, cov.data(), cov.size() * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
-    *out = c;
+    *out = nullptr;
     struct G {
         const char *n;
         const double *p;
@@ -396,6 +402,8 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
     for (const G &g : geo)
         if ((rc = sih_field_put(c, g.n, g.p, g.cnt))) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
+    guard.c = nullptr;
+    *out = c;
     return SIH_OK;
 }
 

@@ -272,9 +272,14 @@ class DistComm(CommBase):
         self.rank = rank
         self.dist = dist
         super().__init__(domain, [halo], nblocks)
-        if self.device and dist.get_backend() == "nccl":
-            # RCCL orders its transfers against torch's current stream: the block must work on it too
+        if self.device:
+            # torch orders its transfers (RCCL's own stream, or the copies that stage gloo messages) against
+            # its current stream, so the block works on that stream too.  The legacy default stream has no
+            # handle to pass and synchronises with every other stream: use an explicit one instead.
             import torch
+            if torch.cuda.current_stream().cuda_stream == 0:
+                self._stream = torch.cuda.Stream()
+                torch.cuda.set_stream(self._stream)
             domain.blocklist[0].ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def allreduce_min(self, x):
@@ -428,8 +433,7 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
     dom, halo, _ = make_partitioned_domain(mesh, name, world, configs=cfg, only_block=rank)
     vs.seaice_mesh_pool_create(dom, device=local_rank, renumber=renumber)
     ctx = dom.blocklist[0].ctx
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    dom.comm = DistComm(dom, halo, world, rank)
+    dom.comm = DistComm(dom, halo, world, rank)  # also moves the block onto torch's (explicit) current stream
     vs.seaice_init_velocity_solver(dom)
     for b in dom.blocklist:
         vs._upload(dom, b)
