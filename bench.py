@@ -223,7 +223,7 @@ def main():
         "config": {"workload": f"{args.mesh} full-sphere mesh ({n_cells_total} cells, maxEdges {M}), "
                                f"{nsub} EVP subcycles per step, variational Wachspress operators, idealised forcing",
                    "parallelism": parallelism, "hip_graph": bool(args.graph)},
-        "roofline": {"bound": "hbm", "kernel": "k_sub_cells (fused strain + EVP stress + stress-divergence partial sums)",
+        "roofline": {"bound": "hbm", "kernel": "k_sub_cells_split (fused strain + EVP stress + stress-divergence partial sums, one thread per cell corner)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_launch": roof_bytes,
                      "kernel_ms": cell_ms, "vertex_kernel_ms": vert_ms},

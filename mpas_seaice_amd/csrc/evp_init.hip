@@ -667,6 +667,12 @@ extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
     double dv = cfg->minEdgeLengthGlobal > 0.0 ? cfg->minEdgeLengthGlobal : c->minDvEdge;
     double gamma = 0.25 * 1.0e11 * dtDyn;
     c->inited = true;
+    {
+        // which cell kernel: one thread per (cell, corner) unless SIH_CELL_KERNEL=fused asks for the
+        // one-thread-per-cell kernel (measured slower at every mesh size from 10 k to 164 k cells)
+        const char *e = getenv("SIH_CELL_KERNEL");
+        c->splitCells = !(e && strcmp(e, "fused") == 0);
+    }
     sih_bind_dev(c);
     c->dev.dtDyn = dtDyn;
     c->dev.dtE = dtE;

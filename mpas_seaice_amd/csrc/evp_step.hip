@@ -510,6 +510,145 @@ __global__ void __launch_bounds__(256) k_sub_cells(SihDev d, const int *__restri
     }
 }
 
+// The same arithmetic as k_sub_cells<M, SPARSE, LAST, 0> with one thread per (cell, corner): a block is 64
+// consecutive cells (threadIdx.x) times M corners (threadIdx.y), so every wave still reads 64 consecutive
+// entries of one plane.  Corner velocities and the new corner stresses are exchanged through LDS.  Each
+// thread issues 1/M of the loads of the one-thread-per-cell kernel, which shortens the dependent chain
+// that dominates on small blocks (many-GPU runs), at the price of two block barriers.
+template <int M, bool SPARSE, bool LAST>
+__global__ void __launch_bounds__(64 * M) k_sub_cells_split(SihDev d, const int *__restrict__ list, int nList)
+{
+    __shared__ double su[M][64], sv[M][64], s11[M][64], s22[M][64], s12[M][64];
+    const int lane = threadIdx.x, g = threadIdx.y;
+    int c = blockIdx.x * 64 + lane;
+    bool inRange;
+    if (list) {
+        inRange = c < nList;
+        c = inRange ? list[c] : 0;
+    } else {
+        inRange = c < d.nCells;
+        if (!inRange) c = 0;
+    }
+    const int P = d.padC;
+    const bool solve = inRange && d.solveStress[c] == 1;
+    const int E = inRange ? d.nEdgesOnCell[c] : 0;
+    const bool corner = solve && g < E;
+    const size_t k = (size_t)g * P + c;
+    double ug = 0.0, vg = 0.0, tg = 0.0;
+    if (corner) {
+        const int iv = d.voc[k];
+        ug = d.u[iv];
+        vg = d.v[iv];
+        tg = d.tanLat[iv];
+    }
+    su[g][lane] = ug;
+    sv[g][lane] = vg;
+    __syncthreads();
+    double a11 = 0.0, a22 = 0.0, a12 = 0.0;
+    if (corner) {
+        double e11 = 0.0, e22 = 0.0, e12 = 0.0;
+        if (SPARSE) {
+            // the three non-zero basis gradients of corner g, met in ascending basis-vertex order
+            int i0, i1, i2;
+            if (g == 0) {
+                i0 = 0;
+                i1 = 1;
+                i2 = E - 1;
+            } else if (g == E - 1) {
+                i0 = 0;
+                i1 = g - 1;
+                i2 = g;
+            } else {
+                i0 = g - 1;
+                i1 = g;
+                i2 = g + 1;
+            }
+            const double xu[3] = {su[i0][lane], su[i1][lane], su[i2][lane]};
+            const double xv[3] = {sv[i0][lane], sv[i1][lane], sv[i2][lane]};
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const double gu = d.gradU3[(size_t)(q * M + g) * P + c];
+                const double gv = d.gradV3[(size_t)(q * M + g) * P + c];
+                e11 = e11 + xu[q] * gu;
+                e22 = e22 + xv[q] * gv;
+                e12 = e12 + 0.5 * (xu[q] * gv + xv[q] * gu);
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < M; b++) {
+                if (b < E) {
+                    const double gu = d.gradU[(size_t)(g * M + b) * P + c];
+                    const double gv = d.gradV[(size_t)(g * M + b) * P + c];
+                    e11 = e11 + su[b][lane] * gu;
+                    e22 = e22 + sv[b][lane] * gv;
+                    e12 = e12 + 0.5 * (su[b][lane] * gv + sv[b][lane] * gu);
+                }
+            }
+        }
+        e11 = e11 - vg * tg;
+        e12 = e12 + ug * tg * 0.5;
+        if (LAST) {
+            d.strain11[k] = e11;
+            d.strain22[k] = e22;
+            d.strain12[k] = e12;
+        }
+        if (d.relation == 3) {
+            a11 = 1.0 * e11;
+            a22 = 1.0 * e22;
+            a12 = 1.0 * e12;
+        } else {
+            const double P_ice = d.icePressure[c];
+            const double dtE = d.dtE, T = d.dampT;
+            a11 = d.stress11[k];
+            a22 = d.stress22[k];
+            a12 = d.stress12[k];
+            double eD = e11 + e22, eT = e11 - e22, eS = e12 * 2.0;
+            double st1 = a11 + a22, st2 = a11 - a22;
+            double Delta = sqrt(eD * eD + (eT * eT + eS * eS) / ECC2);
+            double pc = P_ice / fmax(Delta, PUNY);
+            if (LAST) d.Prep[k] = pc * Delta;
+            double den;
+            if (d.relation == 1) {
+                pc = (pc * dtE) / (2.0 * T);
+                den = 1.0 + (0.5 * dtE) / T;
+            } else {
+                pc = (pc * 2.0 * 5.5e-3) / 0.86;
+                den = 1.0 + (2.0 * 5.5e-3) / 0.86;
+            }
+            st1 = (st1 + pc * (eD - Delta)) / den;
+            st2 = (st2 + (pc / ECC2) * eT) / den;
+            a12 = (a12 + (pc / ECC2) * eS * 0.5) / den;
+            a11 = 0.5 * (st1 + st2);
+            a22 = 0.5 * (st1 - st2);
+        }
+        d.stress11[k] = a11;
+        d.stress22[k] = a22;
+        d.stress12[k] = a12;
+    } else if (LAST && inRange && d.relation == 1) {
+        d.Prep[k] = 0.0;  // unsolved cells and the unused corners of solved ones
+    }
+    s11[g][lane] = a11;
+    s22[g][lane] = a22;
+    s12[g][lane] = a12;
+    __syncthreads();
+    if (corner) {
+        // partial sums of the stress divergence for corner j = g
+        double cu = 0.0, cv = 0.0;
+#pragma unroll
+        for (int s = 0; s < M; s++) {
+            if (s < E) {
+                const size_t kb = (size_t)(g * M + s) * P + c;
+                const double bu = d.SU[kb], bv = d.SV[kb], bm = d.SM[kb];
+                const double x11 = s11[s][lane], x22 = s22[s][lane], x12 = s12[s][lane];
+                cu = cu - x11 * bu - x12 * bv - x12 * bm * tg;
+                cv = cv - x22 * bv - x12 * bu + x11 * bm * tg;
+            }
+        }
+        d.partU[k] = cu;
+        d.partV[k] = cv;
+    }
+}
+
 // seaice_average_strains_on_vertex (variational.F:684-763): area-weighted mean of the (up to) three corner
 // strains that meet at a vertex, written back to those corners.  A (corner, cell) entry belongs to exactly
 // one vertex, so threads do not collide; sums run in cellsOnVertex order like the reference's.
@@ -837,6 +976,22 @@ static void launchCells(sih_ctx *c, bool last, const int *list, int nList, int m
 {
     dim3 b(256), g = gridFor(list ? nList : c->nCells);
     const SihDev &d = c->dev;
+    if (mode == 0 && c->splitCells) {
+        const int n = list ? nList : c->nCells;
+        dim3 bs(64, M), gs((unsigned)((n + 63) / 64));
+        if (c->sparseGrad) {
+            if (last)
+                hipLaunchKernelGGL((k_sub_cells_split<M, true, true>), gs, bs, 0, c->stream, d, list, nList);
+            else
+                hipLaunchKernelGGL((k_sub_cells_split<M, true, false>), gs, bs, 0, c->stream, d, list, nList);
+        } else {
+            if (last)
+                hipLaunchKernelGGL((k_sub_cells_split<M, false, true>), gs, bs, 0, c->stream, d, list, nList);
+            else
+                hipLaunchKernelGGL((k_sub_cells_split<M, false, false>), gs, bs, 0, c->stream, d, list, nList);
+        }
+        return;
+    }
     if (mode == 1) {
         hipLaunchKernelGGL((k_sub_cells<M, false, false, 1>), g, b, 0, c->stream, d, list, nList);
     } else if (mode == 2) {

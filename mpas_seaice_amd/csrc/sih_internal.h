@@ -70,6 +70,7 @@ struct sih_ctx {
     size_t arenaSize = 0, arenaUsed = 0;
     sih_evp_config cfg{};
     bool inited = false, sparseGrad = false;
+    bool splitCells = false;  // cell kernel with one thread per (cell, corner) instead of one per cell
     double minDvEdge = 0.0;
     SihDev dev{};
     void *d_stage = nullptr;
