@@ -107,6 +107,19 @@ void sih_ir_destroy(sih_ctx *c)
     c->ir = nullptr;
 }
 
+// Blocks are dealt round-robin over the 8 XCDs, each with its own L2, so blocks b and b + 8 share one.
+// A launch over (tile, part) pairs whose `nPart` parts re-read the tile's geometry puts all parts of a tile
+// on one XCD, back to back: linear block id -> (tile, part).  Affinity only; any placement is correct.
+// The grid must hold roundUp(nTile, 8) * nPart blocks; returns false for the padding blocks.
+__device__ inline bool xcdTile(unsigned nTile, unsigned nPart, unsigned &tile, unsigned &part)
+{
+    const unsigned L = blockIdx.x, xcd = L % 8u, j = L / 8u;
+    tile = xcd + 8u * (j / nPart);
+    part = j % nPart;
+    return tile < nTile;
+}
+static inline unsigned xcdGrid(unsigned nTile, unsigned nPart) { return ((nTile + 7u) / 8u) * 8u * nPart; }
+
 // ------------------------------------------------------------------------------------------ helpers
 __device__ inline void unitVector3(double v[3])
 {  // :8900-8918
@@ -553,9 +566,12 @@ __global__ void k_ir_mono_check(IrDev d, const double *__restrict__ val, const i
 template <int M>
 __global__ void __launch_bounds__(256) k_ir_reconstruct(IrDev d, const IrTabEntry *__restrict__ tab, int nT)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    // the categories of one block of cells share its geometry and neighbour lists: one XCD for all of them
+    unsigned cb, ucat;
+    if (!xcdTile((d.nCells + 255u) / 256u, (unsigned)d.nCat, cb, ucat)) return;
+    const int c = cb * blockDim.x + threadIdx.x;
     if (c >= d.nCells) return;
-    const int cat = blockIdx.y;
+    const int cat = (int)ucat;
     const size_t pc = d.padC;
     const bool ice = d.maskCell[c] == 1;
     const int n = d.nEdgesOnCell[c];
@@ -595,13 +611,35 @@ __global__ void __launch_bounds__(256) k_ir_reconstruct(IrDev d, const IrTabEntr
         const IrTabEntry T = tab[ti];
         const bool hasParent = T.parent >= 0;
         const IrTabEntry *P = hasParent ? &tab[T.parent] : nullptr;
+        // masks of make_masks (:3523-3553): the parent value decides; a parent without layers gives the same
+        // answer for every layer of the child, so it is looked up once per tracer
+        const bool sharedMask = hasParent && P->L == 1;
+        bool mcS = true;
+        unsigned mnbS = 0xffffffffu;
+        double pprodS = 1.0, xbS = 0.0, ybS = 0.0;  // likewise the parent's product and barycentre
+        if (sharedMask) {
+            pprodS = P->prod[(size_t)cat * pc + c];
+            xbS = P->xB[(size_t)cat * pc + c];
+            ybS = P->yB[(size_t)cat * pc + c];
+        }
+        if (ice && sharedMask) {
+            const size_t lp1 = (size_t)cat * pc;
+            mcS = P->val[lp1 + c] > EPS11;
+            mnbS = 0;
+#pragma unroll
+            for (int ie = 0; ie < M; ie++)
+                if (ie < n && nb[ie] < d.nCells && P->val[lp1 + nb[ie]] > EPS11) mnbS |= 1u << ie;
+        }
         for (int layer = 0; layer < T.L; layer++) {
             const size_t k = (size_t)(cat * T.L + layer) * pc + c;
             const size_t lp = hasParent ? (size_t)(P->L == 1 ? cat : cat * T.L + layer) * pc : 0;
             const double f = T.val[k];
-            T.prod[k] = (hasParent ? P->prod[lp + c] : 1.0) * f;
+            T.prod[k] = (hasParent ? (sharedMask ? pprodS : P->prod[lp + c]) : 1.0) * f;
             double xb, yb;
-            if (hasParent) {
+            if (sharedMask) {
+                xb = xbS;
+                yb = ybS;
+            } else if (hasParent) {
                 xb = P->xB[lp + c];
                 yb = P->yB[lp + c];
             } else {
@@ -610,14 +648,15 @@ __global__ void __launch_bounds__(256) k_ir_reconstruct(IrDev d, const IrTabEntr
             }
             double gxv = 0.0, gyv = 0.0;
             if (ice) {
-                const bool mc = hasParent ? (P->val[lp + c] > EPS11) : true;
+                const bool mc = !hasParent ? true : (sharedMask ? mcS : (P->val[lp + c] > EPS11));
                 double g0 = 0.0, g1 = 0.0, g2 = 0.0, mx = f, mn = f;
 #pragma unroll
                 for (int ie = 0; ie < M; ie++) {
                     if (ie < n) {
                         double ng = 0.0;
                         if (nb[ie] < d.nCells) {
-                            bool mnb = hasParent ? (P->val[lp + nb[ie]] > EPS11) : true;
+                            bool mnb = !hasParent ? true
+                                                  : (sharedMask ? ((mnbS >> ie) & 1u) != 0 : (P->val[lp + nb[ie]] > EPS11));
                             double fnb = T.val[k - c + nb[ie]];
                             if (mc && mnb) {
                                 double sg = (plus >> ie) & 1u ? 1.0 : -1.0;
@@ -959,11 +998,14 @@ struct IrPlane {
 };
 
 __global__ void __launch_bounds__(256) k_ir_flux_planes(IrDev d, const IrTabEntry *__restrict__ tab,
-                                                        const IrPlane *__restrict__ planes)
+                                                        const IrPlane *__restrict__ planes, int nPlanes)
 {
-    const int e = blockIdx.y * blockDim.x + threadIdx.x;
+    // all plane groups of one block of edges read the same triangles: keep them on one XCD
+    unsigned eb, pi;
+    if (!xcdTile((d.nEdges + 255u) / 256u, (unsigned)nPlanes, eb, pi)) return;
+    const int e = eb * blockDim.x + threadIdx.x;
     if (e >= d.nEdges) return;
-    const IrPlane pl = planes[blockIdx.x];
+    const IrPlane pl = planes[pi];
     const IrTabEntry T = tab[pl.ti];
     const int cat = pl.cat, layer0 = pl.layer0;
     const int nl = min(IR_LCHUNK, T.L - layer0);
@@ -1479,7 +1521,8 @@ static void launchCellKernels(sih_ir_state *ir, hipStream_t s, bool update)
     IrDev &d = ir->d;
     const int nT = (int)ir->tracers.size();
     if (!update)
-        hipLaunchKernelGGL(k_ir_reconstruct<M>, dim3((d.nCells + 255) / 256, d.nCat), dim3(256), 0, s, d, ir->d_tab, nT);
+        hipLaunchKernelGGL(k_ir_reconstruct<M>, dim3(xcdGrid((d.nCells + 255) / 256, d.nCat)), dim3(256), 0, s, d,
+                           ir->d_tab, nT);
     else
         hipLaunchKernelGGL(k_ir_update<M>, dim3((d.nCellsSolve + 255) / 256, d.nCat), dim3(256), 0, s, d, ir->d_tab,
                            nT);
@@ -1598,7 +1641,8 @@ static int irRun(sih_ctx *c, double dt, int checks, bool timed, double *totalMs,
     hipLaunchKernelGGL(k_ir_triangles, dim3((d.nEdges + 127) / 128), dim3(128), 0, s, d);
     mark(3);
     if (ir->fluxMode == 1)
-        hipLaunchKernelGGL(k_ir_flux_planes, dim3(ir->nPlanes, gE), blk, 0, s, d, ir->d_tab, ir->d_planes);
+        hipLaunchKernelGGL(k_ir_flux_planes, dim3(xcdGrid(gE, ir->nPlanes)), blk, 0, s, d, ir->d_tab, ir->d_planes,
+                           ir->nPlanes);
     else
         hipLaunchKernelGGL(k_ir_flux, dim3(gE, d.nCat), blk, 0, s, d, ir->d_tab, nT);
     mark(4);
