@@ -119,7 +119,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mesh", default="QU60")
+    ap.add_argument("--mesh", default="QU60", help="QU480/QU240/QU120/QU60/QU30, or an MPAS grid file (*.nc)")
+    ap.add_argument("--partition-file", default=None, help="METIS graph.info.part.N for --gpus N (default: "
+                    "cut along a space-filling curve)")
     ap.add_argument("--subcycles", type=int, default=120)
     ap.add_argument("--graph", type=int, default=int(os.environ.get("SIH_BENCH_GRAPH", "0")))
     ap.add_argument("--sample-every", type=int, default=8)
@@ -141,7 +143,16 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    mesh = meshmod.make_named_mesh(args.mesh)
+    cell_owner = None
+    mesh_label = os.path.basename(args.mesh)
+    if args.mesh.endswith(".nc"):
+        from mpas_seaice_amd import mesh_io
+        mesh = mesh_io.read_mpas_mesh(args.mesh, earth_radius=6371229.0)
+        args.mesh = None  # idealised state from latitude / longitude only
+        if args.partition_file:
+            cell_owner = mesh_io.read_graph_partition(args.partition_file, mesh.nCells)
+    else:
+        mesh = meshmod.make_named_mesh(args.mesh)
     nsub = args.subcycles
     M = int(mesh.maxEdges)
     advection = None
@@ -193,7 +204,7 @@ def main():
     else:
         from mpas_seaice_amd import parallel
         res = parallel.bench_multi_gpu(mesh, args.mesh, nsub, args.steps, args.warmup, local_rank,
-                                       renumber=not args.no_renumber)
+                                       renumber=not args.no_renumber, cell_owner=cell_owner)
         wall, pre_ms, post_ms, cell_ms, vert_ms, n_cells_total = (res[k] for k in (
             "wall", "pre_ms", "post_ms", "cell_ms", "vert_ms", "n_cells_total"))
         parallelism = (f"{world} MPAS blocks, one per GPU, {res['interval']} halo layers, RCCL exchange of "
@@ -220,7 +231,7 @@ def main():
         "metric": "EVP cell-subcycle-updates/sec at QU60", "value": value, "unit": "cell-subcycle-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.mesh} full-sphere mesh ({n_cells_total} cells, maxEdges {M}), "
+        "config": {"workload": f"{mesh_label} full-sphere mesh ({n_cells_total} cells, maxEdges {M}), "
                                f"{nsub} EVP subcycles per step, variational Wachspress operators, idealised forcing",
                    "parallelism": parallelism, "hip_graph": bool(args.graph)},
         "roofline": {"bound": "hbm", "kernel": "k_sub_cells_split (fused strain + EVP stress + stress-divergence partial sums, one thread per cell corner)",

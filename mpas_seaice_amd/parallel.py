@@ -371,10 +371,12 @@ class DistComm(CommBase):
 
 
 # ----------------------------------------------------------------------------------------------
-def make_partitioned_domain(mesh, name, nblocks, configs=None, only_block=None, **case_kw):
-    """Domain holding all blocks of the partition (only_block=None) or just one of them."""
+def make_partitioned_domain(mesh, name, nblocks, configs=None, only_block=None, cell_owner=None, **case_kw):
+    """Domain holding all blocks of the partition (only_block=None) or just one of them.  ``cell_owner``:
+    block of every cell, e.g. from a METIS ``graph.info.part.N`` file (mesh_io.read_graph_partition);
+    default is a cut along a space-filling curve."""
     num_halos = int((configs or {}).get("config_num_halos", 2))
-    meshes, halos = partition_mesh(mesh, nblocks, num_halos=num_halos)
+    meshes, halos = partition_mesh(mesh, nblocks, num_halos=num_halos, cell_owner=cell_owner)
     if only_block is not None:
         dom = cases.make_domain([meshes[only_block]], name, configs=configs, **case_kw)
         return dom, halos[only_block], halos
@@ -400,7 +402,7 @@ def oracle_halo_callback(comm):
     return halo
 
 
-def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, interval=None):
+def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, interval=None, cell_owner=None):
     """One block per rank over RCCL: K steps of nsub subcycles; halos are `interval` layers deep and are
     exchanged every `interval` subcycles (uVelocity, vVelocity, stress11/22/12)."""
     import os
@@ -430,7 +432,7 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
     overlap = os.environ.get("SIH_OVERLAP", "1") != "0"
     cfg = {"config_elastic_subcycle_number": nsub, "config_num_halos": max(2, interval),
            "config_halo_exchange_interval": interval, "config_overlap_halo_exchange": overlap}
-    dom, halo, _ = make_partitioned_domain(mesh, name, world, configs=cfg, only_block=rank)
+    dom, halo, _ = make_partitioned_domain(mesh, name, world, configs=cfg, only_block=rank, cell_owner=cell_owner)
     vs.seaice_mesh_pool_create(dom, device=local_rank, renumber=renumber)
     ctx = dom.blocklist[0].ctx
     dom.comm = DistComm(dom, halo, world, rank)  # also moves the block onto torch's (explicit) current stream
