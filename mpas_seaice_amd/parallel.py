@@ -413,8 +413,11 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
 
     from . import velocity_solver as vs
     if interval is None:
-        # more ranks -> smaller blocks -> the exchange latency weighs more: deeper halos, fewer exchanges
-        default = 4 if int(os.environ.get("WORLD_SIZE", "1")) <= 2 else 8
+        # more ranks -> smaller blocks -> the exchange latency weighs more: deeper halos, fewer exchanges.
+        # Measured on one GPU (scripts/bench_block.py, QU60): a block of an 8-way partition needs 14.6 us per
+        # subcycle with 8 halo layers and 16.0 us with 16, pack + unpack cost 10 us per exchange; with a
+        # collective of 25 us or more per exchange the deeper halo wins at 8 ranks and 8 layers at 2 and 4.
+        default = 16 if int(os.environ.get("WORLD_SIZE", "1")) >= 8 else 8
         interval = int(os.environ.get("SIH_HALO_INTERVAL", str(default)))
     use_graph = os.environ.get("SIH_MULTI_GRAPH", "1") != "0"
     backend = os.environ.get("SIH_DIST_BACKEND", "nccl")  # "gloo" only for rehearsals on a box with one GPU
@@ -429,7 +432,9 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
         dist.all_reduce(t, op=op)
         return float(t.item())
     rank, world = dist.get_rank(), dist.get_world_size()
-    overlap = os.environ.get("SIH_OVERLAP", "1") != "0"
+    # the overlapped order costs two more launches per exchange (rim cells, send vertices: 11-14 us on a
+    # 25 k-cell block) and can hide at most the 13 us its interior pieces take: off unless asked for
+    overlap = os.environ.get("SIH_OVERLAP", "0") != "0"
     cfg = {"config_elastic_subcycle_number": nsub, "config_num_halos": max(2, interval),
            "config_halo_exchange_interval": interval, "config_overlap_halo_exchange": overlap}
     dom, halo, _ = make_partitioned_domain(mesh, name, world, configs=cfg, only_block=rank, cell_owner=cell_owner)
