@@ -164,6 +164,9 @@ def main():
         ctx = dom.blocklist[0].ctx
         for b in dom.blocklist:
             vs._upload(dom, b)
+        vs.velocity_solver_pre_subcycle(dom)  # first call: code objects are loaded on first launch
+        for b in dom.blocklist:
+            vs._upload(dom, b)  # same inputs again, so that the timed call starts from the same state
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         vs.velocity_solver_pre_subcycle(dom)
