@@ -299,7 +299,11 @@ int sih_ir_get_sums(sih_ctx *ctx, const char *tracer, double *initSums, double *
  * (phases: 0 conversion+masks, 1 reconstruction, 2 departure triangles, 3 fluxes, 4 update+zap) */
 int sih_ir_run_timed(sih_ctx *ctx, double dt, double *totalMs, double *phaseMs5);
 
-/* introspection for tests and reports */
+/* introspection for tests and reports.  Keys: sparseGradient, splitCellKernel, dampingTimescale,
+ * elasticTimeStep, dynamicsTimeStep, numericalInertiaCoefficient, padC, padV, minDvEdge, and
+ * irCflWarnings: number of vertices whose departure distance in the last sih_ir_run exceeded the
+ * shortest adjacent edge (the reference logs "Potential CFL violation in IR advection" and continues,
+ * incremental_remap.F:5330-5345). */
 int sih_get_info(sih_ctx *ctx, const char *key, double *value);
 
 #ifdef __cplusplus

@@ -116,6 +116,7 @@ SihField *sih_find_field(sih_ctx *c, const char *name);
 int sih_add_field(sih_ctx *c, const char *name, SihLoc loc, int lead, bool isInt);
 int sih_dev_alloc(sih_ctx *c, void **p, size_t bytes);
 void sih_ir_destroy(sih_ctx *c);
+int sih_ir_cfl_warnings(sih_ctx *c);
 int sih_hip_fail(hipError_t e, const char *what, const char *file, int line);
 #define HIPCHK(x)                                                             \
     do {                                                                      \

@@ -280,3 +280,25 @@ def test_monotonicity_violation_is_reported(oracle):
         ctx.ir_run(dt, False, False)  # the context is usable again
     finally:
         vs.seaice_mesh_pool_destroy(dom)
+
+
+def test_cfl_warning_count(oracle):
+    """find_departure_points (:5325-5345) only warns when a trajectory is longer than the shortest edge at
+    the vertex; the library reports how many vertices that happened at."""
+    ir = _ir()
+    dom, ref = make_pair(oracle, "hex_12_10", None, configs={"config_dt": 600.0})
+    try:
+        for d in (dom, ref):
+            vsol = d.blocklist[0].structs["velocity_solver"]
+            vsol["uVelocity"][:] = 0.0
+            vsol["vVelocity"][:] = 0.0
+            vsol["uVelocity"][5:9] = 1.0e3  # 600 s * 1 km/s = 600 km against ~60 km edges
+        diag = {}
+        ir.seaice_run_advection(ref, diagnostics=diag)
+        try:
+            adv.seaice_run_advection(dom)
+        except Exception:
+            pass  # such a flow may also trip the remap's own aborts; the count is set before them
+        assert int(dom.blocklist[0].ctx.info("irCflWarnings")) == diag["cflWarnings"] == 4
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
