@@ -41,6 +41,7 @@ module seaice_hip_interface
      integer(c_int32_t) :: computeHaloVertices
      integer(c_int32_t) :: averageVariationalStrain = 0
      integer(c_int32_t) :: useSpecialBoundariesVelocity = 0, useSpecialBoundariesVelocityMasks = 0
+     integer(c_int32_t) :: strainScheme = 0, stressDivergenceScheme = 0   ! 0 variational, 1 weak
   end type sih_evp_config
 
   !> struct sih_ir_desc
@@ -96,6 +97,14 @@ module seaice_hip_interface
        type(c_ptr), value :: ctx
        integer(c_int) :: ierr
      end function sih_evp_static_changed
+
+     ! edge description of the mesh for the weak scheme (before sih_evp_init)
+     function sih_evp_set_edge_mesh(ctx, edges) bind(C, name="sih_evp_set_edge_mesh") result(ierr)
+       import :: sih_ir_desc, c_int, c_ptr
+       type(c_ptr), value :: ctx
+       type(sih_ir_desc), intent(in) :: edges
+       integer(c_int) :: ierr
+     end function sih_evp_set_edge_mesh
 
      ! arrays of the special_boundaries pool (c_loc; c_null_ptr for a part that is switched off)
      function sih_evp_set_special_boundaries(ctx, vertexBoundaryType, vertexBoundarySourceLocal, &

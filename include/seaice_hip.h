@@ -102,6 +102,9 @@ typedef struct sih_evp_config {
     int32_t averageVariationalStrain; /* config_average_variational_strain (velocity_solver.F:2756-2766) */
     int32_t useSpecialBoundariesVelocity;      /* config_use_special_boundaries_velocity */
     int32_t useSpecialBoundariesVelocityMasks; /* config_use_special_boundaries_velocity_masks */
+    int32_t strainScheme;             /* config_strain_scheme: 0 variational, 1 weak */
+    int32_t stressDivergenceScheme;   /* config_stress_divergence_scheme: 0 variational, 1 weak; the two must
+                                         agree (the mixed schemes of velocity_solver.F:2768-2784 are not built) */
 } sih_evp_config;
 
 /* ---- life cycle ----------------------------------------------------------------------------- */
@@ -116,6 +119,12 @@ int sih_set_stream(sih_ctx *ctx, void *hipStream);
 int sih_sync(sih_ctx *ctx);
 
 /* ---- initialisation ------------------------------------------------------------------------- */
+/* Edge description of the mesh for the weak scheme (velocity_solver_weak.F; its normal vectors
+ * mesh.F:703-1606 need edge positions and the edge <-> cell / vertex connectivity): the same struct the
+ * advection takes; nCategories and rotateCartesianGrid are ignored here.  Call before sih_evp_init when
+ * sih_evp_config.strainScheme = 1; arrays are copied. */
+struct sih_ir_desc;
+int sih_evp_set_edge_mesh(sih_ctx *ctx, const struct sih_ir_desc *edges);
 /* replaces the per-block part of seaice_init_velocity_solver (velocity_solver.F:85-252) and
  * interior_vertices (mesh.F:423): time steps, EVP constants, metric terms, cellVerticesAtVertex,
  * local coordinates, Wachspress basis gradients/integrals, variational denominator. */

@@ -625,6 +625,14 @@ extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
         sih_set_error("Unknown variational denominator type");
         return SIH_ERR_ARG;
     }
+    if (cfg->strainScheme != cfg->stressDivergenceScheme || cfg->strainScheme < 0 || cfg->strainScheme > 1) {
+        sih_set_error("config_strain_scheme / config_stress_divergence_scheme: both 'variational' or both 'weak'");
+        return SIH_ERR_UNSUPPORTED;
+    }
+    if (cfg->strainScheme == 1 && (cfg->computeHaloVertices || cfg->averageVariationalStrain)) {
+        sih_set_error("the weak scheme has no redundant halo update and no strain averaging");
+        return SIH_ERR_UNSUPPORTED;
+    }
     if (cfg->computeHaloVertices && (cfg->averageVariationalStrain || cfg->useSpecialBoundariesVelocity)) {
         sih_set_error("computeHaloVertices: not together with strain averaging or special boundaries "
                       "(their loops cover owned or source vertices only)");
@@ -661,6 +669,7 @@ extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
     HIPCHK(hipGetLastError());
     int rc = packStatic(c, a);
     if (rc) return rc;
+    if (cfg->strainScheme == 1 && (rc = sih_weak_init(c))) return rc;
     // time steps and EVP constants: velocity_solver.F:155-157, constitutive_relation.F:125, 158-159
     double dtDyn = cfg->dt / (double)cfg->dynamicsSubcycleNumber;
     double dtE = dtDyn / (double)cfg->elasticSubcycleNumber;
@@ -678,6 +687,7 @@ extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
     c->dev.dtE = dtE;
     c->dev.dampT = 0.36 * dtDyn;
     c->dev.brlx = dv > 0.0 ? (2.0 * 0.86 * 5.5e-3 * gamma) / (dv * dv) : 0.0;
+    if (cfg->strainScheme == 1) sih_weak_bind(c);
     if (cfg->constitutiveRelation == 2 && !(dv > 0.0)) {
         sih_set_error("evp_revised needs dvEdge (minEdgeLengthGlobal)");
         return SIH_ERR_ARG;

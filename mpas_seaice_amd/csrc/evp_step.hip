@@ -726,7 +726,8 @@ __global__ void k_sb_masks(SihDev d, const int *__restrict__ maskV, const int *_
 // Fused vertex kernel: outer sum and division of seaice_stress_divergence_variational
 // (variational.F:1139-1178), ocean_stress_coefficient (velocity_solver.F:2986-3082) and solve_velocity
 // (:3096-3208) or solve_velocity_revised (:3222-3342).
-template <bool LAST>
+// PREDIV: the stress divergence was computed by another kernel (weak scheme) and is read from divU / divV
+template <bool LAST, bool PREDIV>
 __global__ void __launch_bounds__(256) k_sub_vertices(SihDev d, const int *__restrict__ list, int nList)
 {
     int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -747,15 +748,20 @@ __global__ void __launch_bounds__(256) k_sub_vertices(SihDev d, const int *__res
     }
     const int PV = d.padV;
     double dU = 0.0, dV = 0.0;
+    if (PREDIV) {
+        dU = d.divU[v];
+        dV = d.divV[v];
+    } else {
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        int g = d.gidx[k * PV + v];
-        dU = dU + d.partU[g];
-        dV = dV + d.partV[g];
+        for (int k = 0; k < 3; k++) {
+            int g = d.gidx[k * PV + v];
+            dU = dU + d.partU[g];
+            dV = dV + d.partV[g];
+        }
+        const double den0 = d.varDenom[v];
+        dU = dU / den0;
+        dV = dV / den0;
     }
-    const double den0 = d.varDenom[v];
-    dU = dU / den0;
-    dV = dV / den0;
     double uu = d.u[v], vv = d.v[v];
     const double uo = d.uOcnVert[v], vo = d.vOcnVert[v];
     double coeff = 0.0;
@@ -965,6 +971,7 @@ extern "C" int sih_evp_pre_subcycle(sih_ctx *c, int stage)
     if (stage == -1 || stage == 4) {
         hipLaunchKernelGGL(k_pre4_vertices, gv, b, 0, s, d);
         hipLaunchKernelGGL(k_pre4_cells, gc, b, 0, s, d);
+        if (c->cfg.strainScheme == 1) sih_weak_launch_pre(c);
     }
     if (stage == -1 || stage == 4) c->sbPending = c->sbVelocity || c->sbMasks;
     HIPCHK(hipGetLastError());
@@ -1032,6 +1039,10 @@ static void launchCellKernel(sih_ctx *c, bool last, int subset = -1)
     const int *list = subset >= 0 ? c->d_part[subset] : nullptr;
     const int nList = subset >= 0 ? c->nPart[subset] : 0;
     if (subset >= 0 && nList == 0) return;
+    if (c->cfg.strainScheme == 1) {  // weak scheme: strain + stress per cell, then the divergence at every vertex
+        sih_weak_launch_cells(c);
+        return;
+    }
     if (c->cfg.averageVariationalStrain) {  // whole block only (checked where subsets are set up)
         launchCellsM(c, last, nullptr, 0, 1);
         hipLaunchKernelGGL(k_avg_strain_vertices, gridFor(c->nVerticesSolve), dim3(256), 0, c->stream, c->dev);
@@ -1067,10 +1078,15 @@ static void launchVertexKernel(sih_ctx *c, bool last, int subset = -1)
     const int nList = subset >= 0 ? c->nPart[subset] : 0;
     if (subset >= 0 && nList == 0) return;
     dim3 b(256), g = gridFor(list ? nList : (c->cfg.computeHaloVertices ? c->nVertices : c->nVerticesSolve));
-    if (last)
-        hipLaunchKernelGGL(k_sub_vertices<true>, g, b, 0, c->stream, c->dev, list, nList);
+    if (c->cfg.strainScheme == 1) {
+        if (last)
+            hipLaunchKernelGGL((k_sub_vertices<true, true>), g, b, 0, c->stream, c->dev, list, nList);
+        else
+            hipLaunchKernelGGL((k_sub_vertices<false, true>), g, b, 0, c->stream, c->dev, list, nList);
+    } else if (last)
+        hipLaunchKernelGGL((k_sub_vertices<true, false>), g, b, 0, c->stream, c->dev, list, nList);
     else
-        hipLaunchKernelGGL(k_sub_vertices<false>, g, b, 0, c->stream, c->dev, list, nList);
+        hipLaunchKernelGGL((k_sub_vertices<false, false>), g, b, 0, c->stream, c->dev, list, nList);
     applySpecialBoundaryVelocity(c);  // velocity_solver.F:2454-2456
 }
 
@@ -1103,7 +1119,10 @@ extern "C" int sih_evp_post_subcycle(sih_ctx *c, int stage)
     const SihDev &d = c->dev;
     dim3 b(256), gc = gridFor(c->nCells), gv = gridFor(c->nVertices);
     if (stage == -1 || stage == 0) {
-        hipLaunchKernelGGL(k_post0_cells, gc, b, 0, c->stream, d);
+        if (c->cfg.strainScheme == 1)
+            sih_weak_launch_post(c);  // velocity_solver.F:3416-3418, 3497-3516
+        else
+            hipLaunchKernelGGL(k_post0_cells, gc, b, 0, c->stream, d);
         hipLaunchKernelGGL(k_post0_vertices, gv, b, 0, c->stream, d);
     }
     if (stage == -1 || stage == 1) {
@@ -1265,8 +1284,9 @@ extern "C" int sih_evp_overlap_setup(sih_ctx *c)
 {
     int rc = checkInit(c, "sih_evp_overlap_setup");
     if (rc) return rc;
-    if (c->cfg.averageVariationalStrain || c->sbVelocity) {
-        sih_set_error("sih_evp_overlap_setup: strain averaging and special boundaries need whole-block loops");
+    if (c->cfg.averageVariationalStrain || c->sbVelocity || c->cfg.strainScheme == 1) {
+        sih_set_error("sih_evp_overlap_setup: strain averaging, special boundaries and the weak scheme need "
+                      "whole-block loops");
         return SIH_ERR_UNSUPPORTED;
     }
     HIPCHK(hipSetDevice(c->device));

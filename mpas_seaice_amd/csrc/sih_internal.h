@@ -64,6 +64,7 @@ struct sih_ctx {
     std::vector<int> edgePerm, edgeInv;                      // filled by sih_ir_init (identity until then)
     int *d_cellPerm = nullptr, *d_vertPerm = nullptr, *d_edgePerm = nullptr;
     struct sih_ir_state *ir = nullptr;                       // incremental-remap advection state
+    struct sih_weak_state *weak = nullptr;                   // weak strain / stress-divergence scheme
     std::map<std::string, SihField> fields;
     std::vector<void *> allocs;
     char *arenaBase = nullptr;  // current chunk of the device arena
@@ -116,6 +117,12 @@ SihField *sih_find_field(sih_ctx *c, const char *name);
 int sih_add_field(sih_ctx *c, const char *name, SihLoc loc, int lead, bool isInt);
 int sih_dev_alloc(sih_ctx *c, void **p, size_t bytes);
 void sih_ir_destroy(sih_ctx *c);
+void sih_weak_destroy(sih_ctx *c);
+int sih_weak_init(sih_ctx *c);
+void sih_weak_bind(sih_ctx *c);
+void sih_weak_launch_pre(sih_ctx *c);
+void sih_weak_launch_cells(sih_ctx *c);
+void sih_weak_launch_post(sih_ctx *c);
 int sih_ir_cfl_warnings(sih_ctx *c);
 int sih_hip_fail(hipError_t e, const char *what, const char *file, int line);
 #define HIPCHK(x)                                                             \

@@ -51,6 +51,7 @@ class EvpConfig(ctypes.Structure):
         ("nCategories", ctypes.c_int32), ("minEdgeLengthGlobal", ctypes.c_double),
         ("computeHaloVertices", ctypes.c_int32), ("averageVariationalStrain", ctypes.c_int32),
         ("useSpecialBoundariesVelocity", ctypes.c_int32), ("useSpecialBoundariesVelocityMasks", ctypes.c_int32),
+        ("strainScheme", ctypes.c_int32), ("stressDivergenceScheme", ctypes.c_int32),
     ]
 
 
@@ -71,7 +72,7 @@ EXPORTS = [
     "sih_evp_subcycle_timed", "sih_evp_subcycle_graph", "sih_halo_set_lists", "sih_halo_pack", "sih_halo_unpack", "sih_get_info",
     "sih_ir_init", "sih_ir_set_tracers", "sih_ir_run", "sih_ir_get_sums", "sih_ir_run_timed",
     "sih_fields_put", "sih_fields_get", "sih_evp_overlap_setup", "sih_evp_subcycle_parts",
-    "sih_evp_set_special_boundaries", "sih_ir_check_monotonicity",
+    "sih_evp_set_special_boundaries", "sih_ir_check_monotonicity", "sih_evp_set_edge_mesh",
 ]
 
 
@@ -127,6 +128,7 @@ def load():
                                     ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
     lib.sih_get_info.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]
     lib.sih_ir_init.argtypes = [ctypes.c_void_p, ctypes.POINTER(IrDesc)]
+    lib.sih_evp_set_edge_mesh.argtypes = [ctypes.c_void_p, ctypes.POINTER(IrDesc)]
     lib.sih_ir_set_tracers.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
                                        ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
     lib.sih_ir_run.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int]
@@ -321,7 +323,8 @@ class BlockContext:
                                         ctypes.c_void_p(device_ptr)), "sih_halo_unpack")
 
     # -- incremental remap ---------------------------------------------------------------------
-    def ir_init(self, mesh_pool, nCategories, rotate):
+    @staticmethod
+    def _edge_desc(mesh_pool):
         d = IrDesc()
         for k in ("edgesOnCell", "cellsOnEdge", "verticesOnEdge", "edgesOnVertex"):
             a = mesh_pool[k]
@@ -331,6 +334,15 @@ class BlockContext:
             a = mesh_pool[k]
             assert a.dtype == np.float64, k
             setattr(d, k, _ptr(a))
+        return d
+
+    def set_edge_mesh(self, mesh_pool):
+        """edge positions and connectivity for the weak scheme (before evp_init)"""
+        d = self._edge_desc(mesh_pool)
+        check(self._lib.sih_evp_set_edge_mesh(self.handle, ctypes.byref(d)), "sih_evp_set_edge_mesh")
+
+    def ir_init(self, mesh_pool, nCategories, rotate):
+        d = self._edge_desc(mesh_pool)
         a = mesh_pool["coeffs_reconstruct"]
         assert a.dtype == np.float64 and a.flags["F_CONTIGUOUS"]
         d.coeffsReconstruct = _ptr(a)

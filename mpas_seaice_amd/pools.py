@@ -164,6 +164,14 @@ class Block:
         vv["cellVerticesAtVertex"] = iv(D)
         self.structs["velocity_variational"] = vv
 
+        # velocity_weak pool (Registry.xml:3730-3744; keys are the name_in_code values)
+        vw = {"normalVectorPolygon": rc(2, M), "normalVectorTriangle": rv(2, D), "latCellRotated": rc(),
+              "latVertexRotated": rv()}
+        for k in ("strain11", "strain22", "strain12", "stress11", "stress22", "stress12", "principalStress1",
+                  "principalStress2", "replacementPressure"):
+            vw[k] = rc()
+        self.structs["velocity_weak"] = vw
+
         self.structs["icestate"] = {k: (rv() if "Vertex" in k else rc()) for k in (
             "iceAreaVertex", "totalMassVertex", "iceAreaCellInitial", "totalMassCell", "openWaterArea")}
         self.structs["tracers_aggregate"] = {k: rc() for k in ("iceAreaCell", "iceVolumeCell", "snowVolumeCell")}

@@ -58,6 +58,31 @@ STATIC_OUTPUTS = [
     "basisIntegralsU", "basisIntegralsV", "basisIntegralsMetric", "variationalDenominator")]
 
 
+# velocity_weak pool: pool key (Registry name_in_code) -> device field (Registry name), Registry.xml:3730-3744
+WEAK_FIELDS = {"strain11": "strain11weak", "strain22": "strain22weak", "strain12": "strain12weak",
+               "stress11": "stress11weak", "stress22": "stress22weak", "stress12": "stress12weak",
+               "principalStress1": "principalStress1Weak", "principalStress2": "principalStress2Weak",
+               "replacementPressure": "replacementPressureWeak"}
+WEAK_STATIC = ("normalVectorPolygon", "normalVectorTriangle", "latCellRotated", "latVertexRotated")
+
+
+def _weak(domain):
+    return domain.configs["config_strain_scheme"] == "weak"
+
+
+def _items(domain, b, pairs):
+    """(device field, host array) for (pool, key) pairs; with the weak scheme the per-corner fields of the
+    velocity_variational pool give way to the per-cell ones of the velocity_weak pool"""
+    out = []
+    for pool, name in pairs:
+        if _weak(domain) and pool == "velocity_variational":
+            if name in WEAK_FIELDS:
+                out.append((WEAK_FIELDS[name], b.structs["velocity_weak"][name]))
+            continue
+        out.append((name, b.structs[pool][name]))
+    return out
+
+
 def _evp_config(domain, block):
     cfg = domain.configs
     c = _lib.EvpConfig()
@@ -68,8 +93,12 @@ def _evp_config(domain, block):
     if rel not in RELATION:
         raise _lib.SeaiceHipError("config_constitutive_relation_type unknown: " + str(rel))
     c.constitutiveRelation = RELATION[rel]
-    if cfg["config_strain_scheme"] != "variational" or cfg["config_stress_divergence_scheme"] != "variational":
-        raise _lib.SeaiceHipError("only the variational strain / stress-divergence schemes are implemented")
+    schemes = {"variational": 0, "weak": 1}
+    for key in ("config_strain_scheme", "config_stress_divergence_scheme"):
+        if cfg[key] not in schemes:
+            raise _lib.SeaiceHipError(f"{key} unknown: {cfg[key]}")
+    c.strainScheme = schemes[cfg["config_strain_scheme"]]
+    c.stressDivergenceScheme = schemes[cfg["config_stress_divergence_scheme"]]
     c.averageVariationalStrain = int(bool(cfg["config_average_variational_strain"]))
     c.useSpecialBoundariesVelocity = int(bool(cfg["config_use_special_boundaries_velocity"]))
     c.useSpecialBoundariesVelocityMasks = int(bool(cfg["config_use_special_boundaries_velocity_masks"]))
@@ -140,6 +169,8 @@ def seaice_init_velocity_solver(domain):
         vs["elasticTimeStep"][0] = vs["dynamicsTimeStep"][0] / float(cfg["config_elastic_subcycle_number"])
         if not cfg["config_use_velocity_solver"]:
             continue
+        if _weak(domain):
+            b.ctx.set_edge_mesh(b.structs["mesh"])
         b.ctx.evp_init(_evp_config(domain, b))
         if cfg["config_variational_basis"] == "none":
             vv = b.structs["velocity_variational"]
@@ -148,6 +179,9 @@ def seaice_init_velocity_solver(domain):
             b.ctx.static_changed()
         for pool, name in STATIC_OUTPUTS:
             b.ctx.get(name, b.structs[pool][name])
+        if _weak(domain):
+            for name in WEAK_STATIC:
+                b.ctx.get(name, b.structs["velocity_weak"][name])
     if cfg["config_use_velocity_solver"]:
         # seaice_init calls this before the solver's init (mpas_seaice_initialize.F:91); the device lists need
         # the initialised context, so it runs here
@@ -169,14 +203,14 @@ def _upload(domain, b):
         items += [("ocean_coupling", "seaSurfaceTiltU"), ("ocean_coupling", "seaSurfaceTiltV")]
     if not cfg["config_calc_velocity_masks"]:
         items += [("velocity_solver", "solveStress"), ("velocity_solver", "solveVelocity")]
-    b.ctx.put_many((name, b.structs[pool][name]) for pool, name in items)
+    b.ctx.put_many(_items(domain, b, items))
 
 
 def _download(domain, b):
     items = list(RUN_OUTPUTS)
     if domain.configs["config_use_column_package"]:
         items += [("ridging", "ridgeConvergence"), ("ridging", "ridgeShear")]
-    b.ctx.get_many((name, b.structs[pool][name]) for pool, name in items)
+    b.ctx.get_many(_items(domain, b, items))
 
 
 def velocity_solver_pre_subcycle(domain):

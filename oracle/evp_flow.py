@@ -84,6 +84,16 @@ def halo_needed(domain):
     return getattr(domain, "halo", None) is not None and domain.configs["config_use_halo_exch"]
 
 
+def weak_scheme(cfg):
+    """velocity_solver.F:169-187: both schemes 'variational' (default) or both 'weak'; the mixed ones
+    (weak strain interpolated to the variational divergence, :2768-2784) are not restated."""
+    pair = (cfg["config_strain_scheme"], cfg["config_stress_divergence_scheme"])
+    if pair == ("weak", "weak"):
+        return True
+    assert pair == ("variational", "variational"), pair
+    return False
+
+
 def seaice_init_velocity_solver(domain):
     cfg = domain.configs
     st = domain.solver_state
@@ -133,6 +143,15 @@ def seaice_init_velocity_solver(domain):
              m["areaTriangle"], m["cellsOnVertex"], vv["cellVerticesAtVertex"], vv["basisIntegralsMetric"],
              cfg["config_variational_denominator_type"] == "alternate")
         b._xLocal, b._yLocal = xl, yl
+        if weak_scheme(cfg):  # seaice_init_velocity_solver_weak, velocity_solver_weak.F:48-94
+            vw = b.structs["velocity_weak"]
+            iv = b.structs["boundary"]["interiorVertex"]
+            geo = (m["xCell"], m["yCell"], m["zCell"], m["xEdge"], m["yEdge"], m["zEdge"], m["xVertex"], m["yVertex"],
+                   m["zVertex"], float(m["sphere_radius"]), bool(m["on_a_sphere"]), rot, True)
+            call("ora_normal_vectors_polygon", nC, M, m["nEdgesOnCell"], m["edgesOnCell"], m["verticesOnEdge"],
+                 m["cellsOnEdge"], *geo, vw["normalVectorPolygon"], vw["latCellRotated"])
+            call("ora_normal_vectors_triangle", nV, d["nVerticesSolve"], D, m["edgesOnVertex"], m["cellsOnEdge"],
+                 m["verticesOnEdge"], iv, *geo, vw["normalVectorTriangle"], vw["latVertexRotated"])
 
 
 # ------------------------------------------------------------------------------------ run
@@ -229,6 +248,13 @@ def velocity_solver_pre_subcycle(domain):
              vs["seaSurfaceTiltVertexU"], vs["seaSurfaceTiltVertexV"], vs["surfaceTiltForceU"],
              vs["surfaceTiltForceV"])
         vv = b.structs["velocity_variational"]
+        if weak_scheme(cfg):  # velocity_solver.F:2347-2380: the same with one value per cell
+            vw = b.structs["velocity_weak"]
+            call("ora_init_subcycle_variables", d["nCells"] + 1, d["nVerticesSolve"], d["nVertices"] + 1, 1,
+                 _pad_mask(vs["solveStress"]), vs["solveVelocity"], vs["stressDivergenceU"], vs["stressDivergenceV"],
+                 vs["uVelocity"], vs["vVelocity"], vs["oceanStressCoeff"], vw["strain11"], vw["strain22"],
+                 vw["strain12"], vw["stress11"], vw["stress22"], vw["stress12"])
+            continue
         call("ora_init_subcycle_variables", d["nCells"] + 1, d["nVerticesSolve"], d["nVertices"] + 1, d["maxEdges"],
              _pad_mask(vs["solveStress"]), vs["solveVelocity"], vs["stressDivergenceU"], vs["stressDivergenceV"],
              vs["uVelocity"], vs["vVelocity"], vs["oceanStressCoeff"], vv["strain11"], vv["strain22"],
@@ -237,6 +263,33 @@ def velocity_solver_pre_subcycle(domain):
 
 def _pad_mask(a):
     return a
+
+
+def _subcycle_args_weak(domain, b):
+    cfg, st = domain.configs, domain.solver_state
+    d = b.dimensions
+    m, vs, vw, ic = b.structs["mesh"], b.structs["velocity_solver"], b.structs["velocity_weak"], b.structs["icestate"]
+    return (d["nCells"], d["nVerticesSolve"], d["nVertices"], d["maxEdges"], d["vertexDegree"],
+            m["nEdgesOnCell"], m["verticesOnCell"], m["edgesOnCell"], m["verticesOnEdge"], m["cellsOnVertex"],
+            m["edgesOnVertex"], m["cellsOnEdge"], m["dvEdge"], m["dcEdge"], m["areaCell"], m["areaTriangle"],
+            float(m["sphere_radius"]) if m["on_a_sphere"] else 0.0, vs["solveStress"], vs["solveVelocity"],
+            vw["normalVectorPolygon"], vw["normalVectorTriangle"], vw["latCellRotated"], vw["latVertexRotated"],
+            vs["icePressure"], ic["totalMassVertex"], vs["totalMassVertexfVertex"], ic["iceAreaVertex"],
+            vs["airStressVertexU"], vs["airStressVertexV"], vs["surfaceTiltForceU"], vs["surfaceTiltForceV"],
+            vs["oceanStressU"], vs["oceanStressV"], vs["uOceanVelocityVertex"], vs["vOceanVelocityVertex"],
+            vs["uVelocityInitial"], vs["vVelocityInitial"], vs["uVelocity"], vs["vVelocity"], vw["strain11"],
+            vw["strain22"], vw["strain12"], vw["stress11"], vw["stress22"], vw["stress12"], vw["replacementPressure"],
+            vs["stressDivergenceU"], vs["stressDivergenceV"], vs["oceanStressCoeff"], float(vs["elasticTimeStep"][0]),
+            float(vs["dynamicsTimeStep"][0]), float(st["dampingTimescale"]),
+            float(st["numericalInertiaCoefficient"]), RELATION[cfg["config_constitutive_relation_type"]],
+            bool(cfg["config_use_ocean_stress"]), cfg["config_ocean_stress_type"] == "quadratic")
+
+
+def _subcycle_call(domain, b, n):
+    if weak_scheme(domain.configs):
+        call("ora_evp_subcycle_loop_weak", n, *_subcycle_args_weak(domain, b))
+    else:
+        call("ora_evp_subcycle_loop", n, *_subcycle_args(domain, b))
 
 
 def _subcycle_args(domain, b):
@@ -282,18 +335,18 @@ def subcycle_velocity_solver(domain, n_subcycles=None):
         _set_special_boundaries(domain)
         for _ in range(n):
             for b in domain.blocklist:
-                call("ora_evp_subcycle_loop", 1, *_subcycle_args(domain, b))
+                _subcycle_call(domain, b, 1)
             if halo_needed(domain):
                 domain.halo(domain, "velocity_solver", ["uVelocity", "vVelocity"])
             _set_special_boundaries(domain)
         return
     if not halo_needed(domain):
         for b in domain.blocklist:
-            call("ora_evp_subcycle_loop", n, *_subcycle_args(domain, b))
+            _subcycle_call(domain, b, n)
         return
     for _ in range(n):
         for b in domain.blocklist:
-            call("ora_evp_subcycle_loop", 1, *_subcycle_args(domain, b))
+            _subcycle_call(domain, b, 1)
         domain.halo(domain, "velocity_solver", ["uVelocity", "vVelocity"])
 
 
@@ -303,12 +356,20 @@ def velocity_solver_post_subcycle(domain):
         d = b.dimensions
         m, vs, vv, ic = b.structs["mesh"], b.structs["velocity_solver"], b.structs["velocity_variational"], b.structs["icestate"]
         rg = b.structs["ridging"]
-        call("ora_final_divergence_shear", d["nCells"], d["maxEdges"], m["nEdgesOnCell"], vs["solveStress"],
-             vv["strain11"], vv["strain22"], vv["strain12"], vs["divergence"], vs["shear"],
-             bool(cfg["config_use_column_package"]), rg["ridgeConvergence"], rg["ridgeShear"])
-        call("ora_principal_stresses", d["nCellsSolve"], d["maxEdges"], m["nEdgesOnCell"], vv["stress11"],
-             vv["stress22"], vv["stress12"], vv["replacementPressure"], vv["principalStress1"],
-             vv["principalStress2"])
+        if weak_scheme(cfg):  # velocity_solver.F:3416-3418, 3497-3516
+            vw = b.structs["velocity_weak"]
+            call("ora_final_divergence_shear_weak", d["nCellsSolve"], vw["strain11"], vw["strain22"], vw["strain12"],
+                 vs["divergence"], vs["shear"], bool(cfg["config_use_column_package"]), rg["ridgeConvergence"],
+                 rg["ridgeShear"])
+            call("ora_principal_stresses_weak", d["nCellsSolve"], vw["stress11"], vw["stress22"], vw["stress12"],
+                 vw["replacementPressure"], vw["principalStress1"], vw["principalStress2"])
+        else:
+            call("ora_final_divergence_shear", d["nCells"], d["maxEdges"], m["nEdgesOnCell"], vs["solveStress"],
+                 vv["strain11"], vv["strain22"], vv["strain12"], vs["divergence"], vs["shear"],
+                 bool(cfg["config_use_column_package"]), rg["ridgeConvergence"], rg["ridgeShear"])
+            call("ora_principal_stresses", d["nCellsSolve"], d["maxEdges"], m["nEdgesOnCell"], vv["stress11"],
+                 vv["stress22"], vv["stress12"], vv["replacementPressure"], vv["principalStress1"],
+                 vv["principalStress2"])
         call("ora_ocean_stress_coefficient", d["nVerticesSolve"], d["nVertices"] + 1, cfg["config_use_ocean_stress"],
              cfg["config_ocean_stress_type"] == "quadratic", vs["solveVelocity"], vs["oceanStressCoeff"],
              vs["uOceanVelocityVertex"], vs["vOceanVelocityVertex"], vs["uVelocity"], vs["vVelocity"],

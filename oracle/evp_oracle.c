@@ -1297,3 +1297,366 @@ void ora_evp_subcycle_loop(int nSubcycles, int nCells, int nVerticesSolve, int n
                                        oceanStressCoeff, dynamicsTimeStep, numericalInertiaCoefficient);
     }
 }
+
+/* ================================================================== weak (cell-centred) scheme
+ * mpas_seaice_velocity_solver_weak.F and the normal vectors of mpas_seaice_mesh.F:703-1606.
+ * Layouts: normalVectorPolygon(2, maxEdges, nCells), normalVectorTriangle(2, vertexDegree, nVertices). */
+#define NV3(i, k, e, K) (((size_t)((e) - 1) * (size_t)(K) + (size_t)((k) - 1)) * 2 + (size_t)((i) - 1))
+
+/* the rotation onto the rotated equator of normal_vectors_spherical_*_metric (mesh.F:1148-1169, 1199-1201):
+ * out = Ry(lat) * Rz(-lon) * in */
+static void to_equator(double out[3], const double in[3], double lat, double lon, int removeMetricTerms)
+{
+    double y[3][3] = {{0, 0, 0}, {0, 1, 0}, {0, 0, 0}}, z[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 1}};
+    if (removeMetricTerms) {
+        y[0][0] = cos(lat);
+        y[0][2] = sin(lat);
+        y[2][0] = -sin(lat);
+        y[2][2] = cos(lat);
+        z[0][0] = cos(-lon);
+        z[0][1] = -sin(-lon);
+        z[1][0] = sin(-lon);
+        z[1][1] = cos(-lon);
+    } else {
+        y[0][0] = y[2][2] = 1.0;
+        z[0][0] = z[1][1] = 1.0;
+    }
+    double t[3];
+    for (int i = 0; i < 3; i++) t[i] = z[i][0] * in[0] + z[i][1] * in[1] + z[i][2] * in[2]; /* matmul order */
+    for (int i = 0; i < 3; i++) out[i] = y[i][0] * t[0] + y[i][1] * t[1] + y[i][2] * t[2];
+}
+
+/* normal of the great circle through a and b (a, b, mid on the rotated equator frame) projected on the local
+ * east / north directions at `mid`, mesh.F:1203-1233 */
+static void great_circle_normal(double n2[2], const double a[3], const double b[3], const double mid[3], int flip)
+{
+    double v[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+    double g[3] = {v[1] * mid[2] - v[2] * mid[1], v[2] * mid[0] - v[0] * mid[2], v[0] * mid[1] - v[1] * mid[0]};
+    if (flip) {
+        g[0] = -1.0 * g[0];
+        g[1] = -1.0 * g[1];
+        g[2] = -1.0 * g[2];
+    }
+    double norm = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    g[0] = g[0] / norm;
+    g[1] = g[1] / norm;
+    g[2] = g[2] / norm;
+    double e[3] = {-mid[1], mid[0], 0.0};
+    double en = sqrt(e[0] * e[0] + e[1] * e[1]);
+    e[0] = e[0] / en;
+    e[1] = e[1] / en;
+    e[2] = e[2] / en;
+    n2[0] = g[0] * e[0] + g[1] * e[1] + g[2] * e[2];
+    double cl = fmax(fmin(n2[0], 1.0), -1.0);
+    n2[1] = sign1(g[2]) * sqrt(1.0 - cl * cl);
+}
+
+/* seaice_normal_vectors_polygon, mesh.F:760-793 -> normal_vectors_spherical_polygon_metric :1038-1241 or
+ * normal_vectors_planar_polygon :858-943 */
+void ora_normal_vectors_polygon(int nCells, int maxEdges, const int *nEdgesOnCell, const int *edgesOnCell,
+                                const int *verticesOnEdge, const int *cellsOnEdge, const double *xCell,
+                                const double *yCell, const double *zCell, const double *xEdge, const double *yEdge,
+                                const double *zEdge, const double *xVertex, const double *yVertex,
+                                const double *zVertex, double sphere_radius, int onASphere, int rotate,
+                                int removeMetricTerms, double *normalVectorPolygon, double *latCellRotated)
+{
+    for (int c = 1; c <= nCells; c++) {
+        if (!onASphere) {
+            for (int ie = 1; ie <= nEdgesOnCell[c - 1]; ie++) {
+                int e = edgesOnCell[IX2(ie, c, maxEdges)];
+                int v1 = verticesOnEdge[IX2(1, e, 2)], v2 = verticesOnEdge[IX2(2, e, 2)];
+                double tx = xVertex[v2 - 1] - xVertex[v1 - 1], ty = yVertex[v2 - 1] - yVertex[v1 - 1];
+                double tmag = sqrt(tx * tx + ty * ty);
+                tx = tx / tmag;
+                ty = ty / tmag;
+                double nx = xEdge[e - 1] - xCell[c - 1], ny = yEdge[e - 1] - yCell[c - 1];
+                if ((nx * ty - ny * tx) < 0.0) {
+                    tx = -tx;
+                    ty = -ty;
+                }
+                normalVectorPolygon[NV3(1, ie, c, maxEdges)] = ty;
+                normalVectorPolygon[NV3(2, ie, c, maxEdges)] = -tx;
+            }
+            latCellRotated[c - 1] = 0.0;
+            continue;
+        }
+        double cr[3];
+        grid_rotation_forward(&cr[0], &cr[1], &cr[2], xCell[c - 1], yCell[c - 1], zCell[c - 1], rotate);
+        double lon = atan2(cr[1], cr[0]), lat = asin(cr[2] / sphere_radius);
+        for (int ie = 1; ie <= nEdgesOnCell[c - 1]; ie++) {
+            int e = edgesOnCell[IX2(ie, c, maxEdges)];
+            int v1 = verticesOnEdge[IX2(1, e, 2)], v2 = verticesOnEdge[IX2(2, e, 2)];
+            double er[3], a[3], b[3], eq[3], aq[3], bq[3];
+            grid_rotation_forward(&er[0], &er[1], &er[2], xEdge[e - 1], yEdge[e - 1], zEdge[e - 1], rotate);
+            grid_rotation_forward(&a[0], &a[1], &a[2], xVertex[v1 - 1], yVertex[v1 - 1], zVertex[v1 - 1], rotate);
+            grid_rotation_forward(&b[0], &b[1], &b[2], xVertex[v2 - 1], yVertex[v2 - 1], zVertex[v2 - 1], rotate);
+            to_equator(eq, er, lat, lon, removeMetricTerms);
+            to_equator(aq, a, lat, lon, removeMetricTerms);
+            to_equator(bq, b, lat, lon, removeMetricTerms);
+            great_circle_normal(&normalVectorPolygon[NV3(1, ie, c, maxEdges)], aq, bq, eq,
+                                c == cellsOnEdge[IX2(2, e, 2)]);
+        }
+        latCellRotated[c - 1] = lat;
+    }
+}
+
+/* seaice_normal_vectors_triangle, mesh.F:807-844 -> normal_vectors_spherical_triangle_metric :1393-1606 (owned
+ * vertices) or normal_vectors_planar_triangle :957-1024 (all vertices) */
+void ora_normal_vectors_triangle(int nVertices, int nVerticesSolve, int vertexDegree, const int *edgesOnVertex,
+                                 const int *cellsOnEdge, const int *verticesOnEdge, const int *interiorVertex,
+                                 const double *xCell, const double *yCell, const double *zCell, const double *xEdge,
+                                 const double *yEdge, const double *zEdge, const double *xVertex,
+                                 const double *yVertex, const double *zVertex, double sphere_radius, int onASphere,
+                                 int rotate, int removeMetricTerms, double *normalVectorTriangle,
+                                 double *latVertexRotated)
+{
+    int nLoop = onASphere ? nVerticesSolve : nVertices;
+    if (!onASphere)
+        for (int v = 0; v < nVertices; v++) latVertexRotated[v] = 0.0;
+    for (int v = 1; v <= nLoop; v++) {
+        for (int k = 1; k <= vertexDegree; k++) {
+            normalVectorTriangle[NV3(1, k, v, vertexDegree)] = 0.0;
+            normalVectorTriangle[NV3(2, k, v, vertexDegree)] = 0.0;
+        }
+        if (onASphere) latVertexRotated[v - 1] = 0.0;
+        if (interiorVertex[v - 1] != 1) continue;
+        if (!onASphere) {
+            for (int k = 1; k <= vertexDegree; k++) {
+                int e = edgesOnVertex[IX2(k, v, vertexDegree)];
+                double dx = xEdge[e - 1] - xVertex[v - 1], dy = yEdge[e - 1] - yVertex[v - 1];
+                normalVectorTriangle[NV3(1, k, v, vertexDegree)] = dx / sqrt(dx * dx + dy * dy);
+                normalVectorTriangle[NV3(2, k, v, vertexDegree)] = dy / sqrt(dx * dx + dy * dy);
+            }
+            continue;
+        }
+        double vr[3];
+        grid_rotation_forward(&vr[0], &vr[1], &vr[2], xVertex[v - 1], yVertex[v - 1], zVertex[v - 1], rotate);
+        double lon = atan2(vr[1], vr[0]), lat = asin(vr[2] / sphere_radius);
+        for (int k = 1; k <= vertexDegree; k++) {
+            int e = edgesOnVertex[IX2(k, v, vertexDegree)];
+            int c1 = cellsOnEdge[IX2(1, e, 2)], c2 = cellsOnEdge[IX2(2, e, 2)];
+            double er[3], a[3], b[3], eq[3], aq[3], bq[3];
+            grid_rotation_forward(&er[0], &er[1], &er[2], xEdge[e - 1], yEdge[e - 1], zEdge[e - 1], rotate);
+            grid_rotation_forward(&a[0], &a[1], &a[2], xCell[c1 - 1], yCell[c1 - 1], zCell[c1 - 1], rotate);
+            grid_rotation_forward(&b[0], &b[1], &b[2], xCell[c2 - 1], yCell[c2 - 1], zCell[c2 - 1], rotate);
+            to_equator(eq, er, lat, lon, removeMetricTerms);
+            to_equator(aq, a, lat, lon, removeMetricTerms);
+            to_equator(bq, b, lat, lon, removeMetricTerms);
+            great_circle_normal(&normalVectorTriangle[NV3(1, k, v, vertexDegree)], aq, bq, eq,
+                                v == verticesOnEdge[IX2(1, e, 2)]);
+        }
+        latVertexRotated[v - 1] = lat;
+    }
+}
+
+/* seaice_strain_tensor_weak, velocity_solver_weak.F:112-253 */
+void ora_strain_tensor_weak(int nCells, int maxEdges, const int *nEdgesOnCell, const int *verticesOnCell,
+                            const int *edgesOnCell, const int *verticesOnEdge, const double *dvEdge,
+                            const double *areaCell, double sphere_radius, double *strain11, double *strain22,
+                            double *strain12, const double *uVelocity, const double *vVelocity,
+                            const double *normalVectorPolygon, const double *latCellRotated, const int *solveStress)
+{
+    double sphereRadius = sphere_radius;
+    if (sphereRadius == 0.0) sphereRadius = 1.0;
+    for (int c = 1; c <= nCells; c++) {
+        double s11 = 0.0, s22 = 0.0, s12 = 0.0;
+        if (solveStress[c - 1] == 1) {
+            double uc = 0.0, vc = 0.0;
+            for (int ie = 1; ie <= nEdgesOnCell[c - 1]; ie++) {
+                int iv = verticesOnCell[IX2(ie, c, maxEdges)];
+                uc = uc + uVelocity[iv - 1];
+                vc = vc + vVelocity[iv - 1];
+                int e = edgesOnCell[IX2(ie, c, maxEdges)];
+                double ue = 0.0, ve = 0.0;
+                for (int k = 1; k <= 2; k++) {
+                    int w = verticesOnEdge[IX2(k, e, 2)];
+                    ue = ue + uVelocity[w - 1];
+                    ve = ve + vVelocity[w - 1];
+                }
+                ue = ue / 2.0;
+                ve = ve / 2.0;
+                double n1 = normalVectorPolygon[NV3(1, ie, c, maxEdges)], n2 = normalVectorPolygon[NV3(2, ie, c, maxEdges)];
+                s11 = s11 + ue * n1 * dvEdge[e - 1];
+                s22 = s22 + ve * n2 * dvEdge[e - 1];
+                s12 = s12 + 0.5 * (ue * n2 + ve * n1) * dvEdge[e - 1];
+            }
+            uc = uc / (double)nEdgesOnCell[c - 1];
+            vc = vc / (double)nEdgesOnCell[c - 1];
+            s11 = s11 / areaCell[c - 1];
+            s22 = s22 / areaCell[c - 1];
+            s12 = s12 / areaCell[c - 1];
+            s11 = s11 - (vc * tan(latCellRotated[c - 1])) / sphereRadius;
+            s12 = s12 + (uc * tan(latCellRotated[c - 1]) * 0.5) / sphereRadius;
+        }
+        strain11[c - 1] = s11;
+        strain22[c - 1] = s22;
+        strain12[c - 1] = s12;
+    }
+}
+
+/* seaice_stress_tensor_weak, velocity_solver_weak.F:267-405 */
+void ora_stress_tensor_weak(int nCells, double *stress11, double *stress22, double *stress12, const double *strain11,
+                            const double *strain22, const double *strain12, const double *icePressure,
+                            double *replacementPressure, const int *solveStress, double dtElastic,
+                            double dampingTimescale, int relation)
+{
+    for (int c = 0; c < nCells; c++) {
+        if (solveStress[c] == 1) {
+            if (relation == 1)
+                evp_constitutive_relation(&stress11[c], &stress22[c], &stress12[c], strain11[c], strain22[c],
+                                          strain12[c], icePressure[c], &replacementPressure[c], dtElastic,
+                                          dampingTimescale);
+            else if (relation == 2)
+                evp_constitutive_relation_revised(&stress11[c], &stress22[c], &stress12[c], strain11[c], strain22[c],
+                                                  strain12[c], icePressure[c], &replacementPressure[c]);
+            else { /* seaice_linear_constitutive_relation, constitutive_relation.F:344-373 */
+                stress11[c] = 1.0 * strain11[c];
+                stress22[c] = 1.0 * strain22[c];
+                stress12[c] = 1.0 * strain12[c];
+            }
+        } else {
+            stress11[c] = 0.0;
+            stress22[c] = 0.0;
+            stress12[c] = 0.0;
+        }
+    }
+}
+
+/* seaice_stress_divergence_weak, velocity_solver_weak.F:493-640.  Loops over ALL vertices of the block (:558);
+ * the stress arrays carry the extra slot that cell index nCells+1 points to. */
+void ora_stress_divergence_weak(int nVertices, int vertexDegree, const int *cellsOnVertex, const int *edgesOnVertex,
+                                const int *cellsOnEdge, const double *areaTriangle, const double *dcEdge,
+                                double sphere_radius, double *stressDivergenceU, double *stressDivergenceV,
+                                const double *stress11, const double *stress22, const double *stress12,
+                                const double *normalVectorTriangle, const double *latVertexRotated,
+                                const int *solveVelocity)
+{
+    double sphereRadius = sphere_radius;
+    if (sphereRadius == 0.0) sphereRadius = 1.0;
+    for (int v = 1; v <= nVertices; v++) {
+        double dU = 0.0, dV = 0.0;
+        if (solveVelocity[v - 1] == 1) {
+            double s11v = 0.0, s22v = 0.0, s12v = 0.0;
+            for (int k = 1; k <= vertexDegree; k++) {
+                int c = cellsOnVertex[IX2(k, v, vertexDegree)];
+                s11v = s11v + stress11[c - 1];
+                s22v = s22v + stress22[c - 1];
+                s12v = s12v + stress12[c - 1];
+                int e = edgesOnVertex[IX2(k, v, vertexDegree)];
+                double s11e = 0.0, s22e = 0.0, s12e = 0.0;
+                for (int j = 1; j <= 2; j++) {
+                    int cc = cellsOnEdge[IX2(j, e, 2)];
+                    s11e = s11e + stress11[cc - 1];
+                    s22e = s22e + stress22[cc - 1];
+                    s12e = s12e + stress12[cc - 1];
+                }
+                s11e = s11e / 2.0;
+                s22e = s22e / 2.0;
+                s12e = s12e / 2.0;
+                double n1 = normalVectorTriangle[NV3(1, k, v, vertexDegree)];
+                double n2 = normalVectorTriangle[NV3(2, k, v, vertexDegree)];
+                dU = dU + (s11e * n1 + s12e * n2) * dcEdge[e - 1];
+                dV = dV + (s22e * n2 + s12e * n1) * dcEdge[e - 1];
+            }
+            s11v = s11v / (double)vertexDegree;
+            s22v = s22v / (double)vertexDegree;
+            s12v = s12v / (double)vertexDegree;
+            dU = dU / areaTriangle[v - 1];
+            dV = dV / areaTriangle[v - 1];
+            dU = dU - (tan(latVertexRotated[v - 1]) * s12v * 2.0) / sphereRadius;
+            dV = dV + (tan(latVertexRotated[v - 1]) * (s11v - s22v)) / sphereRadius;
+        }
+        stressDivergenceU[v - 1] = dU;
+        stressDivergenceV[v - 1] = dV;
+    }
+}
+
+/* seaice_final_divergence_shear_weak, velocity_solver_weak.F:654-749.  `Delta = sqrt(...)` at :720 assigns the
+ * whole array in every iteration, so after the loop every entry holds the last owned cell's value; the ridging
+ * diagnostics at :739-740 are computed from that, and so they are here. */
+void ora_final_divergence_shear_weak(int nCellsSolve, const double *strain11, const double *strain22,
+                                     const double *strain12, double *divergence, double *shear, int useColumn,
+                                     double *ridgeConvergence, double *ridgeShear)
+{
+    double DeltaAll = 0.0;
+    for (int c = 0; c < nCellsSolve; c++) {
+        double sd = strain11[c] + strain22[c], st = strain11[c] - strain22[c], ss = strain12[c] * 2.0;
+        DeltaAll = sqrt(sd * sd + (st * st + ss * ss) / eccentricitySquared);
+        divergence[c] = sd;
+        shear[c] = sqrt(st * st + ss * ss);
+    }
+    if (useColumn)
+        for (int c = 0; c < nCellsSolve; c++) {
+            ridgeConvergence[c] = -fmin(divergence[c], 0.0);
+            ridgeShear[c] = 0.5 * (DeltaAll - fabs(divergence[c]));
+        }
+}
+
+/* principal_stresses_driver weak branch (velocity_solver.F:3497-3516) */
+void ora_principal_stresses_weak(int nCellsSolve, const double *stress11, const double *stress22,
+                                 const double *stress12, const double *replacementPressure, double *p1, double *p2)
+{
+    for (int c = 0; c < nCellsSolve; c++) {
+        if (replacementPressure[c] > puny) {
+            double sq = (stress11[c] + stress22[c]) * (stress11[c] + stress22[c]) - 4.0 * stress11[c] * stress22[c] +
+                        4.0 * (stress12[c] * stress12[c]);
+            p1[c] = 0.5 * (stress11[c] + stress22[c]) + 0.5 * sqrt(sq);
+            p2[c] = 0.5 * (stress11[c] + stress22[c]) - 0.5 * sqrt(sq);
+            p1[c] = p1[c] / replacementPressure[c];
+            p2[c] = p2[c] / replacementPressure[c];
+        } else {
+            p1[c] = 1.0e30;
+            p2[c] = 1.0e30;
+        }
+    }
+}
+
+/* one block, no halo partner: single_subcycle_velocity_solver (velocity_solver.F:2478-2592) with
+ * config_strain_scheme = config_stress_divergence_scheme = 'weak' (seaice_internal_stress :2722-2858) */
+void ora_evp_subcycle_loop_weak(int nSubcycles, int nCells, int nVerticesSolve, int nVertices, int maxEdges,
+                                int vertexDegree, const int *nEdgesOnCell, const int *verticesOnCell,
+                                const int *edgesOnCell, const int *verticesOnEdge, const int *cellsOnVertex,
+                                const int *edgesOnVertex, const int *cellsOnEdge, const double *dvEdge,
+                                const double *dcEdge, const double *areaCell, const double *areaTriangle,
+                                double sphere_radius, const int *solveStress, const int *solveVelocity,
+                                const double *normalVectorPolygon, const double *normalVectorTriangle,
+                                const double *latCellRotated, const double *latVertexRotated,
+                                const double *icePressure, const double *totalMassVertex,
+                                const double *totalMassVertexfVertex, const double *iceAreaVertex,
+                                const double *airStressVertexU, const double *airStressVertexV,
+                                const double *surfaceTiltForceU, const double *surfaceTiltForceV,
+                                const double *oceanStressU, const double *oceanStressV,
+                                const double *uOceanVelocityVertex, const double *vOceanVelocityVertex,
+                                const double *uVelocityInitial, const double *vVelocityInitial, double *uVelocity,
+                                double *vVelocity, double *strain11, double *strain22, double *strain12,
+                                double *stress11, double *stress22, double *stress12, double *replacementPressure,
+                                double *stressDivergenceU, double *stressDivergenceV, double *oceanStressCoeff,
+                                double elasticTimeStep, double dynamicsTimeStep, double dampingTimescale,
+                                double numericalInertiaCoefficient, int relation, int useOceanStress,
+                                int quadraticOceanStress)
+{
+    for (int it = 0; it < nSubcycles; it++) {
+        ora_strain_tensor_weak(nCells, maxEdges, nEdgesOnCell, verticesOnCell, edgesOnCell, verticesOnEdge, dvEdge,
+                               areaCell, sphere_radius, strain11, strain22, strain12, uVelocity, vVelocity,
+                               normalVectorPolygon, latCellRotated, solveStress);
+        ora_stress_tensor_weak(nCells, stress11, stress22, stress12, strain11, strain22, strain12, icePressure,
+                               replacementPressure, solveStress, elasticTimeStep, dampingTimescale, relation);
+        ora_stress_divergence_weak(nVertices, vertexDegree, cellsOnVertex, edgesOnVertex, cellsOnEdge, areaTriangle,
+                                   dcEdge, sphere_radius, stressDivergenceU, stressDivergenceV, stress11, stress22,
+                                   stress12, normalVectorTriangle, latVertexRotated, solveVelocity);
+        ora_ocean_stress_coefficient(nVerticesSolve, nVertices, useOceanStress, quadraticOceanStress, solveVelocity,
+                                     oceanStressCoeff, uOceanVelocityVertex, vOceanVelocityVertex, uVelocity,
+                                     vVelocity, iceAreaVertex);
+        if (relation == 1)
+            ora_solve_velocity(nVerticesSolve, solveVelocity, uVelocity, vVelocity, totalMassVertex,
+                               totalMassVertexfVertex, stressDivergenceU, stressDivergenceV, airStressVertexU,
+                               airStressVertexV, surfaceTiltForceU, surfaceTiltForceV, oceanStressU, oceanStressV,
+                               oceanStressCoeff, elasticTimeStep);
+        else if (relation == 2)
+            ora_solve_velocity_revised(nVerticesSolve, solveVelocity, uVelocity, vVelocity, uVelocityInitial,
+                                       vVelocityInitial, totalMassVertex, totalMassVertexfVertex,
+                                       stressDivergenceU, stressDivergenceV, airStressVertexU, airStressVertexV,
+                                       surfaceTiltForceU, surfaceTiltForceV, oceanStressU, oceanStressV,
+                                       oceanStressCoeff, dynamicsTimeStep, numericalInertiaCoefficient);
+    }
+}

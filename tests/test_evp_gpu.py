@@ -218,3 +218,40 @@ def test_variable_resolution_960_subcycles(oracle):
     ref, dev = _run_both(oracle, "var16", cfg)
     worst = compare_domains(dev, ref, STATE, 1e-10)
     print("var16", mesh.nCells, "cells, 960 subcycles, worst rel err", worst)
+
+
+WEAK_CFG = {"config_strain_scheme": "weak", "config_stress_divergence_scheme": "weak"}
+WEAK_STATIC = [("velocity_weak", k) for k in ("normalVectorPolygon", "normalVectorTriangle", "latCellRotated",
+                                               "latVertexRotated")]
+WEAK_STATE = [("velocity_solver", k) for k in ("uVelocity", "vVelocity", "stressDivergenceU", "stressDivergenceV",
+                                               "divergence", "shear", "oceanStressCellU", "solveVelocity")] + \
+             [("velocity_weak", k) for k in ("strain11", "strain22", "strain12", "stress11", "stress22", "stress12",
+                                             "replacementPressure", "principalStress1", "principalStress2")] + \
+             [("ridging", "ridgeConvergence"), ("ridging", "ridgeShear")]
+
+
+@pytest.mark.parametrize("mesh_name,extra", [
+    ("QU480", {}), ("hex_24_20", {}), ("var12", {"config_dt": 1800.0}),
+    ("QU480", {"config_constitutive_relation_type": "evp_revised"}),
+    ("QU480", {"config_use_column_package": True, "config_use_column_vertical_thermodynamics": False}),
+])
+def test_weak_scheme(oracle, mesh_name, extra):
+    """config_strain_scheme = config_stress_divergence_scheme = 'weak' (velocity_solver_weak.F): normal vectors
+    and rotated latitudes to 1e-11 (device trigonometry; the second component is sqrt(1 - n1^2), which
+    magnifies the last-bit differences of n1 where the normal points east or west), the step to 1e-10."""
+    cfg = dict(WEAK_CFG, config_elastic_subcycle_number=40, **extra)
+    ref, dev = _run_both(oracle, mesh_name, cfg)
+    compare_domains(dev, ref, WEAK_STATIC, 1e-11)
+    compare_domains(dev, ref, WEAK_STATE, 1e-10)
+    assert np.abs(ref.blocklist[0].structs["velocity_weak"]["stress12"]).max() > 0
+
+
+def test_mixed_schemes_are_refused():
+    from mpas_seaice_amd.lib import SeaiceHipError
+    dom = cases.make_domain(get_mesh("QU480"), "QU480", configs={"config_strain_scheme": "weak"})
+    vs.seaice_mesh_pool_create(dom)
+    try:
+        with pytest.raises(SeaiceHipError, match="both 'variational' or both 'weak'"):
+            vs.seaice_init_velocity_solver(dom)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)

@@ -109,3 +109,29 @@ def test_subcycle_parts_error_paths():
         ctx.sync()
     finally:
         vs.seaice_mesh_pool_destroy(dom)
+
+
+def test_weak_scheme_on_three_blocks(oracle):
+    mesh = get_mesh("QU480")
+    cfg = {"config_elastic_subcycle_number": 30, "config_strain_scheme": "weak",
+           "config_stress_divergence_scheme": "weak"}
+    ref = cases.make_domain(mesh, "QU480", configs=cfg, open_water_band=(-0.2, 0.3))
+    oracle.seaice_init_velocity_solver(ref)
+    oracle.seaice_run_velocity_solver(ref)
+    dom, halos, _ = parallel.make_partitioned_domain(mesh, "QU480", 3, configs=cfg, open_water_band=(-0.2, 0.3))
+    vs.seaice_mesh_pool_create(dom, device=0)
+    try:
+        dom.comm = parallel.LocalComm(dom, halos, 3)
+        vs.seaice_init_velocity_solver(dom)
+        vs.seaice_run_velocity_solver(dom)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+    for pool, name, loc, n in (("velocity_solver", "uVelocity", "vertex", mesh.nVertices),
+                               ("velocity_solver", "vVelocity", "vertex", mesh.nVertices),
+                               ("velocity_weak", "stress11", "cell", mesh.nCells),
+                               ("velocity_weak", "stress12", "cell", mesh.nCells),
+                               ("velocity_solver", "shear", "cell", mesh.nCells)):
+        g = parallel.gather_global(dom.blocklist, halos, pool, name, n, loc).astype(np.float64)
+        r = ref.blocklist[0].structs[pool][name][..., :n].astype(np.float64)
+        err = np.abs(g - r).max() / max(np.abs(r).max(), 1e-300)
+        assert err <= TOL, (name, err)

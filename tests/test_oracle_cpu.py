@@ -202,3 +202,54 @@ def test_pwl_basis_invariants(oracle, mesh_name):
         for g in range(n):
             assert abs((u * gu[:n, g, c]).sum() - 0.3) <= 1e-10
             assert abs((u * gv[:n, g, c]).sum() + 1.7) <= 1e-10
+
+
+@pytest.mark.parametrize("mesh_name", ["hex_8_6", "QU480"])
+def test_weak_operators(oracle, mesh_name):
+    """Weak scheme (velocity_solver_weak.F): polygon normals are unit vectors that close (sum n dv = 0 on
+    the plane); the strain of a linear velocity field on the plane is exact in every interior cell; the
+    divergence of a uniform stress field vanishes at interior vertices."""
+    mesh = get_mesh(mesh_name)
+    cfg = {"config_strain_scheme": "weak", "config_stress_divergence_scheme": "weak"}
+    dom = cases.make_domain(mesh, mesh_name if mesh_name.startswith("QU") else None, configs=cfg)
+    oracle.seaice_init_velocity_solver(dom)
+    b = dom.blocklist[0]
+    d, m, vw = b.dimensions, b.structs["mesh"], b.structs["velocity_weak"]
+    nC, nV, M = d["nCells"], d["nVertices"], d["maxEdges"]
+    ne = m["nEdgesOnCell"][:nC]
+    npoly = vw["normalVectorPolygon"][:, :, :nC]
+    live = np.arange(M)[:, None] < ne[None, :]
+    assert np.abs(np.sqrt((npoly ** 2).sum(axis=0))[live] - 1.0).max() < 1e-14
+    ntri = vw["normalVectorTriangle"][:, :, :nV]
+    interior = b.structs["boundary"]["interiorVertex"][:nV] == 1
+    assert np.abs(np.sqrt((ntri ** 2).sum(axis=0))[:, interior] - 1.0).max() < 1e-14
+    if mesh_name.startswith("hex"):
+        dv = m["dvEdge"][np.clip(m["edgesOnCell"][:, :nC] - 1, 0, d["nEdges"] - 1)]
+        closure = (npoly * np.where(live, dv, 0.0)[None, :, :]).sum(axis=1)
+        assert np.abs(closure).max() < 1e-9 * dv.max()
+        # linear velocity u = a x + b y + c, v = e x + f y + g
+        a_, b_, e_, f_ = 2.0e-6, -1.0e-6, 0.5e-6, 3.0e-6
+        u = np.zeros(nV + 1)
+        v = np.zeros(nV + 1)
+        u[:nV] = a_ * m["xVertex"][:nV] + b_ * m["yVertex"][:nV] + 0.3
+        v[:nV] = e_ * m["xVertex"][:nV] + f_ * m["yVertex"][:nV] - 0.1
+        s = [np.zeros(nC + 1) for _ in range(3)]
+        solve = np.ones(nC + 1, dtype=np.int32)
+        oracle.call("ora_strain_tensor_weak", nC, M, m["nEdgesOnCell"], m["verticesOnCell"], m["edgesOnCell"],
+                    m["verticesOnEdge"], m["dvEdge"], m["areaCell"], 0.0, s[0], s[1], s[2], u, v,
+                    vw["normalVectorPolygon"], vw["latCellRotated"], solve)
+        assert np.abs(s[0][:nC] - a_).max() < 1e-12 * abs(a_) * 1e3
+        assert np.abs(s[1][:nC] - f_).max() < 1e-12 * abs(f_) * 1e3
+        assert np.abs(s[2][:nC] - 0.5 * (b_ + e_)).max() < 1e-15
+        # uniform stress: no force on interior vertices
+        st = [np.full(nC + 1, x) for x in (3.0, -2.0, 0.7)]
+        for x in st:
+            x[nC] = 0.0
+        dU, dV = np.zeros(nV + 1), np.zeros(nV + 1)
+        sv = np.zeros(nV + 1, dtype=np.int32)
+        sv[:nV] = interior
+        oracle.call("ora_stress_divergence_weak", nV, 3, m["cellsOnVertex"], m["edgesOnVertex"], m["cellsOnEdge"],
+                    m["areaTriangle"], m["dcEdge"], 0.0, dU, dV, st[0], st[1], st[2], vw["normalVectorTriangle"],
+                    vw["latVertexRotated"], sv)
+        scale = 3.0 * m["dcEdge"].max() / m["areaTriangle"][:nV].min()
+        assert np.abs(dU[:nV][interior]).max() < 1e-12 * scale and np.abs(dV[:nV][interior]).max() < 1e-12 * scale
