@@ -103,8 +103,10 @@ typedef struct sih_evp_config {
     int32_t useSpecialBoundariesVelocity;      /* config_use_special_boundaries_velocity */
     int32_t useSpecialBoundariesVelocityMasks; /* config_use_special_boundaries_velocity_masks */
     int32_t strainScheme;             /* config_strain_scheme: 0 variational, 1 weak */
-    int32_t stressDivergenceScheme;   /* config_stress_divergence_scheme: 0 variational, 1 weak; the two must
-                                         agree (the mixed schemes of velocity_solver.F:2768-2784 are not built) */
+    int32_t stressDivergenceScheme;   /* config_stress_divergence_scheme: 0 variational, 1 weak.  Weak strain
+                                         with variational divergence interpolates the cell strains to the
+                                         corners (velocity_solver.F:2768-2784); variational strain with weak
+                                         divergence is an error in the reference too (:191-194) */
 } sih_evp_config;
 
 /* ---- life cycle ----------------------------------------------------------------------------- */

@@ -625,9 +625,14 @@ extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
         sih_set_error("Unknown variational denominator type");
         return SIH_ERR_ARG;
     }
-    if (cfg->strainScheme != cfg->stressDivergenceScheme || cfg->strainScheme < 0 || cfg->strainScheme > 1) {
-        sih_set_error("config_strain_scheme / config_stress_divergence_scheme: both 'variational' or both 'weak'");
-        return SIH_ERR_UNSUPPORTED;
+    if (cfg->strainScheme < 0 || cfg->strainScheme > 1 || cfg->stressDivergenceScheme < 0 ||
+        cfg->stressDivergenceScheme > 1) {
+        sih_set_error("config_strain_scheme / config_stress_divergence_scheme unknown");
+        return SIH_ERR_ARG;
+    }
+    if (cfg->strainScheme == 0 && cfg->stressDivergenceScheme == 1) {  // the reference's message, velocity_solver.F:193
+        sih_set_error("Cannot have variational strain scheme with variational stress divergence scheme");
+        return SIH_ERR_ARG;
     }
     if (cfg->strainScheme == 1 && (cfg->computeHaloVertices || cfg->averageVariationalStrain)) {
         sih_set_error("the weak scheme has no redundant halo update and no strain averaging");

@@ -971,7 +971,7 @@ extern "C" int sih_evp_pre_subcycle(sih_ctx *c, int stage)
     if (stage == -1 || stage == 4) {
         hipLaunchKernelGGL(k_pre4_vertices, gv, b, 0, s, d);
         hipLaunchKernelGGL(k_pre4_cells, gc, b, 0, s, d);
-        if (c->cfg.strainScheme == 1) sih_weak_launch_pre(c);
+        if (c->cfg.stressDivergenceScheme == 1) sih_weak_launch_pre(c);
     }
     if (stage == -1 || stage == 4) c->sbPending = c->sbVelocity || c->sbMasks;
     HIPCHK(hipGetLastError());
@@ -1039,8 +1039,13 @@ static void launchCellKernel(sih_ctx *c, bool last, int subset = -1)
     const int *list = subset >= 0 ? c->d_part[subset] : nullptr;
     const int nList = subset >= 0 ? c->nPart[subset] : 0;
     if (subset >= 0 && nList == 0) return;
-    if (c->cfg.strainScheme == 1) {  // weak scheme: strain + stress per cell, then the divergence at every vertex
-        sih_weak_launch_cells(c);
+    if (c->cfg.strainScheme == 1 && c->cfg.stressDivergenceScheme == 1) {
+        sih_weak_launch_cells(c);  // weak scheme: strain + stress per cell, then the divergence at every vertex
+        return;
+    }
+    if (c->cfg.strainScheme == 1) {  // weak strain interpolated to the corners, variational from there on
+        sih_weak_launch_hybrid_strain(c);
+        launchCellsM(c, last, nullptr, 0, 2);
         return;
     }
     if (c->cfg.averageVariationalStrain) {  // whole block only (checked where subsets are set up)
@@ -1078,7 +1083,7 @@ static void launchVertexKernel(sih_ctx *c, bool last, int subset = -1)
     const int nList = subset >= 0 ? c->nPart[subset] : 0;
     if (subset >= 0 && nList == 0) return;
     dim3 b(256), g = gridFor(list ? nList : (c->cfg.computeHaloVertices ? c->nVertices : c->nVerticesSolve));
-    if (c->cfg.strainScheme == 1) {
+    if (c->cfg.stressDivergenceScheme == 1) {
         if (last)
             hipLaunchKernelGGL((k_sub_vertices<true, true>), g, b, 0, c->stream, c->dev, list, nList);
         else
@@ -1119,7 +1124,7 @@ extern "C" int sih_evp_post_subcycle(sih_ctx *c, int stage)
     const SihDev &d = c->dev;
     dim3 b(256), gc = gridFor(c->nCells), gv = gridFor(c->nVertices);
     if (stage == -1 || stage == 0) {
-        if (c->cfg.strainScheme == 1)
+        if (c->cfg.stressDivergenceScheme == 1)
             sih_weak_launch_post(c);  // velocity_solver.F:3416-3418, 3497-3516
         else
             hipLaunchKernelGGL(k_post0_cells, gc, b, 0, c->stream, d);

@@ -28,6 +28,9 @@ struct WeakDev {
     double *divU, *divV, *divergence, *shear, *ridgeConv, *ridgeShear;
     double sphereRadius, dtE, dampT;
     int relation, useColumn;
+    // weak strain + variational divergence: strains at vertices and the variational pool's corner strains
+    double *sv11, *sv22, *sv12, *var11, *var22, *var12;
+    const int *gidx;
 };
 
 struct sih_weak_state {
@@ -261,7 +264,8 @@ __global__ void k_weak_pre(WeakDev d)
 }
 
 // seaice_strain_tensor_weak (velocity_solver_weak.F:112-253) and seaice_stress_tensor_weak (:267-405)
-__global__ void __launch_bounds__(256) k_weak_cells(WeakDev d)
+// strainOnly: the mixed scheme uses the weak strain but the variational stresses
+__global__ void __launch_bounds__(256) k_weak_cells(WeakDev d, int strainOnly)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.nCells) return;
@@ -271,9 +275,11 @@ __global__ void __launch_bounds__(256) k_weak_cells(WeakDev d)
         d.strain11[c] = 0.0;
         d.strain22[c] = 0.0;
         d.strain12[c] = 0.0;
-        d.stress11[c] = 0.0;
-        d.stress22[c] = 0.0;
-        d.stress12[c] = 0.0;
+        if (!strainOnly) {
+            d.stress11[c] = 0.0;
+            d.stress22[c] = 0.0;
+            d.stress12[c] = 0.0;
+        }
         return;
     }
     const int n = d.nEdgesOnCell[c];
@@ -308,6 +314,7 @@ __global__ void __launch_bounds__(256) k_weak_cells(WeakDev d)
     d.strain11[c] = s11;
     d.strain22[c] = s22;
     d.strain12[c] = s12;
+    if (strainOnly) return;
     double a11, a22, a12;
     if (d.relation == 3) {
         a11 = 1.0 * s11;
@@ -387,6 +394,45 @@ __global__ void __launch_bounds__(256) k_weak_divergence(WeakDev d)
     d.divV[v] = dV;
 }
 
+// interpolate_strains_weak_to_variational (velocity_solver.F:2877-2960), first loop: area-weighted mean of
+// the cell strains at every owned vertex
+__global__ void k_hybrid_vertex_strain(WeakDev d)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= d.nVerticesSolve) return;
+    const size_t pv = d.padV;
+    double a = 0.0, b = 0.0, c12 = 0.0, denom = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int c = d.cov[k * pv + v];
+        if (c < d.nCells) {
+            const double area = d.areaCell[c];
+            a = a + area * d.strain11[c];
+            b = b + area * d.strain22[c];
+            c12 = c12 + area * d.strain12[c];
+            denom = denom + area;
+        }
+    }
+    d.sv11[v] = a / denom;
+    d.sv22[v] = b / denom;
+    d.sv12[v] = c12 / denom;
+}
+
+// second loop: every corner of every cell takes its vertex's value
+__global__ void k_hybrid_fill_corners(WeakDev d)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nCells) return;
+    const size_t pc = d.padC;
+    const int n = d.nEdgesOnCell[c];
+    for (int s = 0; s < n; s++) {
+        const int v = d.voc[(size_t)s * pc + c];
+        d.var11[(size_t)s * pc + c] = d.sv11[v];
+        d.var22[(size_t)s * pc + c] = d.sv22[v];
+        d.var12[(size_t)s * pc + c] = d.sv12[v];
+    }
+}
+
 // seaice_final_divergence_shear_weak (velocity_solver_weak.F:654-749) and the weak branch of
 // principal_stresses_driver (velocity_solver.F:3497-3516).  At :720 the reference assigns the scalar Delta of
 // the current cell to its whole work array, so the ridging diagnostics of every cell are computed from the
@@ -458,7 +504,8 @@ int sih_weak_init(sih_ctx *c)
                         {"replacementPressureWeak", LOC_CELL, 1, false}, {"_weakEv1", LOC_CELL, M, true},
                         {"_weakEv2", LOC_CELL, M, true},                 {"_weakEc1", LOC_VERTEX, 3, true},
                         {"_weakEc2", LOC_VERTEX, 3, true},               {"_weakDv", LOC_CELL, M, false},
-                        {"_weakDc", LOC_VERTEX, 3, false}};
+                        {"_weakDc", LOC_VERTEX, 3, false},               {"strain11Vertex", LOC_VERTEX, 1, false},
+                        {"strain22Vertex", LOC_VERTEX, 1, false},        {"strain12Vertex", LOC_VERTEX, 1, false}};
     for (const F &f : fields)
         if ((rc = sih_add_field(c, f.n, f.loc, f.lead, f.isInt))) return rc;
     auto fi = [&](const char *n) { return (int *)sih_find_field(c, n)->d; };
@@ -608,6 +655,13 @@ void sih_weak_bind(sih_ctx *c)
     d.dampT = c->dev.dampT;
     d.relation = c->dev.relation;
     d.useColumn = c->dev.useColumn;
+    d.sv11 = fd("strain11Vertex");
+    d.sv22 = fd("strain22Vertex");
+    d.sv12 = fd("strain12Vertex");
+    d.var11 = c->dev.strain11;
+    d.var22 = c->dev.strain22;
+    d.var12 = c->dev.strain12;
+    d.gidx = c->dev.gidx;
 }
 
 void sih_weak_launch_pre(sih_ctx *c)
@@ -615,9 +669,19 @@ void sih_weak_launch_pre(sih_ctx *c)
     hipLaunchKernelGGL(k_weak_pre, dim3((c->nCells + 255) / 256), dim3(256), 0, c->stream, c->weak->d);
 }
 
+// weak strain, then the variational pool's corner strains from it; the caller follows with the variational
+// stress / partial-sum pass that starts from stored strains
+void sih_weak_launch_hybrid_strain(sih_ctx *c)
+{
+    const dim3 b(256), gc((c->nCells + 255) / 256), gv((c->nVerticesSolve + 255) / 256);
+    hipLaunchKernelGGL(k_weak_cells, gc, b, 0, c->stream, c->weak->d, 1);
+    hipLaunchKernelGGL(k_hybrid_vertex_strain, gv, b, 0, c->stream, c->weak->d);
+    hipLaunchKernelGGL(k_hybrid_fill_corners, gc, b, 0, c->stream, c->weak->d);
+}
+
 void sih_weak_launch_cells(sih_ctx *c)
 {
-    hipLaunchKernelGGL(k_weak_cells, dim3((c->nCells + 255) / 256), dim3(256), 0, c->stream, c->weak->d);
+    hipLaunchKernelGGL(k_weak_cells, dim3((c->nCells + 255) / 256), dim3(256), 0, c->stream, c->weak->d, 0);
     hipLaunchKernelGGL(k_weak_divergence, dim3((c->nVertices + 255) / 256), dim3(256), 0, c->stream, c->weak->d);
 }
 

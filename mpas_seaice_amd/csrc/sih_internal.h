@@ -122,6 +122,7 @@ int sih_weak_init(sih_ctx *c);
 void sih_weak_bind(sih_ctx *c);
 void sih_weak_launch_pre(sih_ctx *c);
 void sih_weak_launch_cells(sih_ctx *c);
+void sih_weak_launch_hybrid_strain(sih_ctx *c);
 void sih_weak_launch_post(sih_ctx *c);
 int sih_ir_cfl_warnings(sih_ctx *c);
 int sih_hip_fail(hipError_t e, const char *what, const char *file, int line);

@@ -171,6 +171,9 @@ class Block:
                   "principalStress2", "replacementPressure"):
             vw[k] = rc()
         self.structs["velocity_weak"] = vw
+        # velocity_weak_variational pool (Registry.xml:3768-3772)
+        self.structs["velocity_weak_variational"] = {k: rv() for k in ("strain11Vertex", "strain22Vertex",
+                                                                        "strain12Vertex")}
 
         self.structs["icestate"] = {k: (rv() if "Vertex" in k else rc()) for k in (
             "iceAreaVertex", "totalMassVertex", "iceAreaCellInitial", "totalMassCell", "openWaterArea")}

@@ -67,6 +67,12 @@ WEAK_STATIC = ("normalVectorPolygon", "normalVectorTriangle", "latCellRotated", 
 
 
 def _weak(domain):
+    """both schemes weak: the per-cell fields of the velocity_weak pool carry the state"""
+    return domain.configs["config_stress_divergence_scheme"] == "weak"
+
+
+def _weak_strain(domain):
+    """weak strain (alone or with the weak divergence): the weak initialisation is needed"""
     return domain.configs["config_strain_scheme"] == "weak"
 
 
@@ -169,7 +175,7 @@ def seaice_init_velocity_solver(domain):
         vs["elasticTimeStep"][0] = vs["dynamicsTimeStep"][0] / float(cfg["config_elastic_subcycle_number"])
         if not cfg["config_use_velocity_solver"]:
             continue
-        if _weak(domain):
+        if _weak_strain(domain):
             b.ctx.set_edge_mesh(b.structs["mesh"])
         b.ctx.evp_init(_evp_config(domain, b))
         if cfg["config_variational_basis"] == "none":
@@ -179,7 +185,7 @@ def seaice_init_velocity_solver(domain):
             b.ctx.static_changed()
         for pool, name in STATIC_OUTPUTS:
             b.ctx.get(name, b.structs[pool][name])
-        if _weak(domain):
+        if _weak_strain(domain):
             for name in WEAK_STATIC:
                 b.ctx.get(name, b.structs["velocity_weak"][name])
     if cfg["config_use_velocity_solver"]:
@@ -208,6 +214,10 @@ def _upload(domain, b):
 
 def _download(domain, b):
     items = list(RUN_OUTPUTS)
+    if _weak_strain(domain) and not _weak(domain):  # mixed scheme: the weak strains are diagnostics of it
+        b.ctx.get_many([(WEAK_FIELDS[k], b.structs["velocity_weak"][k]) for k in ("strain11", "strain22", "strain12")]
+                       + [(k, b.structs["velocity_weak_variational"][k])
+                          for k in ("strain11Vertex", "strain22Vertex", "strain12Vertex")])
     if domain.configs["config_use_column_package"]:
         items += [("ridging", "ridgeConvergence"), ("ridging", "ridgeShear")]
     b.ctx.get_many(_items(domain, b, items))

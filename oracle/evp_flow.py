@@ -90,8 +90,13 @@ def weak_scheme(cfg):
     pair = (cfg["config_strain_scheme"], cfg["config_stress_divergence_scheme"])
     if pair == ("weak", "weak"):
         return True
-    assert pair == ("variational", "variational"), pair
+    assert pair in (("variational", "variational"), ("weak", "variational")), pair
     return False
+
+
+def hybrid_scheme(cfg):
+    """weak strain interpolated to the corners, variational stress and divergence (velocity_solver.F:2768-2784)"""
+    return (cfg["config_strain_scheme"], cfg["config_stress_divergence_scheme"]) == ("weak", "variational")
 
 
 def seaice_init_velocity_solver(domain):
@@ -143,7 +148,7 @@ def seaice_init_velocity_solver(domain):
              m["areaTriangle"], m["cellsOnVertex"], vv["cellVerticesAtVertex"], vv["basisIntegralsMetric"],
              cfg["config_variational_denominator_type"] == "alternate")
         b._xLocal, b._yLocal = xl, yl
-        if weak_scheme(cfg):  # seaice_init_velocity_solver_weak, velocity_solver_weak.F:48-94
+        if weak_scheme(cfg) or hybrid_scheme(cfg):  # seaice_init_velocity_solver_weak, velocity_solver_weak.F:48-94
             vw = b.structs["velocity_weak"]
             iv = b.structs["boundary"]["interiorVertex"]
             geo = (m["xCell"], m["yCell"], m["zCell"], m["xEdge"], m["yEdge"], m["zEdge"], m["xVertex"], m["yVertex"],
@@ -285,8 +290,33 @@ def _subcycle_args_weak(domain, b):
             bool(cfg["config_use_ocean_stress"]), cfg["config_ocean_stress_type"] == "quadratic")
 
 
+def _subcycle_args_hybrid(domain, b):
+    cfg, st = domain.configs, domain.solver_state
+    d = b.dimensions
+    m, vs, vw, ic = b.structs["mesh"], b.structs["velocity_solver"], b.structs["velocity_weak"], b.structs["icestate"]
+    vv, wv = b.structs["velocity_variational"], b.structs["velocity_weak_variational"]
+    return (d["nCells"], d["nVerticesSolve"], d["nVertices"] + 1, d["maxEdges"], d["vertexDegree"],
+            m["nEdgesOnCell"], m["verticesOnCell"], m["edgesOnCell"], m["verticesOnEdge"], m["cellsOnVertex"],
+            vv["cellVerticesAtVertex"], m["dvEdge"], m["areaCell"],
+            float(m["sphere_radius"]) if m["on_a_sphere"] else 0.0, vs["solveStress"], vs["solveVelocity"],
+            vw["normalVectorPolygon"], vw["latCellRotated"], vv["basisIntegralsU"], vv["basisIntegralsV"],
+            vv["basisIntegralsMetric"], vv["variationalDenominator"], vv["tanLatVertexRotatedOverRadius"],
+            vs["icePressure"], ic["totalMassVertex"], vs["totalMassVertexfVertex"], ic["iceAreaVertex"],
+            vs["airStressVertexU"], vs["airStressVertexV"], vs["surfaceTiltForceU"], vs["surfaceTiltForceV"],
+            vs["oceanStressU"], vs["oceanStressV"], vs["uOceanVelocityVertex"], vs["vOceanVelocityVertex"],
+            vs["uVelocityInitial"], vs["vVelocityInitial"], vs["uVelocity"], vs["vVelocity"], vw["strain11"],
+            vw["strain22"], vw["strain12"], wv["strain11Vertex"], wv["strain22Vertex"], wv["strain12Vertex"],
+            vv["strain11"], vv["strain22"], vv["strain12"], vv["stress11"], vv["stress22"], vv["stress12"],
+            vv["replacementPressure"], vs["stressDivergenceU"], vs["stressDivergenceV"], vs["oceanStressCoeff"],
+            float(vs["elasticTimeStep"][0]), float(vs["dynamicsTimeStep"][0]), float(st["dampingTimescale"]),
+            float(st["numericalInertiaCoefficient"]), RELATION[cfg["config_constitutive_relation_type"]],
+            bool(cfg["config_use_ocean_stress"]), cfg["config_ocean_stress_type"] == "quadratic")
+
+
 def _subcycle_call(domain, b, n):
-    if weak_scheme(domain.configs):
+    if hybrid_scheme(domain.configs):
+        call("ora_evp_subcycle_loop_hybrid", n, *_subcycle_args_hybrid(domain, b))
+    elif weak_scheme(domain.configs):
         call("ora_evp_subcycle_loop_weak", n, *_subcycle_args_weak(domain, b))
     else:
         call("ora_evp_subcycle_loop", n, *_subcycle_args(domain, b))

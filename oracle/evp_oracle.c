@@ -1660,3 +1660,94 @@ void ora_evp_subcycle_loop_weak(int nSubcycles, int nCells, int nVerticesSolve, 
                                        oceanStressCoeff, dynamicsTimeStep, numericalInertiaCoefficient);
     }
 }
+
+/* interpolate_strains_weak_to_variational, velocity_solver.F:2877-2960: area-weighted mean of the cell strains
+ * at every owned vertex, copied to the corners of every cell */
+void ora_interpolate_strains_weak_to_variational(int nCells, int nVerticesSolve, int vertexDegree, int maxEdges,
+                                                 const int *cellsOnVertex, const int *nEdgesOnCell,
+                                                 const int *verticesOnCell, const double *areaCell,
+                                                 const double *s11w, const double *s22w, const double *s12w,
+                                                 double *s11v, double *s22v, double *s12v, double *strain11var,
+                                                 double *strain22var, double *strain12var)
+{
+    for (int v = 1; v <= nVerticesSolve; v++) {
+        double a = 0.0, b = 0.0, c12 = 0.0, denom = 0.0;
+        for (int k = 1; k <= vertexDegree; k++) {
+            int c = cellsOnVertex[IX2(k, v, vertexDegree)];
+            if (c >= 1 && c <= nCells) {
+                a = a + areaCell[c - 1] * s11w[c - 1];
+                b = b + areaCell[c - 1] * s22w[c - 1];
+                c12 = c12 + areaCell[c - 1] * s12w[c - 1];
+                denom = denom + areaCell[c - 1];
+            }
+        }
+        s11v[v - 1] = a / denom;
+        s22v[v - 1] = b / denom;
+        s12v[v - 1] = c12 / denom;
+    }
+    for (int c = 1; c <= nCells; c++)
+        for (int i = 1; i <= nEdgesOnCell[c - 1]; i++) {
+            int v = verticesOnCell[IX2(i, c, maxEdges)];
+            strain11var[IX2(i, c, maxEdges)] = s11v[v - 1];
+            strain22var[IX2(i, c, maxEdges)] = s22v[v - 1];
+            strain12var[IX2(i, c, maxEdges)] = s12v[v - 1];
+        }
+}
+
+/* one block: weak strain, variational stress and stress divergence (seaice_internal_stress :2722-2858 with
+ * config_strain_scheme = 'weak', config_stress_divergence_scheme = 'variational') */
+void ora_evp_subcycle_loop_hybrid(int nSubcycles, int nCells, int nVerticesSolve, int nVertices, int maxEdges,
+                                  int vertexDegree, const int *nEdgesOnCell, const int *verticesOnCell,
+                                  const int *edgesOnCell, const int *verticesOnEdge, const int *cellsOnVertex,
+                                  const int *cellVerticesAtVertex, const double *dvEdge, const double *areaCell,
+                                  double sphere_radius, const int *solveStress, const int *solveVelocity,
+                                  const double *normalVectorPolygon, const double *latCellRotated,
+                                  const double *basisIntegralsU, const double *basisIntegralsV,
+                                  const double *basisIntegralsMetric, const double *variationalDenominator,
+                                  const double *tanLatVertexRotatedOverRadius, const double *icePressure,
+                                  const double *totalMassVertex, const double *totalMassVertexfVertex,
+                                  const double *iceAreaVertex, const double *airStressVertexU,
+                                  const double *airStressVertexV, const double *surfaceTiltForceU,
+                                  const double *surfaceTiltForceV, const double *oceanStressU,
+                                  const double *oceanStressV, const double *uOceanVelocityVertex,
+                                  const double *vOceanVelocityVertex, const double *uVelocityInitial,
+                                  const double *vVelocityInitial, double *uVelocity, double *vVelocity,
+                                  double *s11w, double *s22w, double *s12w, double *s11v, double *s22v, double *s12v,
+                                  double *strain11, double *strain22, double *strain12, double *stress11,
+                                  double *stress22, double *stress12, double *replacementPressure,
+                                  double *stressDivergenceU, double *stressDivergenceV, double *oceanStressCoeff,
+                                  double elasticTimeStep, double dynamicsTimeStep, double dampingTimescale,
+                                  double numericalInertiaCoefficient, int relation, int useOceanStress,
+                                  int quadraticOceanStress)
+{
+    for (int it = 0; it < nSubcycles; it++) {
+        ora_strain_tensor_weak(nCells, maxEdges, nEdgesOnCell, verticesOnCell, edgesOnCell, verticesOnEdge, dvEdge,
+                               areaCell, sphere_radius, s11w, s22w, s12w, uVelocity, vVelocity, normalVectorPolygon,
+                               latCellRotated, solveStress);
+        ora_interpolate_strains_weak_to_variational(nCells, nVerticesSolve, vertexDegree, maxEdges, cellsOnVertex,
+                                                    nEdgesOnCell, verticesOnCell, areaCell, s11w, s22w, s12w, s11v,
+                                                    s22v, s12v, strain11, strain22, strain12);
+        ora_stress_tensor_variational(nCells, maxEdges, nEdgesOnCell, stress11, stress22, stress12, strain11,
+                                      strain22, strain12, icePressure, replacementPressure, solveStress,
+                                      elasticTimeStep, dampingTimescale, relation);
+        ora_stress_divergence_variational(nVerticesSolve, vertexDegree, maxEdges, nEdgesOnCell, cellsOnVertex,
+                                          cellVerticesAtVertex, stressDivergenceU, stressDivergenceV, stress11,
+                                          stress22, stress12, basisIntegralsU, basisIntegralsV,
+                                          basisIntegralsMetric, variationalDenominator,
+                                          tanLatVertexRotatedOverRadius, solveVelocity);
+        ora_ocean_stress_coefficient(nVerticesSolve, nVertices, useOceanStress, quadraticOceanStress, solveVelocity,
+                                     oceanStressCoeff, uOceanVelocityVertex, vOceanVelocityVertex, uVelocity,
+                                     vVelocity, iceAreaVertex);
+        if (relation == 1)
+            ora_solve_velocity(nVerticesSolve, solveVelocity, uVelocity, vVelocity, totalMassVertex,
+                               totalMassVertexfVertex, stressDivergenceU, stressDivergenceV, airStressVertexU,
+                               airStressVertexV, surfaceTiltForceU, surfaceTiltForceV, oceanStressU, oceanStressV,
+                               oceanStressCoeff, elasticTimeStep);
+        else if (relation == 2)
+            ora_solve_velocity_revised(nVerticesSolve, solveVelocity, uVelocity, vVelocity, uVelocityInitial,
+                                       vVelocityInitial, totalMassVertex, totalMassVertexfVertex,
+                                       stressDivergenceU, stressDivergenceV, airStressVertexU, airStressVertexV,
+                                       surfaceTiltForceU, surfaceTiltForceV, oceanStressU, oceanStressV,
+                                       oceanStressCoeff, dynamicsTimeStep, numericalInertiaCoefficient);
+    }
+}

@@ -246,12 +246,24 @@ def test_weak_scheme(oracle, mesh_name, extra):
     assert np.abs(ref.blocklist[0].structs["velocity_weak"]["stress12"]).max() > 0
 
 
-def test_mixed_schemes_are_refused():
+@pytest.mark.parametrize("mesh_name", ["QU480", "hex_24_20", "var12"])
+def test_weak_strain_with_variational_divergence(oracle, mesh_name):
+    """config_strain_scheme = 'weak' with the default variational stress divergence: weak cell strains averaged
+    to the vertices and copied to the cell corners (interpolate_strains_weak_to_variational)."""
+    cfg = {"config_strain_scheme": "weak", "config_elastic_subcycle_number": 40}
+    if mesh_name == "var12":
+        cfg["config_dt"] = 1800.0
+    ref, dev = _run_both(oracle, mesh_name, cfg)
+    compare_domains(dev, ref, STATE + [("velocity_weak", "strain11"), ("velocity_weak", "strain12"),
+                                       ("velocity_weak_variational", "strain22Vertex")], 1e-10)
+
+
+def test_variational_strain_with_weak_divergence_is_refused():
     from mpas_seaice_amd.lib import SeaiceHipError
-    dom = cases.make_domain(get_mesh("QU480"), "QU480", configs={"config_strain_scheme": "weak"})
+    dom = cases.make_domain(get_mesh("QU480"), "QU480", configs={"config_stress_divergence_scheme": "weak"})
     vs.seaice_mesh_pool_create(dom)
     try:
-        with pytest.raises(SeaiceHipError, match="both 'variational' or both 'weak'"):
+        with pytest.raises(SeaiceHipError, match="Cannot have variational strain scheme"):
             vs.seaice_init_velocity_solver(dom)
     finally:
         vs.seaice_mesh_pool_destroy(dom)
