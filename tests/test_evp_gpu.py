@@ -267,3 +267,81 @@ def test_variational_strain_with_weak_divergence_is_refused():
             vs.seaice_init_velocity_solver(dom)
     finally:
         vs.seaice_mesh_pool_destroy(dom)
+
+
+def _pad_max_edges(mesh, M2):
+    """the same mesh declared with a larger maxEdges (extra connectivity rows hold the "none" sentinels)"""
+    from mpas_seaice_amd.mesh import Mesh
+    out = Mesh(mesh)
+    M = int(mesh["maxEdges"])
+    fill = {"verticesOnCell": mesh["nVertices"] + 1, "edgesOnCell": mesh["nEdges"] + 1, "cellsOnCell": mesh["nCells"] + 1}
+    for k, f in fill.items():
+        a = np.full((M2, mesh["nCells"]), f, dtype=np.int32, order="F")
+        a[:M] = mesh[k]
+        out[k] = a
+    cr = np.zeros((3, M2, mesh["nCells"]), order="F")
+    cr[:, :M] = mesh["coeffs_reconstruct"]
+    out["coeffs_reconstruct"] = cr
+    out["maxEdges"] = M2
+    return out
+
+
+@pytest.mark.parametrize("M2", [8, 10])
+def test_larger_max_edges_instantiations(oracle, M2):
+    """maxEdges 8 and 10 (the largest the kernels are instantiated for) on a mesh whose cells have 5-7 edges:
+    the oracle with the same padded arrays, and the unpadded device run bit for bit (padding changes nothing)."""
+    from mpas_seaice_amd import advection as adv
+    from oracle import ir_flow
+    base = get_mesh("var12")
+    mesh = _pad_max_edges(base, M2)
+    cfg = {"config_elastic_subcycle_number": 30, "config_dt": 1800.0}
+    doms = [cases.make_domain(m, None, configs=cfg, open_water_band=(-0.2, 0.3)) for m in (mesh, mesh, base)]
+    ref, dev, plain = doms
+    oracle.seaice_init_velocity_solver(ref)
+    ir_flow.seaice_init_advection(ref)
+    oracle.seaice_run_velocity_solver(ref)
+    ir_flow.seaice_run_advection(ref)
+    for d in (dev, plain):
+        vs.seaice_mesh_pool_create(d)
+        try:
+            vs.seaice_init_velocity_solver(d)
+            adv.seaice_init_advection(d)
+            vs.seaice_run_velocity_solver(d)
+            adv.seaice_run_advection(d)
+        finally:
+            vs.seaice_mesh_pool_destroy(d)
+    tr = [("tracers", k) for k in ("iceAreaCategory", "iceVolumeCategory", "iceEnthalpy", "snowEnthalpy")]
+    compare_domains(dev, ref, STATE + tr, 1e-10)
+    M = int(base["maxEdges"])
+    for pool, name in STATE + tr:
+        a, b = dev.blocklist[0].structs[pool][name], plain.blocklist[0].structs[pool][name]
+        if a.shape != b.shape:  # per-corner fields: compare the corners that exist
+            a = a[:M]
+        assert np.array_equal(a, b), name
+
+
+def test_ice_free_domain(oracle):
+    """Nothing to solve anywhere: masks are all zero, velocities and stresses stay zero, the advection leaves
+    the (empty) state alone, nothing is NaN."""
+    from mpas_seaice_amd import advection as adv
+    dom = cases.make_domain(get_mesh("QU480"), "QU480", configs={"config_conservation_check": True})
+    b = dom.blocklist[0]
+    for k in ("iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory"):
+        b.structs["tracers"][k][:] = 0.0
+    vs.seaice_mesh_pool_create(dom)
+    try:
+        vs.seaice_init_velocity_solver(dom)
+        adv.seaice_init_advection(dom)
+        vs.seaice_run_velocity_solver(dom)
+        adv.seaice_run_advection(dom)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+    vsol = b.structs["velocity_solver"]
+    assert vsol["solveStress"].max() == 0 and vsol["solveVelocity"].max() == 0
+    for pool, name in STATE:
+        a = b.structs[pool][name]
+        if a.dtype.kind == "f":
+            assert np.isfinite(a).all() and np.abs(a).max() == 0.0, name
+    for k, a in b.structs["tracers"].items():
+        assert np.isfinite(a).all(), k
+    assert np.abs(b.structs["tracers"]["iceAreaCategory"]).max() == 0.0
