@@ -292,6 +292,47 @@ module seaice_hip_interface
        integer(c_int) :: ierr
      end function sih_ir_get_sums
 
+     ! ---- upwind advection (config_advection_type = 'upwind') ----
+     function sih_upwind_init(ctx, desc) bind(C, name="sih_upwind_init") result(ierr)
+       import :: sih_ir_desc, c_int, c_ptr
+       type(c_ptr), value :: ctx
+       type(sih_ir_desc), intent(in) :: desc
+       integer(c_int) :: ierr
+     end function sih_upwind_init
+
+     ! checks: 1 = config_conservation_check
+     function sih_upwind_prepare(ctx, checks) bind(C, name="sih_upwind_prepare") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: checks
+       integer(c_int) :: ierr
+     end function sih_upwind_prepare
+
+     function sih_upwind_advect(ctx, dt, checks) bind(C, name="sih_upwind_advect") result(ierr)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: dt
+       integer(c_int), value :: checks
+       integer(c_int) :: ierr
+     end function sih_upwind_advect
+
+     function sih_upwind_run(ctx, dt, checks) bind(C, name="sih_upwind_run") result(ierr)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: dt
+       integer(c_int), value :: checks
+       integer(c_int) :: ierr
+     end function sih_upwind_run
+
+     function sih_upwind_get_sums(ctx, tracer, initSums, finalSums) bind(C, name="sih_upwind_get_sums") &
+          result(ierr)
+       import :: c_int, c_ptr, c_char
+       type(c_ptr), value :: ctx
+       character(kind=c_char), dimension(*), intent(in) :: tracer
+       type(c_ptr), value :: initSums, finalSums
+       integer(c_int) :: ierr
+     end function sih_upwind_get_sums
+
      function sih_ir_run_timed(ctx, dt, totalMs, phaseMs5) bind(C, name="sih_ir_run_timed") result(ierr)
        import :: c_int, c_ptr, c_double
        type(c_ptr), value :: ctx

@@ -310,6 +310,36 @@ int sih_ir_get_sums(sih_ctx *ctx, const char *tracer, double *initSums, double *
  * (phases: 0 conversion+masks, 1 reconstruction, 2 departure triangles, 3 fluxes, 4 update+zap) */
 int sih_ir_run_timed(sih_ctx *ctx, double dt, double *totalMs, double *phaseMs5);
 
+/* ---- upwind advection ----------------------------------------------------------------------------
+ * Replaces, for one block, seaice_init_advection_upwind and the per-block parts of
+ * seaice_run_advection_upwind (src/shared/mpas_seaice_advection_upwind.F:79, :385), the alternative the
+ * reference selects with config_advection_type = 'upwind' (mpas_seaice_advection.F:64, :115).  The tracers are
+ * the reference's chain (define_tracer_connectivities :145-189): iceAreaCategory, surfaceTemperature,
+ * iceVolumeCategory, snowVolumeCategory, each a field of nCategories values per cell.  Beside them the
+ * library keeps, per tracer, the second time level "<tracer>Level2", the tendency "<tracer>Tend" (cells) and
+ * the edge flux "<tracer>EdgeFlux" (nCategories values per edge), as the reference leaves them in its
+ * tracers / tracer_tendencies / tracer_edge_fluxes pools, plus normalVectorEdge (2, maxEdges, nCells),
+ * edgeVelocity (nEdges) and interiorEdge (nEdges, int). */
+
+/* seaice_init_advection_upwind (:79-131): the edge normals seaice_normal_vectors_polygon(.., rotate, .false.)
+ * (mesh.F:760) and interior_edges (mesh.F:567) for every edge of the block.  coeffsReconstruct may be NULL. */
+int sih_upwind_init(sih_ctx *ctx, const sih_ir_desc *desc);
+/* prepare_advection (:1549-1619): zeroes the second time level, tendencies and edge fluxes, computes the edge
+ * velocities from uVelocity / vVelocity, converts the volumes to thickness on every cell of the block;
+ * checks & 1 also evaluates initial_conservation (:2454).  A multi-block host exchanges the halos of the four
+ * tracers between this call and sih_upwind_advect (halo_exchange_advection :1786). */
+int sih_upwind_prepare(sih_ctx *ctx, int checks);
+/* the tracer loop (:479-504) and finalize_advection (:1840): per tracer the upwind fluxes, tendencies and new
+ * values with time step dt, then the time levels trade places ("<tracer>" holds the new values,
+ * "<tracer>Level2" the old ones multiplied by their parents), the products are divided back (owned cells) and
+ * thickness becomes volume; checks & 1 also evaluates final_conservation (:2571) */
+int sih_upwind_advect(sih_ctx *ctx, double dt, int checks);
+/* sih_upwind_prepare followed by sih_upwind_advect, for a block that needs no halo exchange */
+int sih_upwind_run(sih_ctx *ctx, double dt, int checks);
+/* the aggregates of the last run with checks & 1 (tracer_conservation pool, time levels 1 and 2):
+ * nCategories values each */
+int sih_upwind_get_sums(sih_ctx *ctx, const char *tracer, double *initSums, double *finalSums);
+
 /* introspection for tests and reports.  Keys: sparseGradient, splitCellKernel, dampingTimescale,
  * elasticTimeStep, dynamicsTimeStep, numericalInertiaCoefficient, padC, padV, minDvEdge, and
  * irCflWarnings: number of vertices whose departure distance in the last sih_ir_run exceeded the

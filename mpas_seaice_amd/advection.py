@@ -1,8 +1,8 @@
 """Host mirror of the reference's advection driver for the device library.
 
 ``seaice_init_advection`` / ``seaice_run_advection`` follow
-/root/reference/src/shared/mpas_seaice_advection.F:40-140 and, for ``config_advection_type =
-'incremental_remap'``, /root/reference/src/shared/mpas_seaice_advection_incremental_remap.F
+/root/reference/src/shared/mpas_seaice_advection.F:40-140 (``config_advection_type = 'upwind'`` goes to
+``advection_upwind``) and, for ``config_advection_type = 'incremental_remap'``, /root/reference/src/shared/mpas_seaice_advection_incremental_remap.F
 (seaice_init_advection_incremental_remap :165, seaice_run_advection_incremental_remap :2338).  The
 per-block arithmetic runs in libseaice_hip.so (sih_ir_*); this module keeps the reference's call
 sequence: halo updates of velocity and tracers, the block loop, the conservation check with its global
@@ -21,8 +21,11 @@ def seaice_init_advection(domain):
     cfg = domain.configs
     if not cfg.get("config_use_advection", True):
         return
+    if cfg["config_advection_type"] == "upwind":  # mpas_seaice_advection.F:64-66
+        from . import advection_upwind
+        return advection_upwind.seaice_init_advection_upwind(domain)
     if cfg["config_advection_type"] != "incremental_remap":
-        raise SeaiceHipError("config_advection_type: only 'incremental_remap' is implemented on the device")
+        raise SeaiceHipError("config_advection_type: unknown option " + str(cfg["config_advection_type"]))
     # check_halo_layer_number, incremental_remap.F:829-874
     if getattr(domain, "comm", None) is not None and int(cfg.get("config_num_halos", 2)) < 2:
         raise SeaiceHipError("IR requires at least two halo layers (config_num_halos)")
@@ -61,6 +64,9 @@ def seaice_run_advection(domain, updateHaloInit=True, updateHaloFinal=False, upl
     cfg = domain.configs
     if not cfg.get("config_use_advection", True):
         return
+    if cfg["config_advection_type"] == "upwind":  # mpas_seaice_advection.F:115-119
+        from . import advection_upwind
+        return advection_upwind.seaice_run_advection_upwind(domain, upload=upload, download=download)
     tracersHead = domain.solver_state["tracersHead"]
     names = [t.tracerName for t in tracersHead]
     comm = getattr(domain, "comm", None)

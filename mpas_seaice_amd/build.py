@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libseaice_hip.so")
-SOURCES = ["sih_core.hip", "evp_init.hip", "evp_step.hip", "evp_weak.hip", "ir_advect.hip"]
+SOURCES = ["sih_core.hip", "evp_init.hip", "evp_step.hip", "evp_weak.hip", "ir_advect.hip", "upwind_advect.hip"]
 
 
 def hipcc():
@@ -23,7 +23,8 @@ def needs_build():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(HERE, "csrc", s) for s in SOURCES] + [
-        os.path.join(HERE, "csrc", "sih_internal.h"), os.path.join(ROOT, "include", "seaice_hip.h")]
+        os.path.join(HERE, "csrc", "sih_internal.h"), os.path.join(HERE, "csrc", "sih_normals.h"),
+        os.path.join(ROOT, "include", "seaice_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 

@@ -1198,21 +1198,11 @@ static int uploadPlaneInts(sih_ctx *c, int *dst, const std::vector<int> &v)
     return SIH_OK;
 }
 
-extern "C" int sih_ir_init(sih_ctx *c, const sih_ir_desc *m)
+// The edge description of the mesh on the device, shared by the incremental remap and the upwind advection:
+// validation of the host's index arrays, the internal edge numbering, the connectivity tables _eoc / _coe /
+// _voe / _eov in internal numbering and the edge coordinates and lengths.
+int sih_setup_edges(sih_ctx *c, const sih_ir_desc *m, const char *who)
 {
-    if (!c || !m) {
-        sih_set_error("sih_ir_init: null argument");
-        return SIH_ERR_ARG;
-    }
-    if (!m->edgesOnCell || !m->cellsOnEdge || !m->verticesOnEdge || !m->edgesOnVertex || !m->xEdge || !m->yEdge ||
-        !m->zEdge || !m->dcEdge || !m->dvEdge || !m->coeffsReconstruct || m->nCategories < 1 || c->nEdges < 1) {
-        sih_set_error("sih_ir_init: incomplete edge description of the mesh");
-        return SIH_ERR_ARG;
-    }
-    if (c->D != 3) {
-        sih_set_error("incremental remap: only vertexDegree = 3 (hexagonal meshes) is implemented");
-        return SIH_ERR_UNSUPPORTED;
-    }
     HIPCHK(hipSetDevice(c->device));
     const int nC = c->nCells, nV = c->nVertices, nE = c->nEdges, M = c->M;
     // validate connectivity before the device dereferences it
@@ -1220,7 +1210,7 @@ extern "C" int sih_ir_init(sih_ctx *c, const sih_ir_desc *m)
         for (int k = 0; k < 2; k++) {
             int cc = m->cellsOnEdge[(size_t)e * 2 + k], vv = m->verticesOnEdge[(size_t)e * 2 + k];
             if (cc < 0 || cc > nC + 1 || vv < 1 || vv > nV) {
-                sih_set_error("sih_ir_init: cellsOnEdge / verticesOnEdge index out of range");
+                sih_set_error(std::string(who) + ": cellsOnEdge / verticesOnEdge index out of range");
                 return SIH_ERR_ARG;
             }
         }
@@ -1228,20 +1218,15 @@ extern "C" int sih_ir_init(sih_ctx *c, const sih_ir_desc *m)
         for (int s = 0; s < M; s++) {
             int e = m->edgesOnCell[(size_t)i * M + s];
             if (e < 0 || e > nE + 1) {
-                sih_set_error("sih_ir_init: edgesOnCell index out of range");
+                sih_set_error(std::string(who) + ": edgesOnCell index out of range");
                 return SIH_ERR_ARG;
             }
         }
     for (size_t k = 0; k < (size_t)nV * 3; k++)
         if (m->edgesOnVertex[k] < 0 || m->edgesOnVertex[k] > nE + 1) {
-            sih_set_error("sih_ir_init: edgesOnVertex index out of range");
+            sih_set_error(std::string(who) + ": edgesOnVertex index out of range");
             return SIH_ERR_ARG;
         }
-    if (c->ir) sih_ir_destroy(c);
-    sih_ir_state *ir = new sih_ir_state();
-    c->ir = ir;
-    ir->nCat = m->nCategories;
-
     // internal edge numbering: edges follow the lower-numbered (internal) of their two cells
     c->edgePerm.resize(nE);
     for (int e = 0; e < nE; e++) c->edgePerm[e] = e;
@@ -1261,32 +1246,19 @@ extern "C" int sih_ir_init(sih_ctx *c, const sih_ir_desc *m)
     HIPCHK(hipMemcpyAsync(c->d_edgePerm, c->edgePerm.data(), sizeof(int) * nE, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
 
-    struct Spec {
+    const struct {
         const char *name;
         SihLoc loc;
         int lead;
         bool isInt;
-    };
-    const Spec specs[] = {
+    } specs[] = {
         {"_eoc", LOC_CELL, M, true}, {"_coe", LOC_EDGE, 2, true}, {"_voe", LOC_EDGE, 2, true},
-        {"_eov", LOC_VERTEX, 3, true}, {"remapEdge", LOC_EDGE, 1, true}, {"_eoer", LOC_EDGE, 4, true},
-        {"_coer", LOC_EDGE, 4, true}, {"_g2c", LOC_CELL, 6, false},
-        {"xVertexOnCell", LOC_CELL, M, false}, {"yVertexOnCell", LOC_CELL, M, false},
-        {"xVertexOnEdge", LOC_EDGE, 6, false}, {"yVertexOnEdge", LOC_EDGE, 6, false},
-        {"geomAvgCell", LOC_CELL, 14, false}, {"minLengthEdgesOnVertex", LOC_VERTEX, 1, false},
-        {"xEdge", LOC_EDGE, 1, false}, {"yEdge", LOC_EDGE, 1, false}, {"zEdge", LOC_EDGE, 1, false},
-        {"dcEdge", LOC_EDGE, 1, false}, {"dvEdge", LOC_EDGE, 1, false},
-        {"coeffs_reconstruct", LOC_CELL, 3 * M, false},
-        {"departurePoint", LOC_VERTEX, 2, false}, {"_triCount", LOC_EDGE, 1, true},
-        {"_triCell", LOC_EDGE, NTRI, true}, {"xTriangle", LOC_EDGE, 3 * NTRI, false},
-        {"yTriangle", LOC_EDGE, 3 * NTRI, false}, {"triangleArea", LOC_EDGE, NTRI, false},
-        {"maskCell", LOC_CELL, 1, true},
+        {"_eov", LOC_VERTEX, 3, true}, {"xEdge", LOC_EDGE, 1, false}, {"yEdge", LOC_EDGE, 1, false},
+        {"zEdge", LOC_EDGE, 1, false}, {"dcEdge", LOC_EDGE, 1, false}, {"dvEdge", LOC_EDGE, 1, false},
     };
-    for (const Spec &s : specs)
+    for (const auto &s : specs)
         if ((rc = sih_add_field(c, s.name, s.loc, s.lead, s.isInt))) return rc;
     auto fi = [&](const char *n) { return (int *)sih_find_field(c, n)->d; };
-    auto fd = [&](const char *n) { return (double *)sih_find_field(c, n)->d; };
-
     // connectivity in internal numbering
     {
         std::vector<int> eoc((size_t)M * c->padC, nE), coe((size_t)2 * c->padE, nC), voe((size_t)2 * c->padE, nV),
@@ -1323,6 +1295,59 @@ extern "C" int sih_ir_init(sih_ctx *c, const sih_ir_desc *m)
     if ((rc = sih_field_put(c, "zEdge", m->zEdge, nE))) return rc;
     if ((rc = sih_field_put(c, "dcEdge", m->dcEdge, nE))) return rc;
     if ((rc = sih_field_put(c, "dvEdge", m->dvEdge, nE))) return rc;
+    return SIH_OK;
+}
+
+extern "C" int sih_ir_init(sih_ctx *c, const sih_ir_desc *m)
+{
+    if (!c || !m) {
+        sih_set_error("sih_ir_init: null argument");
+        return SIH_ERR_ARG;
+    }
+    if (!m->edgesOnCell || !m->cellsOnEdge || !m->verticesOnEdge || !m->edgesOnVertex || !m->xEdge || !m->yEdge ||
+        !m->zEdge || !m->dcEdge || !m->dvEdge || !m->coeffsReconstruct || m->nCategories < 1 || c->nEdges < 1) {
+        sih_set_error("sih_ir_init: incomplete edge description of the mesh");
+        return SIH_ERR_ARG;
+    }
+    if (c->D != 3) {
+        sih_set_error("incremental remap: only vertexDegree = 3 (hexagonal meshes) is implemented");
+        return SIH_ERR_UNSUPPORTED;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    const int nC = c->nCells, nV = c->nVertices, nE = c->nEdges, M = c->M;
+    int rc;
+    if ((rc = sih_setup_edges(c, m, "sih_ir_init"))) return rc;
+    if (c->ir) sih_ir_destroy(c);
+    sih_ir_state *ir = new sih_ir_state();
+    c->ir = ir;
+    ir->nCat = m->nCategories;
+
+    struct Spec {
+        const char *name;
+        SihLoc loc;
+        int lead;
+        bool isInt;
+    };
+    const Spec specs[] = {
+        {"_eoc", LOC_CELL, M, true}, {"_coe", LOC_EDGE, 2, true}, {"_voe", LOC_EDGE, 2, true},
+        {"_eov", LOC_VERTEX, 3, true}, {"remapEdge", LOC_EDGE, 1, true}, {"_eoer", LOC_EDGE, 4, true},
+        {"_coer", LOC_EDGE, 4, true}, {"_g2c", LOC_CELL, 6, false},
+        {"xVertexOnCell", LOC_CELL, M, false}, {"yVertexOnCell", LOC_CELL, M, false},
+        {"xVertexOnEdge", LOC_EDGE, 6, false}, {"yVertexOnEdge", LOC_EDGE, 6, false},
+        {"geomAvgCell", LOC_CELL, 14, false}, {"minLengthEdgesOnVertex", LOC_VERTEX, 1, false},
+        {"xEdge", LOC_EDGE, 1, false}, {"yEdge", LOC_EDGE, 1, false}, {"zEdge", LOC_EDGE, 1, false},
+        {"dcEdge", LOC_EDGE, 1, false}, {"dvEdge", LOC_EDGE, 1, false},
+        {"coeffs_reconstruct", LOC_CELL, 3 * M, false},
+        {"departurePoint", LOC_VERTEX, 2, false}, {"_triCount", LOC_EDGE, 1, true},
+        {"_triCell", LOC_EDGE, NTRI, true}, {"xTriangle", LOC_EDGE, 3 * NTRI, false},
+        {"yTriangle", LOC_EDGE, 3 * NTRI, false}, {"triangleArea", LOC_EDGE, NTRI, false},
+        {"maskCell", LOC_CELL, 1, true},
+    };
+    for (const Spec &s : specs)
+        if ((rc = sih_add_field(c, s.name, s.loc, s.lead, s.isInt))) return rc;
+    auto fi = [&](const char *n) { return (int *)sih_find_field(c, n)->d; };
+    auto fd = [&](const char *n) { return (double *)sih_find_field(c, n)->d; };
+
     if ((rc = sih_field_put(c, "coeffs_reconstruct", m->coeffsReconstruct, (size_t)3 * M * nC))) return rc;
 
     IrDev &d = ir->d;

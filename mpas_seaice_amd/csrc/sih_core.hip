@@ -415,6 +415,7 @@ extern "C" int sih_block_destroy(sih_ctx *c)
     if (c->graphExec) (void)hipGraphExecDestroy(c->graphExec);
     sih_ir_destroy(c);
     sih_weak_destroy(c);
+    sih_upwind_destroy(c);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     for (void *p : c->allocs) (void)hipFree(p);
     for (int k = 0; k < 2; k++) {

@@ -65,6 +65,7 @@ struct sih_ctx {
     int *d_cellPerm = nullptr, *d_vertPerm = nullptr, *d_edgePerm = nullptr;
     struct sih_ir_state *ir = nullptr;                       // incremental-remap advection state
     struct sih_weak_state *weak = nullptr;                   // weak strain / stress-divergence scheme
+    struct sih_upwind_state *upwind = nullptr;               // upwind advection state
     std::map<std::string, SihField> fields;
     std::vector<void *> allocs;
     char *arenaBase = nullptr;  // current chunk of the device arena
@@ -118,6 +119,8 @@ int sih_add_field(sih_ctx *c, const char *name, SihLoc loc, int lead, bool isInt
 int sih_dev_alloc(sih_ctx *c, void **p, size_t bytes);
 void sih_ir_destroy(sih_ctx *c);
 void sih_weak_destroy(sih_ctx *c);
+void sih_upwind_destroy(sih_ctx *c);
+int sih_setup_edges(sih_ctx *c, const sih_ir_desc *m, const char *who);
 int sih_weak_init(sih_ctx *c);
 void sih_weak_bind(sih_ctx *c);
 void sih_weak_launch_pre(sih_ctx *c);

@@ -73,6 +73,7 @@ EXPORTS = [
     "sih_ir_init", "sih_ir_set_tracers", "sih_ir_run", "sih_ir_get_sums", "sih_ir_run_timed",
     "sih_fields_put", "sih_fields_get", "sih_evp_overlap_setup", "sih_evp_subcycle_parts",
     "sih_evp_set_special_boundaries", "sih_ir_check_monotonicity", "sih_evp_set_edge_mesh",
+    "sih_upwind_init", "sih_upwind_prepare", "sih_upwind_advect", "sih_upwind_run", "sih_upwind_get_sums",
 ]
 
 
@@ -136,6 +137,11 @@ def load():
     lib.sih_ir_get_sums.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.sih_ir_run_timed.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
                                      ctypes.c_void_p]
+    lib.sih_upwind_init.argtypes = [ctypes.c_void_p, ctypes.POINTER(IrDesc)]
+    lib.sih_upwind_prepare.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.sih_upwind_advect.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int]
+    lib.sih_upwind_run.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int]
+    lib.sih_upwind_get_sums.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p]
     _lib = lib
     return lib
 
@@ -373,6 +379,28 @@ class BlockContext:
         ph = np.zeros(5)
         check(self._lib.sih_ir_run_timed(self.handle, float(dt), ctypes.byref(t), _ptr(ph)), "sih_ir_run_timed")
         return t.value, ph
+
+    # -- upwind advection -----------------------------------------------------------------------
+    def upwind_init(self, mesh_pool, nCategories, rotate):
+        d = self._edge_desc(mesh_pool)
+        d.nCategories = int(nCategories)
+        d.rotateCartesianGrid = int(bool(rotate))
+        check(self._lib.sih_upwind_init(self.handle, ctypes.byref(d)), "sih_upwind_init")
+
+    def upwind_prepare(self, check_conservation=False):
+        check(self._lib.sih_upwind_prepare(self.handle, int(bool(check_conservation))), "sih_upwind_prepare")
+
+    def upwind_advect(self, dt, check_conservation=False):
+        check(self._lib.sih_upwind_advect(self.handle, float(dt), int(bool(check_conservation))), "sih_upwind_advect")
+
+    def upwind_run(self, dt, check_conservation=False):
+        check(self._lib.sih_upwind_run(self.handle, float(dt), int(bool(check_conservation))), "sih_upwind_run")
+
+    def upwind_get_sums(self, name, n):
+        a = np.zeros(n)
+        b = np.zeros(n)
+        check(self._lib.sih_upwind_get_sums(self.handle, name.encode(), _ptr(a), _ptr(b)), "sih_upwind_get_sums")
+        return a, b
 
     def info(self, key):
         v = ctypes.c_double(0)

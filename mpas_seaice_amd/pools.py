@@ -215,3 +215,34 @@ def mpas_pool_get_subpool(block, name):
 
 def mpas_pool_get_array(pool, name):
     return pool[name]
+
+
+# tracers the upwind advection knows about (mpas_seaice_advection_upwind.F:1691-1697)
+UPWIND_POOL_TRACERS = ("iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory", "surfaceTemperature",
+                       "iceEnthalpy", "iceSalinity", "snowEnthalpy")
+
+
+def allocate_upwind_pools(block):
+    """The pools only the upwind advection touches, allocated on first use: the second time level of
+    ``tracers`` and ``tracer_conservation`` (time_levs="2", Registry.xml:2439, :3351), ``tracer_tendencies``
+    (:2706-2714), ``tracer_edge_fluxes`` (:2788-2795) and ``normalVectorEdge`` of the velocity_solver pool."""
+    if "tracers_level2" in block.structs:
+        return
+    d = block.dimensions
+    nC, nE, M, nCat = d["nCells"], d["nEdges"], d["maxEdges"], d["nCategories"]
+    tr = block.structs["tracers"]
+    block.structs["tracers_level2"] = {k: np.zeros_like(v, order="F") for k, v in tr.items()}
+    block.structs["tracer_tendencies"] = {k + "Tend": np.zeros_like(tr[k], order="F") for k in UPWIND_POOL_TRACERS}
+    block.structs["tracer_edge_fluxes"] = {
+        k + "EdgeFlux": np.zeros(tr[k].shape[:2] + (nE + 1,), order="F") for k in UPWIND_POOL_TRACERS}
+    for lev in ("tracer_conservation", "tracer_conservation_level2"):
+        block.structs[lev] = {k + "Cons": np.zeros(tr[k].shape[:2], order="F") for k in UPWIND_POOL_TRACERS}
+    block.structs["velocity_solver"]["normalVectorEdge"] = np.zeros((2, M, nC + 1), order="F")
+
+
+def mpas_pool_shift_time_levels(block, pool):
+    """MPAS_pool_shift_time_levels for a pool with two time levels: the levels trade places."""
+    a, b = block.structs[pool], block.structs[pool + "_level2"]
+    for k in a:
+        if k in b:
+            a[k], b[k] = b[k], a[k]

@@ -41,7 +41,9 @@ def call(name, *args):
     fn.restype = None
     cargs = []
     for a in args:
-        if isinstance(a, np.ndarray):
+        if a is None:
+            cargs.append(ctypes.c_void_p(0))
+        elif isinstance(a, np.ndarray):
             assert a.flags["F_CONTIGUOUS"] or a.flags["C_CONTIGUOUS"], name
             cargs.append(ctypes.c_void_p(a.ctypes.data))
         elif isinstance(a, (bool, np.bool_)):
