@@ -51,6 +51,39 @@ def velocities_strains_analytical(lat, lon, mu=3, lu=5, mv=2, lv=4, r=1.0):
     return u, v, e11, e22, e12
 
 
+def _d2P(m, l, x):
+    # Legendre's equation: (1 - x^2) P'' - 2 x P' + (l (l + 1) - m^2 / (1 - x^2)) P = 0
+    return (2.0 * x * _dP(m, l, x) - (l * (l + 1) - m * m / (1.0 - x * x)) * _P(m, l, x)) / (1.0 - x * x)
+
+
+def real_harmonic_second_derivs(lon, lat, m, l):
+    """d2/dlon2, d2/dlondlat, d2/dlat2 of the real harmonic."""
+    x, c = np.sin(lat), np.cos(lat)
+    k = np.sqrt(2.0) * _K(m, l)
+    lonlon = -m * m * k * np.cos(m * lon) * _P(m, l, x)
+    lonlat = -m * k * np.sin(m * lon) * _dP(m, l, x) * c
+    latlat = k * np.cos(m * lon) * (_d2P(m, l, x) * c * c - _dP(m, l, x) * x)
+    return lonlon, lonlat, latlat
+
+
+def stress_divergence_analytical(lat, lon, mu=3, lu=5, mv=2, lv=4, r=1.0):
+    """divergence of the stress field sigma = strain(u, v) on the sphere, metric terms included
+    (/root/reference/testing_and_setup/testcases/spherical_operators/stress_divergence/create_ic.py:574-603)"""
+    u, v, e11, e22, e12 = velocities_strains_analytical(lat, lon, mu, lu, mv, lv, r)
+    du_dlon, du_dlat = real_harmonic_derivs(lon, lat, mu, lu)
+    dv_dlon, dv_dlat = real_harmonic_derivs(lon, lat, mv, lv)
+    d2u_lonlon, d2u_lonlat, d2u_latlat = real_harmonic_second_derivs(lon, lat, mu, lu)
+    d2v_lonlon, d2v_lonlat, d2v_latlat = real_harmonic_second_derivs(lon, lat, mv, lv)
+    c, t = np.cos(lat), np.tan(lat)
+    de11_dlon = (1.0 / (r * c)) * (d2u_lonlon - dv_dlon * np.sin(lat))
+    de22_dlat = d2v_latlat / r
+    de12_dlon = (0.5 / r) * (d2u_lonlat + du_dlon * t + d2v_lonlon / c)
+    de12_dlat = (0.5 / r) * (d2u_latlat + du_dlat * t + u / c ** 2 + d2v_lonlat / c + dv_dlon * (t / c))
+    divu = (1.0 / (r * c)) * de11_dlon + (1.0 / r) * de12_dlat - (2.0 / r) * t * e12
+    divv = (1.0 / (r * c)) * de12_dlon + (1.0 / r) * de22_dlat + (1.0 / r) * t * e11 - (1.0 / r) * t * e22
+    return divu, divv
+
+
 # values of the reference's velocities_strains_analytical(0.7, 1.1, 3, 5, 2, 4)
 SPHERE_SAMPLE = dict(lat=0.7, lon=1.1, u=-0.59121435168, v=-0.31027979175, e11=0.63179002647,
                      e22=-0.60078848715, e12=-1.01789907063)

@@ -69,6 +69,56 @@ def test_sphere_strain_converges_to_spherical_harmonic_answer(oracle):
     assert np.log2(e16 / e32) > 0.9, (e8, e16, e32)
 
 
+def test_analytic_stress_divergence_is_the_derivative_of_the_analytic_strain():
+    """The second-derivative formulas restated from the reference's stress-divergence case, checked against
+    central differences of the (sample-pinned) analytic strains with the same metric terms."""
+    lat, lon, h = 0.7, 1.1, 1e-5
+    divu, divv = analytic.stress_divergence_analytical(lat, lon)
+
+    def e(la, lo):
+        return analytic.velocities_strains_analytical(la, lo)[2:]
+    d_lon = [(a - b) / (2 * h) for a, b in zip(e(lat, lon + h), e(lat, lon - h))]
+    d_lat = [(a - b) / (2 * h) for a, b in zip(e(lat + h, lon), e(lat - h, lon))]
+    e11, e22, e12 = e(lat, lon)
+    c, t = np.cos(lat), np.tan(lat)
+    fu = d_lon[0] / c + d_lat[2] - 2.0 * t * e12
+    fv = d_lon[2] / c + d_lat[1] + t * e11 - t * e22
+    assert abs(fu - divu) < 1e-6 * abs(divu) and abs(fv - divv) < 1e-6 * abs(divv)
+
+
+def sphere_stress_divergence_error(oracle, n):
+    """stress := analytic strain at the cell corners; the variational divergence against the analytic one
+    (the reference's spherical_operators/stress_divergence case)"""
+    mesh = meshmod.make_sphere_mesh(n, radius=1.0)
+    dom = _init(oracle, mesh)
+    b = dom.blocklist[0]
+    d, m, vv = b.dimensions, b.structs["mesh"], b.structs["velocity_variational"]
+    nC, nV, M, D = mesh.nCells, mesh.nVertices, d["maxEdges"], d["vertexDegree"]
+    lon, lat = rotated_lonlat(m["xVertex"][:nV], m["yVertex"][:nV], m["zVertex"][:nV], 1.0)
+    _, _, a11, a22, a12 = analytic.velocities_strains_analytical(lat, lon)
+    du, dv = analytic.stress_divergence_analytical(lat, lon)
+    voc = m["verticesOnCell"].astype(np.int64) - 1
+    s11, s22, s12 = (np.zeros((M, nC + 1), order="F") for _ in range(3))
+    for i in range(M):
+        act = m["nEdgesOnCell"][:nC] > i
+        vi = voc[i, :nC][act]
+        s11[i, :nC][act], s22[i, :nC][act], s12[i, :nC][act] = a11[vi], a22[vi], a12[vi]
+    divU, divV = np.zeros(nV + 1), np.zeros(nV + 1)
+    sv = np.ones(nV + 1, dtype=np.int32)
+    oracle.call("ora_stress_divergence_variational", nV, D, M, m["nEdgesOnCell"], m["cellsOnVertex"],
+                vv["cellVerticesAtVertex"], divU, divV, s11, s22, s12, vv["basisIntegralsU"], vv["basisIntegralsV"],
+                vv["basisIntegralsMetric"], vv["variationalDenominator"], vv["tanLatVertexRotatedOverRadius"], sv)
+    keep = np.abs(lat) < np.deg2rad(70.0)
+    err2 = ((divU[:nV][keep] - du[keep]) ** 2).sum() + ((divV[:nV][keep] - dv[keep]) ** 2).sum()
+    return np.sqrt(err2 / ((du[keep] ** 2).sum() + (dv[keep] ** 2).sum()))
+
+
+def test_sphere_stress_divergence_converges_to_analytic_answer(oracle):
+    e8, e16, e32 = (sphere_stress_divergence_error(oracle, n) for n in (8, 16, 32))
+    assert e32 < e16 < e8, (e8, e16, e32)
+    assert np.log2(e16 / e32) > 0.9, (e8, e16, e32)
+
+
 def test_planar_operators_linear_exact_and_sinusoid_converges(oracle):
     errs = []
     for nx in (16, 32):
