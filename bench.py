@@ -225,13 +225,13 @@ def main():
     achieved = roof_bytes / (cell_ms * 1e-3) / 1e9 if cell_ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if world == 1 and os.path.exists(tpath):
+    if world == 1 and mesh_label == "QU60" and os.path.exists(tpath):  # the counters were collected on this workload
         try:
             traffic = json.load(open(tpath)).get("cell_kernel_hbm_bytes_per_launch")
         except Exception:
             traffic = None
     out = {
-        "metric": "EVP cell-subcycle-updates/sec at QU60", "value": value, "unit": "cell-subcycle-updates/s",
+        "metric": "EVP cell-subcycle-updates/sec at " + mesh_label, "value": value, "unit": "cell-subcycle-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{mesh_label} full-sphere mesh ({n_cells_total} cells, maxEdges {M}), "
