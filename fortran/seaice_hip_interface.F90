@@ -284,6 +284,12 @@ module seaice_hip_interface
        integer(c_int) :: ierr
      end function sih_ir_check_monotonicity
 
+     function sih_ir_unpack_reconstruction(ctx) bind(C, name="sih_ir_unpack_reconstruction") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int) :: ierr
+     end function sih_ir_unpack_reconstruction
+
      function sih_ir_get_sums(ctx, tracer, initSums, finalSums) bind(C, name="sih_ir_get_sums") result(ierr)
        import :: c_int, c_ptr, c_char
        type(c_ptr), value :: ctx

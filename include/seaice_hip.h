@@ -304,6 +304,10 @@ int sih_ir_run(sih_ctx *ctx, double dt, int checks);
  * fields of every tracer with a parent between the two calls (:8495-8496).  Returns SIH_ERR_IR with
  * "IR advection, monotonicity violation" where the reference aborts. */
 int sih_ir_check_monotonicity(sih_ctx *ctx);
+/* inspection: copies every tracer's reconstruction of the last sih_ir_run (value at the cell's origin and
+ * limited gradient, linear_tracer_field :3785-4202), which the library keeps as per-cell records, into the
+ * plane fields <tracer>Center, <tracer>Gradx, <tracer>Grady for sih_field_get */
+int sih_ir_unpack_reconstruction(sih_ctx *ctx);
 /* sum_tracers results of the last sih_ir_run(.., checks & 1): nLayers*nCategories values each */
 int sih_ir_get_sums(sih_ctx *ctx, const char *tracer, double *initSums, double *finalSums);
 /* sih_ir_run bracketed by HIP events on the context's stream: total and per-phase durations in ms

@@ -59,8 +59,14 @@ struct IrDev {
 };
 
 // device-resident tracer table (one entry per tracer, in list order: parents before children)
+// The reconstruction of a tracer (value at the cell's origin and the limited gradient) is stored as records:
+// for category cat and cell c the L layers follow each other, three doubles each (centre, x and y gradient).
+// The flux kernel gathers them by source cell; one cell's layers then sit in one or two cache lines instead
+// of 3 L different ones.
+#define IR_LCHUNK 8  // layers handled together (flux threads, staging of the records)
+#define IR_REC(T, cat, pc, c, layer) ((((size_t)(cat) * (pc) + (c)) * (T).L + (layer)) * 3)
 struct IrTabEntry {
-    double *val, *center, *gx, *gy, *xB, *yB, *prod, *flux;
+    double *val, *rec, *xB, *yB, *prod, *flux;
     int L, parent, nLev, hasChild;
     int chain[4];  // tracer indices from the mass-like field (chain[0]) to this tracer (chain[nLev-1])
 };
@@ -69,8 +75,8 @@ struct IrTracer {
     std::string name;
     int parent = -1, L = 1, nParents = 0;
     bool hasChild = false;
-    double *val = nullptr, *center = nullptr, *gx = nullptr, *gy = nullptr, *xB = nullptr, *yB = nullptr,
-           *prod = nullptr, *flux = nullptr;
+    double *val = nullptr, *rec = nullptr, *xB = nullptr, *yB = nullptr, *prod = nullptr, *flux = nullptr;
+    double *center = nullptr, *gx = nullptr, *gy = nullptr;  // plane copies for inspection (sih_ir_unpack_reconstruction)
     std::vector<double> sumInit, sumFinal;
     // monotonicity check: min / max of the old values in the neighbourhood, whether the old parent value
     // exceeded 1e-11 (allocated on first use)
@@ -114,7 +120,13 @@ void sih_ir_destroy(sih_ctx *c)
 __device__ inline bool xcdTile(unsigned nTile, unsigned nPart, unsigned &tile, unsigned &part)
 {
     const unsigned L = blockIdx.x, xcd = L % 8u, j = L / 8u;
+#ifdef SIH_XCD_STRIDED
     tile = xcd + 8u * (j / nPart);
+#else
+    // each XCD walks a contiguous range of tiles: neighbouring tiles, which gather from the same cache lines
+    // along their common border, meet in the same L2 one after the other
+    tile = xcd * ((nTile + 7u) / 8u) + j / nPart;
+#endif
     part = j % nPart;
     return tile < nTile;
 }
@@ -569,8 +581,14 @@ __global__ void __launch_bounds__(256) k_ir_reconstruct(IrDev d, const IrTabEntr
     // the categories of one block of cells share its geometry and neighbour lists: one XCD for all of them
     unsigned cb, ucat;
     if (!xcdTile((d.nCells + 255u) / 256u, (unsigned)d.nCat, cb, ucat)) return;
-    const int c = cb * blockDim.x + threadIdx.x;
-    if (c >= d.nCells) return;
+    // The records of a block's cells are contiguous in memory but a thread's own share is 24 L bytes apart
+    // from its neighbour's: they go through LDS and leave as one coalesced copy per chunk of layers.  All
+    // threads of the block therefore stay to the end; the ones past the last cell repeat the last cell's
+    // work (same values to the same addresses) and their staging rows are not copied.
+    __shared__ double stage[256 * 3 * IR_LCHUNK];
+    const int c0 = cb * blockDim.x;
+    const int nValid = min((int)blockDim.x, d.nCells - c0);
+    const int c = min(c0 + (int)threadIdx.x, d.nCells - 1);
     const int cat = (int)ucat;
     const size_t pc = d.padC;
     const bool ice = d.maskCell[c] == 1;
@@ -630,7 +648,9 @@ __global__ void __launch_bounds__(256) k_ir_reconstruct(IrDev d, const IrTabEntr
             for (int ie = 0; ie < M; ie++)
                 if (ie < n && nb[ie] < d.nCells && P->val[lp1 + nb[ie]] > EPS11) mnbS |= 1u << ie;
         }
-        for (int layer = 0; layer < T.L; layer++) {
+        for (int l0 = 0; l0 < T.L; l0 += IR_LCHUNK) {
+        const int nlc = min(IR_LCHUNK, T.L - l0);
+        for (int layer = l0; layer < l0 + nlc; layer++) {
             const size_t k = (size_t)(cat * T.L + layer) * pc + c;
             const size_t lp = hasParent ? (size_t)(P->L == 1 ? cat : cat * T.L + layer) * pc : 0;
             const double f = T.val[k];
@@ -703,9 +723,12 @@ __global__ void __launch_bounds__(256) k_ir_reconstruct(IrDev d, const IrTabEntr
                 gyv = gyv * fac;
             }
             const double cen = f - gxv * xb - gyv * yb;
-            T.gx[k] = gxv;
-            T.gy[k] = gyv;
-            T.center[k] = cen;
+            {
+                double *r = stage + ((size_t)threadIdx.x * nlc + (layer - l0)) * 3;
+                r[0] = cen;
+                r[1] = gxv;
+                r[2] = gyv;
+            }
             if (T.hasChild) {
                 double bx = 0.0, by = 0.0;
                 if (ice) {
@@ -720,10 +743,11 @@ __global__ void __launch_bounds__(256) k_ir_reconstruct(IrDev d, const IrTabEntr
                         if (j < T.nLev - 1) {
                             const IrTabEntry &A = tab[T.chain[j]];
                             size_t kj = (size_t)(A.L == 1 ? cat : cat * A.L + layer) * pc + c;
+                            const double *r = A.rec + IR_REC(A, cat, pc, c, A.L == 1 ? 0 : layer);
                             mean[j] = A.val[kj];
-                            ce[j] = A.center[kj];
-                            gx[j] = A.gx[kj];
-                            gy[j] = A.gy[kj];
+                            ce[j] = r[0];
+                            gx[j] = r[1];
+                            gy[j] = r[2];
                         }
                     }
                     if (T.nLev == 1) {
@@ -768,6 +792,16 @@ __global__ void __launch_bounds__(256) k_ir_reconstruct(IrDev d, const IrTabEntr
                 T.xB[k] = bx;
                 T.yB[k] = by;
             }
+        }
+        __syncthreads();
+        {  // staged records -> memory: per cell nlc * 3 consecutive doubles starting at layer l0
+            const int row = nlc * 3, total = nValid * row;
+            for (int i = threadIdx.x; i < total; i += blockDim.x) {
+                const int cl = i / row;
+                T.rec[IR_REC(T, cat, pc, c0 + cl, l0) + (i - cl * row)] = stage[i];
+            }
+        }
+        __syncthreads();  // the next chunk reuses the staging rows; later tracers read these records
         }
     }
 }
@@ -965,8 +999,8 @@ __global__ void __launch_bounds__(256) k_ir_flux(IrDev d, const IrTabEntry *__re
                 for (int j = 0; j < 4; j++) {
                     if (j < T.nLev) {
                         const IrTabEntry &A = tab[T.chain[j]];
-                        const size_t kj = (size_t)(A.L == 1 ? cat : cat * A.L + layer) * pc + c;
-                        const double cj = A.center[kj], gxj = A.gx[kj], gyj = A.gy[kj];
+                        const double *r = A.rec + IR_REC(A, cat, pc, c, A.L == 1 ? 0 : layer);
+                        const double cj = r[0], gxj = r[1], gyj = r[2];
 #pragma unroll
                         for (int q = 0; q < 6; q++) val[q] = val[q] * (cj + gxj * xq[q] + gyj * yq[q]);
                     }
@@ -992,7 +1026,6 @@ __global__ void __launch_bounds__(256) k_ir_flux(IrDev d, const IrTabEntry *__re
 // together), blockIdx.y over chunks of edges.  The quadrature points of a triangle and the product of
 // the single-layer ancestors are evaluated once for all layers of the group; every flux is still the
 // reference's sum over triangles of area * (sum over quadrature points), in the same order.
-#define IR_LCHUNK 8
 struct IrPlane {
     int ti, layer0, cat;
 };
@@ -1013,19 +1046,16 @@ __global__ void __launch_bounds__(256) k_ir_flux_planes(IrDev d, const IrTabEntr
     const int cnt = d.triCount[e];
     // ancestors (and the tracer itself if it has one layer) whose value does not depend on the layer
     int nShared = 0;
-    const double *cenp[4], *gxp[4], *gyp[4];
+    const double *recp[4];  // records of category cat, starting at layer0 for a multi-layer chain member
     int Lk[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        cenp[j] = gxp[j] = gyp[j] = nullptr;
+        recp[j] = nullptr;
         Lk[j] = 1;
         if (j < T.nLev) {
             const IrTabEntry &A = tab[T.chain[j]];
             Lk[j] = A.L;
-            const size_t kj = (size_t)(A.L == 1 ? cat : cat * A.L + layer0) * pc;
-            cenp[j] = A.center + kj;
-            gxp[j] = A.gx + kj;
-            gyp[j] = A.gy + kj;
+            recp[j] = A.rec + IR_REC(A, cat, pc, 0, A.L == 1 ? 0 : layer0);
             if (A.L == 1 && nShared == j) nShared = j + 1;
         }
     }
@@ -1051,7 +1081,8 @@ __global__ void __launch_bounds__(256) k_ir_flux_planes(IrDev d, const IrTabEntr
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (j < nShared) {
-                const double cj = cenp[j][c], gxj = gxp[j][c], gyj = gyp[j][c];
+                const double *r = recp[j] + (size_t)c * 3;  // nShared members have one layer
+                const double cj = r[0], gxj = r[1], gyj = r[2];
 #pragma unroll
                 for (int q = 0; q < 6; q++) pv[q] = pv[q] * (cj + gxj * xq[q] + gyj * yq[q]);
             }
@@ -1071,8 +1102,8 @@ __global__ void __launch_bounds__(256) k_ir_flux_planes(IrDev d, const IrTabEntr
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (j >= nShared && j < T.nLev) {
-                        const size_t off = (Lk[j] == 1 ? 0 : (size_t)ly * pc) + c;
-                        const double cj = cenp[j][off], gxj = gxp[j][off], gyj = gyp[j][off];
+                        const double *r = recp[j] + ((size_t)c * Lk[j] + (Lk[j] == 1 ? 0 : ly)) * 3;
+                        const double cj = r[0], gxj = r[1], gyj = r[2];
 #pragma unroll
                         for (int q = 0; q < 6; q++) val[q] = val[q] * (cj + gxj * xq[q] + gyj * yq[q]);
                     }
@@ -1489,8 +1520,7 @@ extern "C" int sih_ir_set_tracers(sih_ctx *c, int nTracers, const char *const *n
             double **p;
             SihLoc loc;
             bool need;
-        } sc[] = {{"Center", &t.center, LOC_CELL, true},       {"Gradx", &t.gx, LOC_CELL, true},
-                  {"Grady", &t.gy, LOC_CELL, true},            {"Product", &t.prod, LOC_CELL, true},
+        } sc[] = {{"Product", &t.prod, LOC_CELL, true},
                   {"Barycenterx", &t.xB, LOC_CELL, t.hasChild}, {"Barycentery", &t.yB, LOC_CELL, t.hasChild},
                   {"EdgeFlux", &t.flux, LOC_EDGE, true}};
         for (auto &s : sc) {
@@ -1498,6 +1528,11 @@ extern "C" int sih_ir_set_tracers(sih_ctx *c, int nTracers, const char *const *n
             std::string fn = t.name + s.suffix;
             if ((rc = sih_add_field(c, fn.c_str(), s.loc, lead, false))) return rc;
             *s.p = (double *)sih_find_field(c, fn.c_str())->d;
+        }
+        {  // the records: not a plane field, only its storage comes from the field table
+            std::string fn = "_" + t.name + "Records";
+            if ((rc = sih_add_field(c, fn.c_str(), LOC_CELL, 3 * lead, false))) return rc;
+            t.rec = (double *)sih_find_field(c, fn.c_str())->d;
         }
         t.sumInit.assign(lead, 0.0);
         t.sumFinal.assign(lead, 0.0);
@@ -1512,7 +1547,7 @@ extern "C" int sih_ir_set_tracers(sih_ctx *c, int nTracers, const char *const *n
     for (int i = 0; i < nTracers; i++) {
         const IrTracer &t = list[i];
         IrTabEntry &q = tab[i];
-        q = IrTabEntry{t.val, t.center, t.gx, t.gy, t.xB, t.yB, t.prod, t.flux, t.L, t.parent, t.nParents + 1,
+        q = IrTabEntry{t.val, t.rec, t.xB, t.yB, t.prod, t.flux, t.L, t.parent, t.nParents + 1,
                        t.hasChild ? 1 : 0, {0, 0, 0, 0}};
         int j = i;
         for (int k = t.nParents; k >= 0; k--) {
@@ -1780,6 +1815,48 @@ extern "C" int sih_ir_check_monotonicity(sih_ctx *c)
 extern "C" int sih_ir_run_timed(sih_ctx *c, double dt, double *totalMs, double *phaseMs5)
 {
     return irRun(c, dt, 0, true, totalMs, phaseMs5);
+}
+
+// records -> planes, for inspection
+__global__ void k_ir_unpack_records(IrDev d, const double *rec, int L, double *center, double *gx, double *gy)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nCells) return;
+    const size_t pc = d.padC;
+    for (int cat = 0; cat < d.nCat; cat++)
+        for (int layer = 0; layer < L; layer++) {
+            const double *r = rec + (((size_t)cat * pc + c) * L + layer) * 3;
+            const size_t k = (size_t)(cat * L + layer) * pc + c;
+            center[k] = r[0];
+            gx[k] = r[1];
+            gy[k] = r[2];
+        }
+}
+
+extern "C" int sih_ir_unpack_reconstruction(sih_ctx *c)
+{
+    if (!c || !c->ir || c->ir->tracers.empty()) {
+        sih_set_error("sih_ir_unpack_reconstruction: sih_ir_set_tracers has not run");
+        return SIH_ERR_STATE;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    sih_ir_state *ir = c->ir;
+    int rc;
+    for (IrTracer &t : ir->tracers) {
+        const int lead = t.L * ir->nCat;
+        double **dst[3] = {&t.center, &t.gx, &t.gy};
+        const char *suffix[3] = {"Center", "Gradx", "Grady"};
+        for (int k = 0; k < 3; k++) {
+            const std::string fn = t.name + suffix[k];
+            if ((rc = sih_add_field(c, fn.c_str(), LOC_CELL, lead, false))) return rc;
+            *dst[k] = (double *)sih_find_field(c, fn.c_str())->d;
+        }
+        hipLaunchKernelGGL(k_ir_unpack_records, dim3((ir->d.nCells + 255) / 256), dim3(256), 0, c->stream, ir->d, t.rec, t.L,
+                           t.center, t.gx, t.gy);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SIH_OK;
 }
 
 extern "C" int sih_ir_get_sums(sih_ctx *c, const char *tracer, double *initSums, double *finalSums)

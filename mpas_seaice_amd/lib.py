@@ -73,7 +73,7 @@ EXPORTS = [
     "sih_ir_init", "sih_ir_set_tracers", "sih_ir_run", "sih_ir_get_sums", "sih_ir_run_timed",
     "sih_fields_put", "sih_fields_get", "sih_evp_overlap_setup", "sih_evp_subcycle_parts",
     "sih_evp_set_special_boundaries", "sih_ir_check_monotonicity", "sih_evp_set_edge_mesh",
-    "sih_upwind_init", "sih_upwind_prepare", "sih_upwind_advect", "sih_upwind_run", "sih_upwind_get_sums",
+    "sih_ir_unpack_reconstruction", "sih_upwind_init", "sih_upwind_prepare", "sih_upwind_advect", "sih_upwind_run", "sih_upwind_get_sums",
 ]
 
 
@@ -134,6 +134,7 @@ def load():
                                        ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
     lib.sih_ir_run.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int]
     lib.sih_ir_check_monotonicity.argtypes = [ctypes.c_void_p]
+    lib.sih_ir_unpack_reconstruction.argtypes = [ctypes.c_void_p]
     lib.sih_ir_get_sums.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.sih_ir_run_timed.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
                                      ctypes.c_void_p]
@@ -364,6 +365,9 @@ class BlockContext:
     def ir_run(self, dt, check_conservation=False, check_monotonicity=False):
         checks = (1 if check_conservation else 0) | (2 if check_monotonicity else 0)
         check(self._lib.sih_ir_run(self.handle, float(dt), checks), "sih_ir_run")
+
+    def ir_unpack_reconstruction(self):
+        check(self._lib.sih_ir_unpack_reconstruction(self.handle), "sih_ir_unpack_reconstruction")
 
     def ir_check_monotonicity(self):
         check(self._lib.sih_ir_check_monotonicity(self.handle), "sih_ir_check_monotonicity")

@@ -111,6 +111,7 @@ def test_advection_step_matches_oracle(oracle, meshname, name, cfg, kw):
         live = (rir["triangleArea"][:, :nE] != 0.0)[None, :, :]
         rep["xTriangle"] = rel_linf(np.where(live, xt, 0.0), np.where(live, diag["xTriangleVertices"][:3, :, :nE], 0.0))
         W = diag["work"]
+        b.ctx.ir_unpack_reconstruction()
         for n, L in (("iceAreaCategory", 1), ("iceVolumeCategory", 1), ("iceEnthalpy", 7)):
             lead = L * nCat
             rep[n + "Gradx"] = rel_linf(dget(b, n + "Gradx", lead, nC),
