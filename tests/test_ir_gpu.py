@@ -303,3 +303,23 @@ def test_cfl_warning_count(oracle):
         assert int(dom.blocklist[0].ctx.info("irCflWarnings")) == diag["cflWarnings"] == 4
     finally:
         vs.seaice_mesh_pool_destroy(dom)
+
+
+def test_more_layers_than_one_chunk(oracle):
+    """10 ice layers and 3 snow layers: the kernels handle layers in chunks of 8, so the 7-layer default never
+    reaches the second chunk; one category fewer as well."""
+    ir = _ir()
+    cfg = {"config_nIceLayers": 10, "config_nSnowLayers": 3, "config_elastic_subcycle_number": 30,
+           "config_conservation_check": True}
+    dom, ref = make_pair(oracle, "QU480", "QU480", configs=cfg, nCategories=4, open_water_band=(-0.2, 0.3))
+    try:
+        assert dom.blocklist[0].structs["tracers"]["iceEnthalpy"].shape[:2] == (10, 4)
+        for _ in range(2):
+            oracle.seaice_run_velocity_solver(ref)
+            ir.seaice_run_advection(ref)
+            vs.seaice_run_velocity_solver(dom)
+            adv.seaice_run_advection(dom)
+        rep = compare_tracers(dom, ref)
+        assert max(rep.values()) <= TOL, rep
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
