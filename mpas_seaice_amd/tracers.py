@@ -9,7 +9,7 @@ the tracers were added).  Here the list is a Python list of :class:`Tracer`.
 from __future__ import annotations
 
 # tracers that are always advected (:218-224) followed by the optional ones in the order the
-# reference adds them (:298-475); each entry: (tracerName, parentName, package that activates it)
+# reference adds them (:298-475, biogeochemistry included); each entry: (tracerName, parentName, package that activates it)
 TRACER_TABLE = [
     ("iceAreaCategory", "None", None),
     ("iceVolumeCategory", "iceAreaCategory", None),
@@ -34,6 +34,53 @@ TRACER_TABLE = [
     ("iceScatteringAerosol", "iceVolumeCategory", "pkgColumnTracerAerosols"),
     ("iceBodyAerosol", "iceVolumeCategory", "pkgColumnTracerAerosols"),
     ("brineFraction", "iceVolumeCategory", "pkgTracerBrine"),
+    # skeletal-layer and vertical biogeochemistry, vertical aerosols and salinity (:347-475)
+    ("skeletalAlgaeConc", "iceAreaCategory", "pkgTracerSkeletalAlgae"),
+    ("skeletalNitrateConc", "iceAreaCategory", "pkgTracerSkeletalNitrate"),
+    ("skeletalDOCConc", "iceAreaCategory", "pkgTracerSkeletalCarbon"),
+    ("skeletalDICConc", "iceAreaCategory", "pkgTracerSkeletalCarbon"),
+    ("skeletalDONConc", "iceAreaCategory", "pkgTracerSkeletalDON"),
+    ("skeletalAmmoniumConc", "iceAreaCategory", "pkgTracerSkeletalAmmonium"),
+    ("skeletalSilicateConc", "iceAreaCategory", "pkgTracerSkeletalSilicate"),
+    ("skeletalDMSConc", "iceAreaCategory", "pkgTracerSkeletalDMS"),
+    ("skeletalDMSPpConc", "iceAreaCategory", "pkgTracerSkeletalDMS"),
+    ("skeletalDMSPdConc", "iceAreaCategory", "pkgTracerSkeletalDMS"),
+    ("skeletalNonreactiveConc", "iceAreaCategory", "pkgTracerSkeletalNonreactive"),
+    ("skeletalHumicsConc", "iceAreaCategory", "pkgTracerSkeletalHumics"),
+    ("skeletalParticulateIronConc", "iceAreaCategory", "pkgTracerSkeletalIron"),
+    ("skeletalDissolvedIronConc", "iceAreaCategory", "pkgTracerSkeletalIron"),
+    ("mobileFraction", "brineFraction", "pkgTracerMobileFraction"),
+    ("verticalAlgaeSnow", "snowVolumeCategory", "pkgTracerVerticalAlgae"),
+    ("verticalAlgaeIce", "brineFraction", "pkgTracerVerticalAlgae"),
+    ("verticalNitrateSnow", "snowVolumeCategory", "pkgTracerVerticalNitrate"),
+    ("verticalNitrateIce", "brineFraction", "pkgTracerVerticalNitrate"),
+    ("verticalDOCSnow", "snowVolumeCategory", "pkgTracerVerticalCarbon"),
+    ("verticalDICSnow", "snowVolumeCategory", "pkgTracerVerticalCarbon"),
+    ("verticalDOCIce", "brineFraction", "pkgTracerVerticalCarbon"),
+    ("verticalDICIce", "brineFraction", "pkgTracerVerticalCarbon"),
+    ("verticalDONSnow", "snowVolumeCategory", "pkgTracerVerticalDON"),
+    ("verticalDONIce", "brineFraction", "pkgTracerVerticalDON"),
+    ("verticalAmmoniumSnow", "snowVolumeCategory", "pkgTracerVerticalAmmonium"),
+    ("verticalAmmoniumIce", "brineFraction", "pkgTracerVerticalAmmonium"),
+    ("verticalSilicateSnow", "snowVolumeCategory", "pkgTracerVerticalSilicate"),
+    ("verticalSilicateIce", "brineFraction", "pkgTracerVerticalSilicate"),
+    ("verticalDMSSnow", "snowVolumeCategory", "pkgTracerVerticalDMS"),
+    ("verticalDMSPpSnow", "snowVolumeCategory", "pkgTracerVerticalDMS"),
+    ("verticalDMSPdSnow", "snowVolumeCategory", "pkgTracerVerticalDMS"),
+    ("verticalDMSIce", "brineFraction", "pkgTracerVerticalDMS"),
+    ("verticalDMSPpIce", "brineFraction", "pkgTracerVerticalDMS"),
+    ("verticalDMSPdIce", "brineFraction", "pkgTracerVerticalDMS"),
+    ("verticalNonreactiveSnow", "snowVolumeCategory", "pkgTracerVerticalNonreactive"),
+    ("verticalNonreactiveIce", "brineFraction", "pkgTracerVerticalNonreactive"),
+    ("verticalHumicsSnow", "snowVolumeCategory", "pkgTracerVerticalHumics"),
+    ("verticalHumicsIce", "brineFraction", "pkgTracerVerticalHumics"),
+    ("verticalParticulateIronSnow", "snowVolumeCategory", "pkgTracerVerticalIron"),
+    ("verticalDissolvedIronSnow", "snowVolumeCategory", "pkgTracerVerticalIron"),
+    ("verticalParticulateIronIce", "brineFraction", "pkgTracerVerticalIron"),
+    ("verticalDissolvedIronIce", "brineFraction", "pkgTracerVerticalIron"),
+    ("verticalAerosolsIce", "brineFraction", "pkgTracerZAerosols"),
+    ("verticalAerosolsSnow", "snowVolumeCategory", "pkgTracerZAerosols"),
+    ("verticalSalinity", "brineFraction", "pkgTracerZSalinity"),
 ]
 
 

@@ -323,3 +323,59 @@ def test_more_layers_than_one_chunk(oracle):
         assert max(rep.values()) <= TOL, rep
     finally:
         vs.seaice_mesh_pool_destroy(dom)
+
+
+def _add_optional_tracers(dom, seed=7):
+    """Optional tracers of the reference's list, three parents deep, with and without layers."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    for b in dom.blocklist:
+        nC, nCat = b.dimensions["nCells"], b.dimensions["nCategories"]
+        tr = b.structs["tracers"]
+
+        def field(L, lo, hi):
+            a = np.zeros((L, nCat, nC + 1), order="F")
+            a[..., :nC] = rng.uniform(lo, hi, (L, nCat, nC))
+            return a
+        tr["iceAge"] = field(1, 0.0, 3.0e7)
+        tr["levelIceArea"] = field(1, 0.2, 1.0)
+        tr["levelIceVolume"] = field(1, 0.2, 1.0)
+        tr["pondArea"] = field(1, 0.0, 0.5)            # child of levelIceArea with config_use_level_meltponds
+        tr["pondDepth"] = field(1, 0.0, 0.3)           # three parents: pondArea, levelIceArea, iceAreaCategory
+        tr["brineFraction"] = field(1, 0.5, 1.0)
+        tr["verticalNitrateIce"] = field(8, 0.0, 5.0)  # layers under a parent without layers, three parents
+        tr["verticalNitrateSnow"] = field(2, 0.0, 5.0)
+        tr["snowScatteringAerosol"] = field(2, 0.0, 1.0e-6)
+
+
+def test_optional_tracers_three_parents_deep(oracle):
+    ir = _ir()
+    mesh = get_mesh("var12")
+    cfg = {"config_elastic_subcycle_number": 30, "config_dt": 1800.0, "config_conservation_check": True,
+           "config_use_level_meltponds": True}
+    ref = cases.make_domain(mesh, None, configs=cfg, open_water_band=(-0.2, 0.3))
+    dom = cases.make_domain(mesh, None, configs=cfg, open_water_band=(-0.2, 0.3))
+    _add_optional_tracers(ref)
+    _add_optional_tracers(dom)
+    oracle.seaice_init_velocity_solver(ref)
+    ir.seaice_init_advection(ref)
+    names = [t.tracerName for t in ref.solver_state["tracersHead"]]
+    assert names[:4] == ["iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory", "surfaceTemperature"]
+    assert {t.tracerName: t.nParents for t in ref.solver_state["tracersHead"]}["pondDepth"] == 3
+    vs.seaice_mesh_pool_create(dom)
+    try:
+        vs.seaice_init_velocity_solver(dom)
+        adv.seaice_init_advection(dom)
+        for _ in range(2):
+            oracle.seaice_run_velocity_solver(ref)
+            ir.seaice_run_advection(ref)
+            vs.seaice_run_velocity_solver(dom)
+            adv.seaice_run_advection(dom)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+    nC = mesh.nCells
+    for n in names:
+        x = dom.blocklist[0].structs["tracers"][n][..., :nC]
+        y = ref.blocklist[0].structs["tracers"][n][..., :nC]
+        assert np.isfinite(x).all(), n
+        assert rel_linf(x, y) <= TOL, (n, rel_linf(x, y))
+    assert len(names) == 16
