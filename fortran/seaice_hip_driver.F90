@@ -41,6 +41,7 @@ program seaice_hip_driver
   real(kind=RKIND), dimension(:), allocatable, target :: xEdge, yEdge, zEdge
   real(kind=RKIND), dimension(:,:,:), allocatable, target :: coeffs_reconstruct
   real(kind=RKIND), dimension(:,:,:), allocatable, target :: surfaceTemperature, iceEnthalpy, iceSalinity, snowEnthalpy
+  real(kind=RKIND), dimension(:,:,:), allocatable, target :: upwindArea, upwindTemperature, upwindVolume, upwindSnow
   integer, parameter :: nTracers = 7
   character(len=32, kind=c_char), dimension(nTracers), target :: tracerNames, parentNames
   type(c_ptr), dimension(nTracers) :: namePtrs, parentPtrs
@@ -204,10 +205,24 @@ program seaice_hip_driver
   call get_r3("iceSalinity", iceSalinity)
   call get_r3("snowEnthalpy", snowEnthalpy)
 
+  ! ---- the upwind alternative (mpas_seaice_advection_upwind.F:79, :385), one more step from the state the
+  !      remap left on the device: surface temperature in kelvin, so that its chain carries volume
+  allocate(upwindArea(1,nCategories,nCells), upwindTemperature(1,nCategories,nCells), &
+           upwindVolume(1,nCategories,nCells), upwindSnow(1,nCategories,nCells))
+  upwindTemperature = surfaceTemperature + 273.15_RKIND
+  call put_r3("surfaceTemperature", upwindTemperature)
+  call check(sih_upwind_init(ctx, irDesc), "sih_upwind_init")
+  call check(sih_upwind_run(ctx, config_dt, 0_c_int), "sih_upwind_run")
+  call get_r3("iceAreaCategory", upwindArea)
+  call get_r3("surfaceTemperature", upwindTemperature)
+  call get_r3("iceVolumeCategory", upwindVolume)
+  call get_r3("snowVolumeCategory", upwindSnow)
+
   open(newunit=ou, file=trim(resultFile), access="stream", form="unformatted", status="replace")
   write(ou) uVelocity, vVelocity, stress11, stress22, stress12, divergence, shear
   write(ou) iceAreaCategory, iceVolumeCategory, snowVolumeCategory, surfaceTemperature, iceEnthalpy, iceSalinity, &
             snowEnthalpy
+  write(ou) upwindArea, upwindTemperature, upwindVolume, upwindSnow
   close(ou)
 
   ! ---- seaice_mesh_pool_destroy ---------------------------------------------------------------

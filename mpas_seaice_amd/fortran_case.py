@@ -57,7 +57,9 @@ def read_result(path, block):
                         ("iceAreaCategory", (1, nCat, nC)), ("iceVolumeCategory", (1, nCat, nC)),
                         ("snowVolumeCategory", (1, nCat, nC)), ("surfaceTemperature", (1, nCat, nC)),
                         ("iceEnthalpy", (nIce, nCat, nC)), ("iceSalinity", (nIce, nCat, nC)),
-                        ("snowEnthalpy", (nSnow, nCat, nC))):
+                        ("snowEnthalpy", (nSnow, nCat, nC)), ("upwindArea", (1, nCat, nC)),
+                        ("upwindTemperature", (1, nCat, nC)), ("upwindVolume", (1, nCat, nC)),
+                        ("upwindSnow", (1, nCat, nC))):
         n = int(np.prod(shape))
         out[name] = raw[o:o + n].reshape(shape, order="F")
         o += n

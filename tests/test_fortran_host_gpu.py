@@ -45,3 +45,14 @@ def test_fortran_driver_matches_oracle(oracle, tmp_path):
         r = b.structs[pool][name][..., :n]
         err = np.abs(got[name] - r).max() / np.abs(r).max()
         assert err <= 1e-10, (name, err)
+    # the driver's last leg: one upwind step from the advected state, surface temperature in kelvin
+    from oracle import upwind_flow
+    b.structs["tracers"]["surfaceTemperature"][..., :nC] += 273.15
+    upwind_flow.seaice_init_advection_upwind(ref)
+    upwind_flow.seaice_run_advection_upwind(ref)
+    for name, key in (("iceAreaCategory", "upwindArea"), ("surfaceTemperature", "upwindTemperature"),
+                      ("iceVolumeCategory", "upwindVolume"), ("snowVolumeCategory", "upwindSnow")):
+        r = b.structs["tracers"][name][..., :nC]
+        err = np.abs(got[key] - r).max() / np.abs(r).max()
+        assert err <= 1e-10, (key, err)
+    assert np.abs(got["upwindVolume"]).max() > 0.0
