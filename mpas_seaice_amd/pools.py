@@ -43,6 +43,8 @@ DEFAULT_CONFIGS = {
     "config_use_column_vertical_thermodynamics": False,
     "config_use_special_boundaries_velocity": False,
     "config_use_special_boundaries_velocity_masks": False,
+    "config_use_special_boundaries_tracers": False,
+    "config_use_dynamics": True,
     "config_use_halo_exch": True,
     "config_aggregate_halo_exch": False,
     "config_reuse_halo_exch": False,
@@ -133,7 +135,8 @@ class Block:
         # special_boundaries pool (mpas_seaice_special_boundaries.F:121-126, 382-383)
         self.structs["special_boundaries"] = {
             "vertexBoundaryType": iv(), "vertexBoundarySource": iv(), "vertexBoundarySourceLocal": iv(),
-            "solveVelocitySpecialBoundaries": iv(), "solveStressSpecialBoundaries": ic()}
+            "solveVelocitySpecialBoundaries": iv(), "solveStressSpecialBoundaries": ic(),
+            "tracerBoundaryType": ic(), "tracerBoundarySource": ic(), "tracerBoundarySourceLocal": ic()}
 
         self.structs["boundary"] = {"interiorVertex": iv(), "interiorCell": ic(),
                                     "interiorEdge": np.zeros(nE + 1, dtype=np.int32)}

@@ -1,4 +1,4 @@
-"""Host mirror of the reference's special-boundaries module for the velocity solver
+"""Host mirror of the reference's special-boundaries module
 (/root/reference/src/shared/mpas_seaice_special_boundaries.F).
 
 ``seaice_init_special_boundaries`` turns the global source ids of the ``special_boundaries`` pool into
@@ -12,6 +12,7 @@ from __future__ import annotations
 import numpy as np
 
 VELOCITY_BOUNDARY_NONE, VELOCITY_BOUNDARY_PERIODIC, VELOCITY_BOUNDARY_REVERSE, VELOCITY_BOUNDARY_ZERO = 0, 1, 2, 3
+TRACER_BOUNDARY_NONE, TRACER_BOUNDARY_ZERO, TRACER_BOUNDARY_SET = 0, 1, 2  # :42-45
 
 
 def seaice_init_special_boundaries(domain):
@@ -24,6 +25,16 @@ def seaice_init_special_boundaries(domain):
         # after its vertex loop, which is the same thing only when no halo update lies in between
         from .lib import SeaiceHipError
         raise SeaiceHipError("special velocity boundaries are implemented for single-block domains only")
+    if bool(cfg.get("config_use_special_boundaries_tracers", False)):  # init_special_boundaries_tracers, :169-239
+        for b in domain.blocklist:
+            sb = b.structs["special_boundaries"]
+            nC = b.dimensions["nCells"]
+            ids = b.structs["mesh"]["indexToCellID"][:nC]
+            g2l = np.zeros(int(ids.max()) + 1, dtype=np.int64)
+            g2l[ids] = np.arange(1, nC + 1)
+            marked = sb["tracerBoundaryType"][:nC] != TRACER_BOUNDARY_NONE
+            src = sb["tracerBoundarySource"][:nC]
+            sb["tracerBoundarySourceLocal"][:nC][marked] = g2l[np.clip(src[marked], 0, g2l.size - 1)]
     for b in domain.blocklist:
         sb = b.structs["special_boundaries"]
         nV = b.dimensions["nVertices"]
@@ -43,3 +54,26 @@ def seaice_init_special_boundaries(domain):
                 np.ascontiguousarray(sb["vertexBoundarySourceLocal"][:nV]) if use_vel else None,
                 np.ascontiguousarray(sb["solveVelocitySpecialBoundaries"][:nV]) if use_masks else None,
                 np.ascontiguousarray(sb["solveStressSpecialBoundaries"][:nC]) if use_masks else None)
+
+
+def seaice_set_special_boundaries_tracers(domain):
+    """:415-485, called at the end of every time step (mpas_seaice_time_integration.F:173) on the host pools:
+    marked cells lose their ice or take the three state tracers of their source cell, in cell order and in
+    place, exactly like the reference's loop (a source that was itself replaced earlier hands on its new
+    value)."""
+    if not bool(domain.configs.get("config_use_special_boundaries_tracers", False)):
+        return
+    for b in domain.blocklist:
+        sb, tr = b.structs["special_boundaries"], b.structs["tracers"]
+        nC = b.dimensions["nCells"]
+        typ = sb["tracerBoundaryType"][:nC]
+        src = sb["tracerBoundarySourceLocal"]
+        fields = [tr[k] for k in ("iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory")]
+        for i in np.nonzero(typ != TRACER_BOUNDARY_NONE)[0]:
+            if typ[i] == TRACER_BOUNDARY_ZERO:
+                for a in fields:
+                    a[:, :, i] = 0.0
+            elif typ[i] == TRACER_BOUNDARY_SET:
+                j = int(src[i]) - 1
+                for a in fields:
+                    a[:, :, i] = a[:, :, j]

@@ -379,3 +379,35 @@ def test_optional_tracers_three_parents_deep(oracle):
         assert np.isfinite(x).all(), n
         assert rel_linf(x, y) <= TOL, (n, rel_linf(x, y))
     assert len(names) == 16
+
+
+@pytest.mark.parametrize("with_column", [False, True])
+def test_timestep_dynamics_loop(oracle, with_column):
+    """the caller of both paths: two dynamics subcycles per time step, with and without a host routine in the
+    place of the column package's ridging between them (time_integration.F:138-162)"""
+    from mpas_seaice_amd import time_integration as ti
+    ir = _ir()
+    cfg = {"config_dynamics_subcycle_number": 2, "config_elastic_subcycle_number": 30}
+
+    def column(domain):  # stands for seaice_column_dynamics_time_integration: any host-side change of the pools
+        for b in domain.blocklist:
+            tr = b.structs["tracers"]
+            small = tr["iceAreaCategory"] < 0.05
+            for k in ("iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory"):
+                tr[k][small] = 0.0
+            tr["iceEnthalpy"] *= 0.999
+    dom, ref = make_pair(oracle, "QU480", "QU480", configs=cfg, open_water_band=(-0.2, 0.3))
+    try:
+        for _ in range(2):
+            oracle.seaice_run_velocity_solver(ref)
+            ir.seaice_run_advection(ref)
+            if with_column:
+                column(ref)
+        ti.seaice_timestep_dynamics(dom, column_dynamics=column if with_column else None)
+        rep = compare_tracers(dom, ref)
+        for k in ("uVelocity", "vVelocity"):
+            x, y = dom.blocklist[0].structs["velocity_solver"][k], ref.blocklist[0].structs["velocity_solver"][k]
+            assert rel_linf(x, y) <= TOL, k
+        assert abs(dom.blocklist[0].structs["velocity_solver"]["dynamicsTimeStep"][0] - 0.5 * dom.configs["config_dt"]) < 1e-9
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)

@@ -303,3 +303,28 @@ def test_weak_operators(oracle, mesh_name):
                     vw["latVertexRotated"], sv)
         scale = 3.0 * m["dcEdge"].max() / m["areaTriangle"][:nV].min()
         assert np.abs(dU[:nV][interior]).max() < 1e-12 * scale and np.abs(dV[:nV][interior]).max() < 1e-12 * scale
+
+
+def test_special_boundaries_tracers_sequential_in_place():
+    """seaice_set_special_boundaries_tracers: zeroed cells, copied cells, and a copy whose source was itself
+    replaced earlier in the loop (special_boundaries.F:460-478)."""
+    from mpas_seaice_amd import special_boundaries as sbm
+    dom = cases.make_domain(get_mesh("QU480"), "QU480", configs={"config_use_special_boundaries_tracers": True})
+    b = dom.blocklist[0]
+    sb, tr = b.structs["special_boundaries"], b.structs["tracers"]
+    ids = b.structs["mesh"]["indexToCellID"]
+    sb["tracerBoundaryType"][[4, 10, 20]] = [sbm.TRACER_BOUNDARY_ZERO, sbm.TRACER_BOUNDARY_SET, sbm.TRACER_BOUNDARY_SET]
+    sb["tracerBoundarySource"][10] = ids[30]   # cell 11 takes cell 31
+    sb["tracerBoundarySource"][20] = ids[10]   # cell 21 takes cell 11, which by then holds cell 31's values
+    before = {k: v.copy(order="F") for k, v in tr.items()}
+    sbm.seaice_init_special_boundaries(dom)
+    assert sb["tracerBoundarySourceLocal"][10] == 31 and sb["tracerBoundarySourceLocal"][20] == 11
+    sbm.seaice_set_special_boundaries_tracers(dom)
+    for k in ("iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory"):
+        assert np.abs(tr[k][:, :, 4]).max() == 0.0
+        assert np.array_equal(tr[k][:, :, 10], before[k][:, :, 30])
+        assert np.array_equal(tr[k][:, :, 20], before[k][:, :, 30])
+        untouched = np.ones(tr[k].shape[-1], dtype=bool)
+        untouched[[4, 10, 20]] = False
+        assert np.array_equal(tr[k][..., untouched], before[k][..., untouched])
+    assert np.array_equal(tr["iceEnthalpy"], before["iceEnthalpy"])
