@@ -135,3 +135,34 @@ def test_weak_scheme_on_three_blocks(oracle):
         r = ref.blocklist[0].structs[pool][name][..., :n].astype(np.float64)
         err = np.abs(g - r).max() / max(np.abs(r).max(), 1e-300)
         assert err <= TOL, (name, err)
+
+
+def test_strain_averaging_on_three_blocks_follows_the_reference_per_block_loop(oracle):
+    """seaice_average_strains_on_vertex visits a block's owned vertices only (variational.F:715), so corners at
+    halo vertices keep their own strain and a partitioned run differs slightly from the one-block run: the
+    device has to agree with the oracle run on the same partition, block by block."""
+    mesh = get_mesh("QU480")
+    cfg = {"config_elastic_subcycle_number": 30, "config_average_variational_strain": True}
+    ref, rhalos, _ = parallel.make_partitioned_domain(mesh, "QU480", 3, configs=cfg, open_water_band=(-0.2, 0.3))
+    rcomm = parallel.LocalComm(ref, rhalos, 3)
+    ref.halo = parallel.oracle_halo_callback(rcomm)
+    ref.allreduce_min = rcomm.allreduce_min
+    oracle.seaice_init_velocity_solver(ref)
+    oracle.seaice_run_velocity_solver(ref)
+    dom, halos, _ = parallel.make_partitioned_domain(mesh, "QU480", 3, configs=cfg, open_water_band=(-0.2, 0.3))
+    vs.seaice_mesh_pool_create(dom, device=0)
+    try:
+        dom.comm = parallel.LocalComm(dom, halos, 3)
+        vs.seaice_init_velocity_solver(dom)
+        vs.seaice_run_velocity_solver(dom)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+    for pool, name, loc, n in (("velocity_solver", "uVelocity", "vertex", mesh.nVertices),
+                               ("velocity_solver", "vVelocity", "vertex", mesh.nVertices),
+                               ("velocity_variational", "stress11", "cell", mesh.nCells),
+                               ("velocity_variational", "strain12", "cell", mesh.nCells),
+                               ("velocity_solver", "divergence", "cell", mesh.nCells)):
+        g = parallel.gather_global(dom.blocklist, halos, pool, name, n, loc).astype(np.float64)
+        r = parallel.gather_global(ref.blocklist, rhalos, pool, name, n, loc).astype(np.float64)
+        err = np.abs(g - r).max() / max(np.abs(r).max(), 1e-300)
+        assert err <= TOL, (name, err)
