@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mesh", default="QU60", help="QU480/QU240/QU120/QU60/QU30, or an MPAS grid file (*.nc)")
+    ap.add_argument("--mesh", default="QU60", help="QU480/QU240/QU120/QU60/QU30/QU15, or an MPAS grid file (*.nc)")
     ap.add_argument("--partition-file", default=None, help="METIS graph.info.part.N for --gpus N (default: "
                     "cut along a space-filling curve)")
     ap.add_argument("--subcycles", type=int, default=120)

@@ -15,7 +15,7 @@ import numpy as np
 from .pools import Domain
 
 # config_dt per resolution, /root/reference/bld/namelist_files/namelist_defaults_mpassi.xml:8-12
-DT_BY_MESH = {"QU480": 7200.0, "QU240": 3600.0, "QU120": 1800.0, "QU60": 900.0, "QU30": 450.0}
+DT_BY_MESH = {"QU480": 7200.0, "QU240": 3600.0, "QU120": 1800.0, "QU60": 900.0, "QU30": 450.0, "QU15": 225.0}
 
 CATEGORY_AREA_FRACTION = np.array([0.10, 0.20, 0.30, 0.25, 0.15])
 CATEGORY_THICKNESS_FACTOR = np.array([0.3, 0.7, 1.0, 1.4, 2.0])

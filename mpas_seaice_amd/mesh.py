@@ -375,7 +375,7 @@ def make_variable_sphere_mesh(n: int, ratio: float = 3.0, jitter: float = 0.22, 
     return m
 
 
-QU_FREQ = {"QU480": 16, "QU240": 32, "QU120": 64, "QU60": 128, "QU30": 256}
+QU_FREQ = {"QU480": 16, "QU240": 32, "QU120": 64, "QU60": 128, "QU30": 256, "QU15": 512}
 
 
 def make_named_mesh(name: str, **kw) -> Mesh:
