@@ -42,6 +42,11 @@ module seaice_hip_interface
      integer(c_int32_t) :: averageVariationalStrain = 0
      integer(c_int32_t) :: useSpecialBoundariesVelocity = 0, useSpecialBoundariesVelocityMasks = 0
      integer(c_int32_t) :: strainScheme = 0, stressDivergenceScheme = 0   ! 0 variational, 1 weak
+     ! ice strength of the column package (colpkg_ice_strength): used when useColumnPackage and
+     ! useColumnVerticalThermodynamics are both set; kstrength, krdg_partic, krdg_redist, mu_rdg, Cf
+     integer(c_int32_t) :: useColumnVerticalThermodynamics = 0
+     integer(c_int32_t) :: iceStrengthFormulation = 1, ridgingParticipation = 1, ridgingRedistribution = 1
+     real(c_double)     :: ridgingEfoldingScale = 3.0_c_double, ridgingWorkRatio = 17.0_c_double
   end type sih_evp_config
 
   !> struct sih_ir_desc

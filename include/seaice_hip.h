@@ -90,7 +90,9 @@ typedef struct sih_evp_config {
     int32_t oceanStressType;          /* 1 quadratic, 2 linear */
     int32_t surfaceTilt;              /* 0 none, 1 geostrophic, 2 ssh gradient */
     int32_t calcVelocityMasks;
-    int32_t useColumnPackage;         /* only selects ridgeConvergence/ridgeShear output; strength is Hibler */
+    int32_t useColumnPackage;         /* config_use_column_package: ridgeConvergence / ridgeShear output; with
+                                         useColumnVerticalThermodynamics the ice strength is the column
+                                         package's (see below) */
     int32_t nCategories;
     double minEdgeLengthGlobal;       /* global min of dvEdge (mpas_dmpar_min_real in seaice_init_evp);
                                          <= 0: use this block's own minimum */
@@ -107,6 +109,18 @@ typedef struct sih_evp_config {
                                          with variational divergence interpolates the cell strains to the
                                          corners (velocity_solver.F:2768-2784); variational strain with weak
                                          divergence is an error in the reference too (:191-194) */
+    /* Ice strength (velocity_solver.F:1419-1458).  Without the column package, or without its vertical
+     * thermodynamics, Hibler's P* h exp(-C* (1 - a)).  With both, colpkg_ice_strength
+     * (src/column/ice_colpkg.F90:3498-3610) from the category areas and volumes and the field openWaterArea,
+     * including its ridge_itd (src/column/ice_mechred.F90:741-1012).  In that setting the fields
+     * iceAreaCellInitial and airStressCellU / airStressCellV are inputs too: the reference's column physics
+     * sets them before the velocity solver runs (velocity_solver.F:808-823, :1562-1565). */
+    int32_t useColumnVerticalThermodynamics; /* config_use_column_vertical_thermodynamics */
+    int32_t iceStrengthFormulation;   /* config_ice_strength_formulation (kstrength): 0 Hibler79, 1 Rothrock75 */
+    int32_t ridgingParticipation;     /* config_ridging_participation_function (krdg_partic): 0 Thorndike75, 1 exponential */
+    int32_t ridgingRedistribution;    /* config_ridging_redistribution_function (krdg_redist): 0 Hibler80, 1 exponential */
+    double ridgingEfoldingScale;      /* config_ridiging_efolding_scale (mu_rdg), 3.0 */
+    double ridgingWorkRatio;          /* config_ratio_ridging_work_to_PE (Cf), 17.0 */
 } sih_evp_config;
 
 /* ---- life cycle ----------------------------------------------------------------------------- */

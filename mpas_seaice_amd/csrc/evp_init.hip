@@ -647,8 +647,23 @@ extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
         sih_set_error("sih_evp_init: dt, subcycle numbers and nCategories must be positive");
         return SIH_ERR_ARG;
     }
+    if (cfg->useColumnPackage && cfg->useColumnVerticalThermodynamics) {
+        if (cfg->iceStrengthFormulation < 0 || cfg->iceStrengthFormulation > 1 || cfg->ridgingParticipation < 0 ||
+            cfg->ridgingParticipation > 1 || cfg->ridgingRedistribution < 0 || cfg->ridgingRedistribution > 1) {
+            sih_set_error("ice strength / ridging participation / redistribution option unknown");
+            return SIH_ERR_ARG;
+        }
+        if (cfg->nCategories > SIH_MAXCAT) {
+            sih_set_error("the column package's ice strength handles at most 32 thickness categories");
+            return SIH_ERR_UNSUPPORTED;
+        }
+    }
     HIPCHK(hipSetDevice(c->device));
     c->cfg = *cfg;
+    {
+        int rc = sih_add_field(c, "openWaterArea", LOC_CELL, 1, false);
+        if (rc) return rc;
+    }
     // category tracers are sized by nCategories, known only now
     if (!sih_find_field(c, "iceAreaCategory")) {
         const char *cats[3] = {"iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory"};

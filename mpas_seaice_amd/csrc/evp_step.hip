@@ -129,6 +129,13 @@ void sih_bind_dev(sih_ctx *c)
     d.useAir = c->cfg.useAirStress;
     d.tiltMode = c->cfg.surfaceTilt;
     d.useColumn = c->cfg.useColumnPackage;
+    d.columnStrength = c->cfg.useColumnPackage && c->cfg.useColumnVerticalThermodynamics;
+    d.kstrength = c->cfg.iceStrengthFormulation;
+    d.krdgPartic = c->cfg.ridgingParticipation;
+    d.krdgRedist = c->cfg.ridgingRedistribution;
+    d.muRdg = c->cfg.ridgingEfoldingScale;
+    d.Cf = c->cfg.ridgingWorkRatio;
+    d.openWater = fd("openWaterArea");
     d.haloVertices = c->cfg.computeHaloVertices ? 1 : 0;
 }
 
@@ -137,7 +144,7 @@ __device__ inline double sign1(double x) { return copysign(1.0, x); }
 // =========================================================================== pre-subcycle kernels
 
 // stage 0: aggregate_mass_and_area, velocity_solver.F:685-752 (loops to nCells, halo included) and
-// iceAreaCellInitial = iceAreaCell (:819)
+// iceAreaCellInitial = iceAreaCell (:819), unless the column physics has set it earlier in the time step (:808)
 __global__ void k_pre0_cells(SihDev d)
 {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -152,7 +159,7 @@ __global__ void k_pre0_cells(SihDev d)
     d.iceVolumeCell[c] = vi;
     d.snowVolumeCell[c] = vs;
     d.totalMassCell[c] = vi * RHOI + vs * RHOS;
-    d.iceAreaCellInitial[c] = a;
+    if (!d.columnStrength) d.iceAreaCellInitial[c] = a;
 }
 
 // seaice_interpolate_cell_to_vertex, mesh.F:2835-2851 (the sentinel slot holds area 0, value 0)
@@ -237,24 +244,107 @@ __global__ void k_pre2_vertices(SihDev d)
     d.vInit[v] = d.v[v];
 }
 
-// stage 3: ice_strength (Hibler branch :1419-1435) and constant_air_stress (:1665-1728)
+// colpkg_ice_strength (src/column/ice_colpkg.F90:3498-3610) with its ridge_itd (src/column/ice_mechred.F90:
+// 741-1012): Rothrock's strength from the potential energy change of the ridging ice.  Once per cell and
+// dynamics step; the per-category work arrays are small and dynamically indexed, which is fine here.
+__device__ double columnIceStrength(const SihDev &d, int c)
+{
+    const double puny = 1.0e-11, c0 = 0.0, c1 = 1.0, c2 = 2.0, p5 = 0.5, p333 = 1.0 / 3.0;
+    const double Gstar = 0.15, astar = 0.05, maxraft = 1.0, Hstar = 25.0;  // ice_mechred.F90:54-61
+    const double Gstari = c1 / Gstar, astari = c1 / astar;
+    const double Cp = 0.5 * 9.80616 * (1026.0 - 917.0) * 917.0 / 1026.0;  // ice_constants_colpkg.F90:60
+    const int ncat = d.nCat;
+    const size_t pc = d.padC;
+    if (d.kstrength != 1) return PSTAR * d.iceVolumeCell[c] * exp(-CSTAR * (c1 - d.iceAreaCell[c]));
+    const double aice0 = d.openWater[c];
+    double GsumA[SIH_MAXCAT + 2], apartic[SIH_MAXCAT + 1], hrmin[SIH_MAXCAT + 1], hrmax[SIH_MAXCAT + 1],
+        hrexp[SIH_MAXCAT + 1], krdg[SIH_MAXCAT + 1];
+    double *Gsum = GsumA + 1;  // Gsum(-1:ncat)
+    Gsum[-1] = c0;
+    Gsum[0] = aice0 > puny ? aice0 : Gsum[-1];
+    apartic[0] = c0;
+    for (int n = 1; n <= ncat; n++) {
+        const double a = d.iceAreaCat[(size_t)(n - 1) * pc + c];
+        apartic[n] = c0;
+        hrmin[n] = c0;
+        hrmax[n] = c0;
+        hrexp[n] = c0;
+        krdg[n] = c1;
+        Gsum[n] = a > puny ? Gsum[n - 1] + a : Gsum[n - 1];
+    }
+    const double work = c1 / Gsum[ncat];
+    for (int n = 0; n <= ncat; n++) Gsum[n] = Gsum[n] * work;
+    if (d.krdgPartic == 0) {  // Thorndike et al. 1975
+        for (int n = 0; n <= ncat; n++) {
+            if (Gsum[n] < Gstar)
+                apartic[n] = Gstari * (Gsum[n] - Gsum[n - 1]) * (c2 - Gstari * (Gsum[n - 1] + Gsum[n]));
+            else if (Gsum[n - 1] < Gstar)
+                apartic[n] = Gstari * (Gstar - Gsum[n - 1]) * (c2 - Gstari * (Gstar + Gsum[n - 1]));
+        }
+    } else {  // exponential dependence on G(h)
+        const double xtmp = c1 / (c1 - exp(-astari));
+        Gsum[-1] = exp(-Gsum[-1] * astari) * xtmp;
+        for (int n = 0; n <= ncat; n++) {
+            Gsum[n] = exp(-Gsum[n] * astari) * xtmp;
+            apartic[n] = Gsum[n - 1] - Gsum[n];
+        }
+    }
+    for (int n = 1; n <= ncat; n++) {
+        const double a = d.iceAreaCat[(size_t)(n - 1) * pc + c], v = d.iceVolCat[(size_t)(n - 1) * pc + c];
+        if (a > puny) {
+            double hi = v / a;
+            if (d.krdgRedist == 0) {  // Hibler 1980
+                hrmin[n] = fmin(c2 * hi, hi + maxraft);
+                hrmax[n] = c2 * sqrt(Hstar * hi);
+                hrmax[n] = fmax(hrmax[n], hrmin[n] + puny);
+                const double hrmean = p5 * (hrmin[n] + hrmax[n]);
+                krdg[n] = hrmean / hi;
+            } else {  // exponential redistribution
+                hi = fmax(hi, puny);
+                hrmin[n] = fmin(c2 * hi, hi + maxraft);
+                hrexp[n] = d.muRdg * sqrt(hi);
+                krdg[n] = (hrmin[n] + hrexp[n]) / hi;
+            }
+        }
+    }
+    double aksum = apartic[0];
+    for (int n = 1; n <= ncat; n++) aksum = aksum + apartic[n] * (c1 - c1 / krdg[n]);
+    double strength = 0.0;
+    for (int n = 1; n <= ncat; n++) {
+        const double a = d.iceAreaCat[(size_t)(n - 1) * pc + c], v = d.iceVolCat[(size_t)(n - 1) * pc + c];
+        if (a > puny && apartic[n] > c0) {
+            const double hi = v / a;
+            double h2rdg;
+            if (d.krdgRedist == 0)
+                h2rdg = p333 * (hrmax[n] * hrmax[n] * hrmax[n] - hrmin[n] * hrmin[n] * hrmin[n]) / (hrmax[n] - hrmin[n]);
+            else
+                h2rdg = hrmin[n] * hrmin[n] + c2 * hrmin[n] * hrexp[n] + c2 * hrexp[n] * hrexp[n];
+            const double dh2rdg = -hi * hi + h2rdg / krdg[n];
+            strength = strength + apartic[n] * dh2rdg;
+        }
+    }
+    return d.Cf * Cp * strength / aksum;
+}
+
+// stage 3: ice_strength (:1419-1458) and constant_air_stress (:1665-1728)
 __global__ void k_pre3_cells(SihDev d)
 {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.nCellsSolve) return;
     if (d.solveStress[c] == 1)
-        d.icePressure[c] = PSTAR * d.iceVolumeCell[c] * exp(-CSTAR * (1.0 - d.iceAreaCell[c]));
+        d.icePressure[c] = d.columnStrength ? columnIceStrength(d, c)
+                                            : PSTAR * d.iceVolumeCell[c] * exp(-CSTAR * (1.0 - d.iceAreaCell[c]));
     else
         d.icePressure[c] = 0.0;
-    if (d.useAir) {
+    if (!d.useAir) {
+        d.airCellU[c] = 0.0;
+        d.airCellV[c] = 0.0;
+    } else if (!d.columnStrength) {
         double ua = d.uAir[c], va = d.vAir[c];
         double windSpeed = sqrt(ua * ua + va * va);
         d.airCellU[c] = d.airDensity[c] * windSpeed * 0.0012 * ua * d.iceAreaCell[c];
         d.airCellV[c] = d.airDensity[c] * windSpeed * 0.0012 * va * d.iceAreaCell[c];
-    } else {
-        d.airCellU[c] = 0.0;
-        d.airCellV[c] = 0.0;
-    }
+    }  // else: airStressCellU / V come from the column physics' atmosphere fluxes (:1562-1565)
 }
 
 // stage 4 (vertices): air stress to vertices (:1638-1646), coriolis_force_coefficient (:1742-1788),

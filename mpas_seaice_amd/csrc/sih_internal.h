@@ -10,6 +10,7 @@
 #include "seaice_hip.h"
 
 #define SIH_MAXE 10  // largest maxEdges the kernels are instantiated for
+#define SIH_MAXCAT 32  // most thickness categories the column package's ice strength handles
 
 enum SihLoc { LOC_CELL = 0, LOC_VERTEX = 1, LOC_EDGE = 2 };
 
@@ -47,9 +48,12 @@ struct SihDev {
     double *iceAreaCell, *iceVolumeCell, *snowVolumeCell;
     const double *iceAreaCat, *iceVolCat, *snowVolCat;
     const double *uOcn, *vOcn, *tiltU, *tiltV, *uAir, *vAir, *airDensity;
+    const double *openWater;  // openWaterArea, read by the column package's ice strength
     // scalars
     double dtDyn, dtE, dampT, brlx;
     int relation, useOcean, quadratic, useAir, tiltMode, useColumn, haloVertices;
+    int columnStrength, kstrength, krdgPartic, krdgRedist;  // colpkg_ice_strength in place of Hibler's formula
+    double muRdg, Cf;
 };
 
 struct sih_ctx {

@@ -52,6 +52,9 @@ class EvpConfig(ctypes.Structure):
         ("computeHaloVertices", ctypes.c_int32), ("averageVariationalStrain", ctypes.c_int32),
         ("useSpecialBoundariesVelocity", ctypes.c_int32), ("useSpecialBoundariesVelocityMasks", ctypes.c_int32),
         ("strainScheme", ctypes.c_int32), ("stressDivergenceScheme", ctypes.c_int32),
+        ("useColumnVerticalThermodynamics", ctypes.c_int32), ("iceStrengthFormulation", ctypes.c_int32),
+        ("ridgingParticipation", ctypes.c_int32), ("ridgingRedistribution", ctypes.c_int32),
+        ("ridgingEfoldingScale", ctypes.c_double), ("ridgingWorkRatio", ctypes.c_double),
     ]
 
 

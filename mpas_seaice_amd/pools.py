@@ -41,6 +41,12 @@ DEFAULT_CONFIGS = {
     "config_calc_velocity_masks": True,
     "config_use_column_package": False,
     "config_use_column_vertical_thermodynamics": False,
+    # ice strength of the column package (Registry.xml:1685-1708), read when both options above are set
+    "config_ice_strength_formulation": "Rothrock75",
+    "config_ridging_participation_function": "exponential",
+    "config_ridging_redistribution_function": "exponential",
+    "config_ridiging_efolding_scale": 3.0,
+    "config_ratio_ridging_work_to_PE": 17.0,
     "config_use_special_boundaries_velocity": False,
     "config_use_special_boundaries_velocity_masks": False,
     "config_use_special_boundaries_tracers": False,

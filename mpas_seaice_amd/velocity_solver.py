@@ -134,9 +134,18 @@ def _evp_config(domain, block):
     c.oceanStressType = 1 if ost == "quadratic" else 2
     c.surfaceTilt = 0 if not cfg["config_use_surface_tilt"] else (1 if cfg["config_geostrophic_surface_tilt"] else 2)
     c.calcVelocityMasks = int(bool(cfg["config_calc_velocity_masks"]))
-    if cfg["config_use_column_package"] and cfg["config_use_column_vertical_thermodynamics"]:
-        raise _lib.SeaiceHipError("colpkg_ice_strength (column package) is outside this solver's scope")
     c.useColumnPackage = int(bool(cfg["config_use_column_package"]))
+    c.useColumnVerticalThermodynamics = int(bool(cfg["config_use_column_vertical_thermodynamics"]))
+    # colpkg_ice_strength options (mpas_seaice_column.F:11432-11460)
+    for attr, key, table in (
+            ("iceStrengthFormulation", "config_ice_strength_formulation", {"Hibler79": 0, "Rothrock75": 1}),
+            ("ridgingParticipation", "config_ridging_participation_function", {"Thorndike75": 0, "exponential": 1}),
+            ("ridgingRedistribution", "config_ridging_redistribution_function", {"Hibler80": 0, "exponential": 1})):
+        if cfg[key] not in table:
+            raise _lib.SeaiceHipError(key + " unknown: " + str(cfg[key]))
+        setattr(c, attr, table[cfg[key]])
+    c.ridgingEfoldingScale = float(cfg["config_ridiging_efolding_scale"])
+    c.ridgingWorkRatio = float(cfg["config_ratio_ridging_work_to_PE"])
     c.nCategories = int(block.dimensions["nCategories"])
     c.minEdgeLengthGlobal = float(domain.solver_state.get("dvEdgeMinGlobal", 0.0))
     k = int(cfg.get("config_halo_exchange_interval", 1))
@@ -209,6 +218,11 @@ def _upload(domain, b):
         items += [("ocean_coupling", "seaSurfaceTiltU"), ("ocean_coupling", "seaSurfaceTiltV")]
     if not cfg["config_calc_velocity_masks"]:
         items += [("velocity_solver", "solveStress"), ("velocity_solver", "solveVelocity")]
+    if cfg["config_use_column_package"] and cfg["config_use_column_vertical_thermodynamics"]:
+        # what the column physics has left in the pools for the solver: open water for colpkg_ice_strength
+        # (velocity_solver.F:1451), the ice area at the start of the step (:808-823) and the air stress (:1562-1565)
+        items += [("icestate", "openWaterArea"), ("icestate", "iceAreaCellInitial"),
+                  ("velocity_solver", "airStressCellU"), ("velocity_solver", "airStressCellV")]
     b.ctx.put_many(_items(domain, b, items))
 
 

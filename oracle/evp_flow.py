@@ -169,6 +169,19 @@ def _interp_c2v(b, vert, cell):
          m["areaCell"])
 
 
+def column_strength_options(cfg):
+    """kstrength, krdg_partic, krdg_redist, mu_rdg, Cf from the namelist strings (mpas_seaice_column.F:11432-11460)"""
+    table = {"config_ice_strength_formulation": {"Hibler79": 0, "Rothrock75": 1},
+             "config_ridging_participation_function": {"Thorndike75": 0, "exponential": 1},
+             "config_ridging_redistribution_function": {"Hibler80": 0, "exponential": 1}}
+    out = []
+    for key, m in table.items():
+        if cfg[key] not in m:
+            raise ValueError(key + " unknown: " + str(cfg[key]))
+        out.append(m[cfg[key]])
+    return out + [float(cfg["config_ridiging_efolding_scale"]), float(cfg["config_ratio_ridging_work_to_PE"])]
+
+
 def velocity_solver_pre_subcycle(domain):
     cfg = domain.configs
     no_column = (not cfg["config_use_column_package"]) or (
@@ -213,9 +226,15 @@ def velocity_solver_pre_subcycle(domain):
     for b in domain.blocklist:
         d = b.dimensions
         vs, ta = b.structs["velocity_solver"], b.structs["tracers_aggregate"]
-        assert no_column, "colpkg_ice_strength is outside the hot path"
-        call("ora_ice_strength_hibler", d["nCellsSolve"], vs["solveStress"], ta["iceAreaCell"], ta["iceVolumeCell"],
-             vs["icePressure"])
+        if no_column:
+            call("ora_ice_strength_hibler", d["nCellsSolve"], vs["solveStress"], ta["iceAreaCell"],
+                 ta["iceVolumeCell"], vs["icePressure"])
+        else:  # colpkg_ice_strength, velocity_solver.F:1437-1458
+            k = column_strength_options(cfg)
+            tr = b.structs["tracers"]
+            call("ora_ice_strength_column", d["nCellsSolve"], d["nCategories"], vs["solveStress"], ta["iceAreaCell"],
+                 ta["iceVolumeCell"], b.structs["icestate"]["openWaterArea"], tr["iceAreaCategory"],
+                 tr["iceVolumeCategory"], k[0], k[1], k[2], k[3], k[4], vs["icePressure"])
     if ex:
         domain.halo(domain, "velocity_solver", ["icePressure"])
     for b in domain.blocklist:

@@ -728,6 +728,118 @@ void ora_ice_strength_hibler(int nCellsSolve, const int *solveStress, const doub
     }
 }
 
+/* The column package's strength, velocity_solver.F:1437-1458 -> colpkg_ice_strength
+ * (src/column/ice_colpkg.F90:3498-3610) with ridge_itd (src/column/ice_mechred.F90:741-1012).
+ * kstrength 1 Rothrock75 / else Hibler79, krdg_partic 0 Thorndike75 / 1 exponential, krdg_redist 0 Hibler80 /
+ * 1 exponential.  iceAreaCategory / iceVolumeCategory are (1, nCategories, nCells+1). */
+static double colpkg_ice_strength(int ncat, double aice, double vice, double aice0, const double *aicen,
+                                  const double *vicen, int kstrength, int krdg_partic, int krdg_redist,
+                                  double mu_rdg, double Cf)
+{
+    const double puny = 1.0e-11, c0 = 0.0, c1 = 1.0, c2 = 2.0, p5 = 0.5, p333 = 1.0 / 3.0;
+    const double Gstar = 0.15, astar = 0.05, maxraft = 1.0, Hstar = 25.0; /* ice_mechred.F90:54-61 */
+    const double Gstari = c1 / Gstar, astari = c1 / astar;
+    const double Cp = 0.5 * 9.80616 * (1026.0 - 917.0) * 917.0 / 1026.0; /* ice_constants_colpkg.F90:60 */
+    const double Pstar = 2.75e4, Cstar = 20.0;
+    double GsumA[64 + 2], apartic[64 + 1], hrmin[64 + 1], hrmax[64 + 1], hrexp[64 + 1], krdg[64 + 1];
+    double *Gsum = GsumA + 1; /* Gsum(-1:ncat) */
+    if (kstrength != 1) return Pstar * vice * exp(-Cstar * (c1 - aice));
+    /* ridge_itd */
+    Gsum[-1] = c0;
+    if (aice0 > puny)
+        Gsum[0] = aice0;
+    else
+        Gsum[0] = Gsum[-1];
+    apartic[0] = c0;
+    for (int n = 1; n <= ncat; n++) {
+        Gsum[n] = c1;
+        apartic[n] = c0;
+        hrmin[n] = c0;
+        hrmax[n] = c0;
+        hrexp[n] = c0;
+        krdg[n] = c1;
+        if (aicen[n - 1] > puny)
+            Gsum[n] = Gsum[n - 1] + aicen[n - 1];
+        else
+            Gsum[n] = Gsum[n - 1];
+    }
+    double work = c1 / Gsum[ncat];
+    for (int n = 0; n <= ncat; n++) Gsum[n] = Gsum[n] * work;
+    if (krdg_partic == 0) {
+        for (int n = 0; n <= ncat; n++) {
+            if (Gsum[n] < Gstar)
+                apartic[n] = Gstari * (Gsum[n] - Gsum[n - 1]) * (c2 - Gstari * (Gsum[n - 1] + Gsum[n]));
+            else if (Gsum[n - 1] < Gstar)
+                apartic[n] = Gstari * (Gstar - Gsum[n - 1]) * (c2 - Gstari * (Gstar + Gsum[n - 1]));
+        }
+    } else if (krdg_partic == 1) {
+        double xtmp = c1 / (c1 - exp(-astari));
+        Gsum[-1] = exp(-Gsum[-1] * astari) * xtmp;
+        for (int n = 0; n <= ncat; n++) {
+            Gsum[n] = exp(-Gsum[n] * astari) * xtmp;
+            apartic[n] = Gsum[n - 1] - Gsum[n];
+        }
+    }
+    if (krdg_redist == 0) {
+        for (int n = 1; n <= ncat; n++)
+            if (aicen[n - 1] > puny) {
+                double hi = vicen[n - 1] / aicen[n - 1];
+                hrmin[n] = fmin(c2 * hi, hi + maxraft);
+                hrmax[n] = c2 * sqrt(Hstar * hi);
+                hrmax[n] = fmax(hrmax[n], hrmin[n] + puny);
+                double hrmean = p5 * (hrmin[n] + hrmax[n]);
+                krdg[n] = hrmean / hi;
+            }
+    } else {
+        for (int n = 1; n <= ncat; n++)
+            if (aicen[n - 1] > puny) {
+                double hi = vicen[n - 1] / aicen[n - 1];
+                hi = fmax(hi, puny);
+                hrmin[n] = fmin(c2 * hi, hi + maxraft);
+                hrexp[n] = mu_rdg * sqrt(hi);
+                krdg[n] = (hrmin[n] + hrexp[n]) / hi;
+            }
+    }
+    double aksum = apartic[0];
+    for (int n = 1; n <= ncat; n++) aksum = aksum + apartic[n] * (c1 - c1 / krdg[n]);
+    /* colpkg_ice_strength, Rothrock branch */
+    double strength = 0.0;
+    if (krdg_redist == 0) {
+        for (int n = 1; n <= ncat; n++)
+            if (aicen[n - 1] > puny && apartic[n] > c0) {
+                double hi = vicen[n - 1] / aicen[n - 1];
+                double h2rdg = p333 * (hrmax[n] * hrmax[n] * hrmax[n] - hrmin[n] * hrmin[n] * hrmin[n]) /
+                               (hrmax[n] - hrmin[n]);
+                double dh2rdg = -hi * hi + h2rdg / krdg[n];
+                strength = strength + apartic[n] * dh2rdg;
+            }
+    } else if (krdg_redist == 1) {
+        for (int n = 1; n <= ncat; n++)
+            if (aicen[n - 1] > puny && apartic[n] > c0) {
+                double hi = vicen[n - 1] / aicen[n - 1];
+                double h2rdg = hrmin[n] * hrmin[n] + c2 * hrmin[n] * hrexp[n] + c2 * hrexp[n] * hrexp[n];
+                double dh2rdg = -hi * hi + h2rdg / krdg[n];
+                strength = strength + apartic[n] * dh2rdg;
+            }
+    }
+    return Cf * Cp * strength / aksum;
+}
+
+void ora_ice_strength_column(int nCellsSolve, int nCategories, const int *solveStress, const double *iceAreaCell,
+                             const double *iceVolumeCell, const double *openWaterArea,
+                             const double *iceAreaCategory, const double *iceVolumeCategory, int kstrength,
+                             int krdg_partic, int krdg_redist, double mu_rdg, double Cf, double *icePressure)
+{
+    for (int c = 0; c < nCellsSolve; c++) {
+        icePressure[c] = 0.0;
+        if (solveStress[c] == 1)
+            icePressure[c] = colpkg_ice_strength(nCategories, iceAreaCell[c], iceVolumeCell[c], openWaterArea[c],
+                                                 iceAreaCategory + (size_t)c * nCategories,
+                                                 iceVolumeCategory + (size_t)c * nCategories, kstrength, krdg_partic,
+                                                 krdg_redist, mu_rdg, Cf);
+    }
+}
+
 /* velocity_solver.F:1665-1728 */
 void ora_constant_air_stress(int nCellsSolve, const double *uAirVelocity, const double *vAirVelocity,
                              const double *airDensity, const double *iceAreaCell, double *airStressCellU,

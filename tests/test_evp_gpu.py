@@ -345,3 +345,44 @@ def test_ice_free_domain(oracle):
     for k, a in b.structs["tracers"].items():
         assert np.isfinite(a).all(), k
     assert np.abs(b.structs["tracers"]["iceAreaCategory"]).max() == 0.0
+
+
+@pytest.mark.parametrize("strength,partic,redist", [("Rothrock75", "exponential", "exponential"),
+                                                    ("Rothrock75", "Thorndike75", "Hibler80"),
+                                                    ("Hibler79", "exponential", "exponential")])
+def test_column_package_ice_strength(oracle, strength, partic, redist):
+    """config_use_column_package with vertical thermodynamics (the production setting): ice strength from
+    colpkg_ice_strength instead of Hibler's formula, and the ridging outputs of the post-cycle"""
+    cfg = {"config_elastic_subcycle_number": 40, "config_use_column_package": True,
+           "config_use_column_vertical_thermodynamics": True, "config_ice_strength_formulation": strength,
+           "config_ridging_participation_function": partic, "config_ridging_redistribution_function": redist}
+    doms = []
+    for _ in range(2):
+        d = cases.make_domain(get_mesh("var12"), None, configs=dict(cfg, config_dt=1800.0), open_water_band=(-0.2, 0.3))
+        b = d.blocklist[0]
+        nC = b.dimensions["nCells"]
+        area = b.structs["tracers"]["iceAreaCategory"][0].sum(axis=0)
+        # what the column physics hands over: open water, the ice area at the start of the step, the air stress
+        b.structs["icestate"]["openWaterArea"][:] = 1.0 - area
+        b.structs["icestate"]["iceAreaCellInitial"][:] = area
+        at, v = b.structs["atmos_coupling"], b.structs["velocity_solver"]
+        v["airStressCellU"][:nC] = 1.3e-3 * 1.3 * np.abs(at["uAirVelocity"][:nC]) * at["uAirVelocity"][:nC] * area[:nC]
+        v["airStressCellV"][:nC] = 1.3e-3 * 1.3 * np.abs(at["vAirVelocity"][:nC]) * at["vAirVelocity"][:nC] * area[:nC]
+        doms.append(d)
+    ref, dev = doms
+    oracle.seaice_init_velocity_solver(ref)
+    oracle.seaice_run_velocity_solver(ref)
+    vs.seaice_mesh_pool_create(dev)
+    try:
+        vs.seaice_init_velocity_solver(dev)
+        vs.seaice_run_velocity_solver(dev)
+    finally:
+        vs.seaice_mesh_pool_destroy(dev)
+    compare_domains(dev, ref, STATE + [("velocity_solver", "icePressure"), ("ridging", "ridgeConvergence"),
+                                       ("ridging", "ridgeShear")], 1e-10)
+    P = dev.blocklist[0].structs["velocity_solver"]["icePressure"]
+    assert P.max() > 1.0e3 and np.isfinite(P).all()
+    if strength == "Rothrock75":  # not Hibler's formula
+        ta = dev.blocklist[0].structs["tracers_aggregate"]
+        hib = 2.75e4 * ta["iceVolumeCell"] * np.exp(-20.0 * (1.0 - ta["iceAreaCell"]))
+        assert np.abs(P - hib).max() > 1.0e2

@@ -328,3 +328,44 @@ def test_special_boundaries_tracers_sequential_in_place():
         untouched[[4, 10, 20]] = False
         assert np.array_equal(tr[k][..., untouched], before[k][..., untouched])
     assert np.array_equal(tr["iceEnthalpy"], before["iceEnthalpy"])
+
+
+def _column_strength(oracle, aicen, vicen, aice0, opts):
+    """one cell through ora_ice_strength_column"""
+    n = len(aicen)
+    a = np.zeros((1, n, 2), order="F")
+    v = np.zeros((1, n, 2), order="F")
+    a[0, :, 0], v[0, :, 0] = aicen, vicen
+    P = np.zeros(2)
+    oracle.call("ora_ice_strength_column", 1, n, np.ones(2, dtype=np.int32), np.array([sum(aicen), 0.0]),
+                np.array([sum(vicen), 0.0]), np.array([aice0, 0.0]), a, v, opts[0], opts[1], opts[2], float(opts[3]),
+                float(opts[4]), P)
+    return P[0]
+
+
+def test_column_package_ice_strength_known_values(oracle):
+    """colpkg_ice_strength restated: closed forms for one category of thickness h and no open water.
+    All ice then participates (apartic(1) = 1 for both participation functions) and the strength is
+    Cf Cp (-h^2 + <h_r^2> / k) / (1 - 1/k) with k the mean ridge thickness ratio."""
+    Cf, Cp = 17.0, 0.5 * 9.80616 * (1026.0 - 917.0) * 917.0 / 1026.0
+    h = 2.0
+    # exponential redistribution: hrmin = min(2h, h + 1), hrexp = mu sqrt(h), k = (hrmin + hrexp) / h
+    hrmin, hrexp = min(2 * h, h + 1.0), 3.0 * np.sqrt(h)
+    k = (hrmin + hrexp) / h
+    want = Cf * Cp * (-h * h + (hrmin ** 2 + 2 * hrmin * hrexp + 2 * hrexp ** 2) / k) / (1.0 - 1.0 / k)
+    for partic in (0, 1):
+        got = _column_strength(oracle, [1.0], [h], 0.0, (1, partic, 1, 3.0, Cf))
+        assert abs(got - want) <= 1e-12 * want, (partic, got, want)
+    # Hibler 1980 redistribution: ridges uniform between hrmin and hrmax = 2 sqrt(25 h)
+    hrmax = 2.0 * np.sqrt(25.0 * h)
+    k = 0.5 * (hrmin + hrmax) / h
+    want = Cf * Cp * (-h * h + (hrmax ** 3 - hrmin ** 3) / (3.0 * (hrmax - hrmin)) / k) / (1.0 - 1.0 / k)
+    got = _column_strength(oracle, [1.0], [h], 0.0, (1, 1, 0, 3.0, Cf))
+    assert abs(got - want) <= 1e-12 * want
+    # kstrength = 0 is Hibler's formula
+    got = _column_strength(oracle, [0.3, 0.5], [0.3, 1.5], 0.2, (0, 1, 1, 3.0, Cf))
+    assert abs(got - 2.75e4 * 1.8 * np.exp(-20.0 * (1.0 - 0.8))) <= 1e-9
+    # open water takes part in the closing first: with 20 % open water the pack is much weaker than without
+    weak = _column_strength(oracle, [0.3, 0.5], [0.3, 1.5], 0.2, (1, 1, 1, 3.0, Cf))
+    strong = _column_strength(oracle, [0.375, 0.625], [0.375, 1.875], 0.0, (1, 1, 1, 3.0, Cf))
+    assert 0.0 < weak < 0.1 * strong
