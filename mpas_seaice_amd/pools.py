@@ -71,6 +71,8 @@ DEFAULT_CONFIGS = {
     "config_nIceLayers": 7,
     "config_nSnowLayers": 1,
     "config_earth_radius": 6371229.0,
+    "config_do_restart": False,
+    "config_calculate_coriolis": True,
 }
 
 

@@ -71,3 +71,25 @@ def test_restart_round_trip(tmp_path, oracle):
         n = b0.dimensions[ent]
         assert np.array_equal(b0.structs[pool][name][..., :n], b1.structs[pool][name][..., :n]), name
     assert np.abs(b1.structs["velocity_variational"]["stress11"]).max() > 0
+
+
+def test_seaice_init_mesh_rescales_and_sets_coriolis():
+    """seaice_init_mesh on the pools: a unit-sphere mesh expanded to config_earth_radius equals the mesh built at
+    that radius; fVertex = 2 omega sin(lat); a restart refuses a mesh of another radius."""
+    from mpas_seaice_amd import cases, mesh as meshmod, mesh_init
+    unit = meshmod.make_sphere_mesh(8, radius=1.0)
+    full = meshmod.make_sphere_mesh(8, radius=6371229.0)
+    dom = cases.make_domain(unit, None)
+    ref = cases.make_domain(full, None)
+    dom.blocklist[0].structs["mesh"]["fVertex"][:] = 0.0
+    mesh_init.seaice_init_mesh(dom)
+    m, r = dom.blocklist[0].structs["mesh"], ref.blocklist[0].structs["mesh"]
+    assert m["sphere_radius"] == 6371229.0
+    for k in ("xCell", "zVertex", "yEdge", "areaCell", "areaTriangle", "dvEdge", "dcEdge", "kiteAreasOnVertex"):
+        assert np.allclose(m[k], r[k], rtol=1e-12, atol=1e-6 * np.abs(r[k]).max() * 1e-6), k
+    nV = unit.nVertices
+    assert np.allclose(m["fVertex"][:nV], 2.0 * 7.29212e-5 * np.sin(m["latVertex"][:nV]), rtol=0, atol=1e-18)
+    dom2 = cases.make_domain(unit, None, configs={"config_do_restart": True})
+    import pytest
+    with pytest.raises(RuntimeError, match="inconsistent radii"):
+        mesh_init.seaice_init_mesh(dom2)
