@@ -289,6 +289,20 @@ module seaice_hip_interface
        integer(c_int) :: ierr
      end function sih_ir_check_monotonicity
 
+     !> page-locked host memory for arrays exchanged every step (use with c_f_pointer)
+     function sih_host_alloc(ptr, bytes) bind(C, name="sih_host_alloc") result(ierr)
+       import :: c_int, c_ptr, c_size_t
+       type(c_ptr), intent(out) :: ptr
+       integer(c_size_t), value :: bytes
+       integer(c_int) :: ierr
+     end function sih_host_alloc
+
+     function sih_host_free(ptr) bind(C, name="sih_host_free") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ptr
+       integer(c_int) :: ierr
+     end function sih_host_free
+
      function sih_ir_unpack_reconstruction(ctx) bind(C, name="sih_ir_unpack_reconstruction") result(ierr)
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx

@@ -134,6 +134,12 @@ const char *sih_last_error(void);
 int sih_set_stream(sih_ctx *ctx, void *hipStream);
 int sih_sync(sih_ctx *ctx);
 
+/* Page-locked host memory (hipHostMalloc) for arrays that travel every step: sih_field(s)_put / _get from
+ * and to it run at the link's DMA rate instead of the pageable-memory rate (about 2x up, 3x down on an
+ * MI355X box).  No counterpart in the reference, where the framework allocates the pools; optional. */
+int sih_host_alloc(void **ptr, size_t bytes);
+int sih_host_free(void *ptr);
+
 /* ---- initialisation ------------------------------------------------------------------------- */
 /* Edge description of the mesh for the weak scheme (velocity_solver_weak.F; its normal vectors
  * mesh.F:703-1606 need edge positions and the edge <-> cell / vertex connectivity): the same struct the

@@ -467,6 +467,26 @@ extern "C" int sih_sync(sih_ctx *c)
     return SIH_OK;
 }
 
+// Page-locked host memory for the arrays a host exchanges with the library every step.  Transfers from and
+// to such memory are plain DMA (measured 57 GB/s either way on an MI355X box, against 30 GB/s up and 18 GB/s
+// down for pageable memory, which the runtime has to stage).
+extern "C" int sih_host_alloc(void **p, size_t bytes)
+{
+    if (!p) {
+        sih_set_error("sih_host_alloc: null argument");
+        return SIH_ERR_ARG;
+    }
+    *p = nullptr;
+    HIPCHK(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocPortable));
+    return SIH_OK;
+}
+
+extern "C" int sih_host_free(void *p)
+{
+    if (p) HIPCHK(hipHostFree(p));
+    return SIH_OK;
+}
+
 extern "C" size_t sih_field_count(sih_ctx *c, const char *name, int *elemSize)
 {
     SihField *f = c ? sih_find_field(c, name) : nullptr;

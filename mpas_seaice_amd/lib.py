@@ -76,7 +76,7 @@ EXPORTS = [
     "sih_ir_init", "sih_ir_set_tracers", "sih_ir_run", "sih_ir_get_sums", "sih_ir_run_timed",
     "sih_fields_put", "sih_fields_get", "sih_evp_overlap_setup", "sih_evp_subcycle_parts",
     "sih_evp_set_special_boundaries", "sih_ir_check_monotonicity", "sih_evp_set_edge_mesh",
-    "sih_ir_unpack_reconstruction", "sih_upwind_init", "sih_upwind_prepare", "sih_upwind_advect", "sih_upwind_run", "sih_upwind_get_sums",
+    "sih_ir_unpack_reconstruction", "sih_host_alloc", "sih_host_free", "sih_upwind_init", "sih_upwind_prepare", "sih_upwind_advect", "sih_upwind_run", "sih_upwind_get_sums",
 ]
 
 
@@ -141,6 +141,8 @@ def load():
     lib.sih_ir_get_sums.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.sih_ir_run_timed.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
                                      ctypes.c_void_p]
+    lib.sih_host_alloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    lib.sih_host_free.argtypes = [ctypes.c_void_p]
     lib.sih_upwind_init.argtypes = [ctypes.c_void_p, ctypes.POINTER(IrDesc)]
     lib.sih_upwind_prepare.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.sih_upwind_advect.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int]
@@ -158,6 +160,19 @@ def check(rc, what=""):
 
 def _ptr(a):
     return ctypes.c_void_p(a.ctypes.data) if a is not None else None
+
+
+def pinned_empty(shape, dtype=np.float64, order="F"):
+    """A numpy array in page-locked host memory (sih_host_alloc); freed with the array."""
+    import weakref
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+    p = ctypes.c_void_p()
+    check(load().sih_host_alloc(ctypes.byref(p), max(n, 1) * dt.itemsize), "sih_host_alloc")
+    buf = (ctypes.c_char * (max(n, 1) * dt.itemsize)).from_address(p.value)
+    a = np.frombuffer(buf, dtype=dt, count=n).reshape(shape, order=order)
+    weakref.finalize(buf, load().sih_host_free, p)  # the array keeps `buf` alive through its base
+    return a
 
 
 class BlockContext:

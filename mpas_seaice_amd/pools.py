@@ -257,3 +257,20 @@ def mpas_pool_shift_time_levels(block, pool):
     for k in a:
         if k in b:
             a[k], b[k] = b[k], a[k]
+
+
+def pin_pools(domain, pools=None):
+    """Move the arrays of the pools (all, or the named ones) into page-locked host memory, contents kept:
+    the per-step transfers between pools and device then run at the link's DMA rate.  Optional; needs the
+    device library (there is no pageable fallback inside this call)."""
+    from . import lib
+    for b in domain.blocklist:
+        for pname, pool in b.structs.items():
+            if pools is not None and pname not in pools:
+                continue
+            for k, a in list(pool.items()):
+                if isinstance(a, np.ndarray) and a.ndim >= 1 and a.size > 1 and a.dtype in (np.float64, np.int32):
+                    order = "F" if a.flags["F_CONTIGUOUS"] else "C"
+                    p = lib.pinned_empty(a.shape, a.dtype, order=order)
+                    p[...] = a
+                    pool[k] = p

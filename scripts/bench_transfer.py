@@ -7,7 +7,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from mpas_seaice_amd import cases, mesh as meshmod, velocity_solver as vs
+from mpas_seaice_amd import cases, mesh as meshmod, pools, velocity_solver as vs
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--mesh", default="QU60")
@@ -15,8 +15,10 @@ ap.add_argument("--reps", type=int, default=3)
 args = ap.parse_args()
 
 out = {}
-for pinned in (False,):
+for pinned in (False, True):
     dom = cases.make_domain(meshmod.make_named_mesh(args.mesh), "analytic")
+    if pinned:
+        pools.pin_pools(dom)
     vs.seaice_mesh_pool_create(dom)
     vs.seaice_init_velocity_solver(dom)
     b = dom.blocklist[0]
