@@ -744,6 +744,7 @@ static double colpkg_ice_strength(int ncat, double aice, double vice, double aic
     double GsumA[64 + 2], apartic[64 + 1], hrmin[64 + 1], hrmax[64 + 1], hrexp[64 + 1], krdg[64 + 1];
     double *Gsum = GsumA + 1; /* Gsum(-1:ncat) */
     if (kstrength != 1) return Pstar * vice * exp(-Cstar * (c1 - aice));
+    if (ncat > 64) return NAN; /* the work arrays above */
     /* ridge_itd */
     Gsum[-1] = c0;
     if (aice0 > puny)
