@@ -121,6 +121,8 @@ typedef struct sih_evp_config {
     int32_t ridgingRedistribution;    /* config_ridging_redistribution_function (krdg_redist): 0 Hibler80, 1 exponential */
     double ridgingEfoldingScale;      /* config_ridiging_efolding_scale (mu_rdg), 3.0 */
     double ridgingWorkRatio;          /* config_ratio_ridging_work_to_PE (Cf), 17.0 */
+    int32_t wachspressIntegrationType; /* config_wachspress_integration_type: 0 or 1 dunavant (order 8 only),
+                                          2 trapezoidal (orders 1..21); wachspress.F:1223-1387 */
 } sih_evp_config;
 
 /* ---- life cycle ----------------------------------------------------------------------------- */

@@ -13,15 +13,15 @@ SihField *sih_find_field(sih_ctx *c, const char *name);
 
 // Dunavant (1985) degree-8 rule, 16 points, as carried (14 digits) by
 // src/shared/mpas_seaice_velocity_solver_wachspress.F:1573-1597; normalisation factor 2 (:1426)
-__constant__ double c_dunU[16] = {0.33333333333333, 0.45929258829272, 0.45929258829272, 0.08141482341455,
+static const double h_dunU[16] = {0.33333333333333, 0.45929258829272, 0.45929258829272, 0.08141482341455,
                                   0.17056930775176, 0.17056930775176, 0.65886138449648, 0.05054722831703,
                                   0.05054722831703, 0.89890554336594, 0.26311282963464, 0.72849239295540,
                                   0.00839477740996, 0.72849239295540, 0.26311282963464, 0.00839477740996};
-__constant__ double c_dunV[16] = {0.33333333333333, 0.45929258829272, 0.08141482341455, 0.45929258829272,
+static const double h_dunV[16] = {0.33333333333333, 0.45929258829272, 0.08141482341455, 0.45929258829272,
                                   0.17056930775176, 0.65886138449648, 0.17056930775176, 0.05054722831703,
                                   0.89890554336594, 0.05054722831703, 0.72849239295540, 0.00839477740996,
                                   0.26311282963464, 0.26311282963464, 0.00839477740996, 0.72849239295540};
-__constant__ double c_dunW[16] = {0.14431560767779, 0.09509163426728, 0.09509163426728, 0.09509163426728,
+static const double h_dunW[16] = {0.14431560767779, 0.09509163426728, 0.09509163426728, 0.09509163426728,
                                   0.10321737053472, 0.10321737053472, 0.10321737053472, 0.03245849762320,
                                   0.03245849762320, 0.03245849762320, 0.02723031417443, 0.02723031417443,
                                   0.02723031417443, 0.02723031417443, 0.02723031417443, 0.02723031417443};
@@ -29,6 +29,10 @@ __constant__ double c_dunW[16] = {0.14431560767779, 0.09509163426728, 0.09509163
 struct InitArgs {
     int nCells, nVertices, nVerticesSolve, M, padC, padV, rotate, onASphere, includeMetric, alternateDenominator;
     int computeHalo;
+    // integration rule on the unit triangle: points (qU, qV), weights qW, sum divided by qNorm
+    int nQ;
+    double qNorm;
+    const double *qU, *qV, *qW;
     double R;
     const int *nEdgesOnCell, *voc, *cov;
     const double *xCell, *yCell, *zCell, *xVertex, *yVertex, *zVertex, *areaTriangle;
@@ -267,9 +271,9 @@ __global__ void k_wach_integrals(InitArgs a)
             double jac = m11 * m22 - m12 * m21;
             double sU[SIH_MAXE], sV[SIH_MAXE], sM[SIH_MAXE];
             for (int s = 0; s < SIH_MAXE; s++) sU[s] = sV[s] = sM[s] = 0.0;
-            for (int p = 0; p < 16; p++) {
-                double px = m11 * c_dunU[p] + m12 * c_dunV[p];
-                double py = m21 * c_dunU[p] + m22 * c_dunV[p];
+            for (int p = 0; p < a.nQ; p++) {
+                double px = m11 * a.qU[p] + m12 * a.qV[p];
+                double py = m21 * a.qU[p] + m22 * a.qV[p];
                 double num[SIH_MAXE], den = 0.0;
                 for (int s = 0; s < w.n; s++) {
                     num[s] = wachNumerator(w, s, px, py);
@@ -279,16 +283,16 @@ __global__ void k_wach_integrals(InitArgs a)
                 wachBasisDerivative(w, j, px, py, dNu, dNv);
                 double Nj = num[j] / den;
                 for (int s = 0; s < w.n; s++) {
-                    double tmp = jac * c_dunW[p] * (num[s] / den);
+                    double tmp = jac * a.qW[p] * (num[s] / den);
                     sU[s] = sU[s] + tmp * dNu;
                     sV[s] = sV[s] + tmp * dNv;
                     sM[s] = sM[s] + tmp * Nj;
                 }
             }
             for (int s = 0; s < w.n; s++) {
-                SU[s] = SU[s] + sU[s] / 2.0;
-                SV[s] = SV[s] + sV[s] / 2.0;
-                SM[s] = SM[s] + sM[s] / 2.0;
+                SU[s] = SU[s] + sU[s] / a.qNorm;
+                SV[s] = SV[s] + sV[s] / a.qNorm;
+                SM[s] = SM[s] + sM[s] / a.qNorm;
             }
         }
     }
@@ -617,9 +621,22 @@ extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
         sih_set_error("the 'pwl' basis needs edgesOnCell and dvEdge in the mesh description");
         return SIH_ERR_ARG;
     }
-    if (cfg->variationalBasis == 1 && cfg->wachspressIntegrationOrder != 8) {
-        sih_set_error("only the dunavant order-8 rule (the reference default) is implemented on the device");
-        return SIH_ERR_UNSUPPORTED;
+    if (cfg->variationalBasis == 1) {
+        // get_integration_factors, wachspress.F:1223-1285
+        if (cfg->wachspressIntegrationType == 0 || cfg->wachspressIntegrationType == 1) {
+            if (cfg->wachspressIntegrationOrder != 8) {
+                sih_set_error("of the dunavant rules only order 8 (the reference default) is implemented on the device");
+                return SIH_ERR_UNSUPPORTED;
+            }
+        } else if (cfg->wachspressIntegrationType == 2) {
+            if (cfg->wachspressIntegrationOrder < 1 || cfg->wachspressIntegrationOrder > SIH_MAX_TRAPEZOID) {
+                sih_set_error("trapezoidal integration: the order must lie between 1 and 21");
+                return SIH_ERR_UNSUPPORTED;
+            }
+        } else {
+            sih_set_error("Unknown Wachspress integration type (the fekete rules are not implemented on the device)");
+            return SIH_ERR_UNSUPPORTED;
+        }
     }
     if (cfg->variationalDenominator < 0 || cfg->variationalDenominator > 1) {
         sih_set_error("Unknown variational denominator type");
@@ -679,6 +696,48 @@ extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
     dim3 block(256);
     hipLaunchKernelGGL(k_init_vertices, dim3((c->nVertices + 255) / 256), block, 0, c->stream, a);
     if (cfg->variationalBasis == 1) {
+        // the integration rule on the unit triangle (get_integration_factors, wachspress.F:1223-1285)
+        std::vector<double> rule;  // [u..., v..., w...]
+        int nQ;
+        double qNorm;
+        if (cfg->wachspressIntegrationType == 2) {  // get_integration_factors_trapezoidal :1301-1387
+            const int n = cfg->wachspressIntegrationOrder;
+            nQ = ((n + 1) * (n + 1) + (n + 1)) / 2;
+            rule.assign((size_t)3 * nQ, 0.0);
+            int ij = 0;
+            for (int i = 0; i <= n; i++)
+                for (int j = 0; j <= n - i; j++) {
+                    rule[ij] = (double)i / (double)n;
+                    rule[nQ + ij] = (double)j / (double)n;
+                    double w;
+                    if (i == n || j == n || (i == 0 && j == 0))
+                        w = 1.0;
+                    else if ((j == 0 && i != 0 && i != n) || (i == 0 && j != 0 && j != n) || (i == n - j && i != 0 && j != 0))
+                        w = 3.0;
+                    else
+                        w = 6.0;
+                    rule[2 * nQ + ij] = w;
+                    ij++;
+                }
+            qNorm = 6.0 * ((double)n * (double)n);
+        } else {
+            nQ = 16;
+            rule.insert(rule.end(), h_dunU, h_dunU + 16);
+            rule.insert(rule.end(), h_dunV, h_dunV + 16);
+            rule.insert(rule.end(), h_dunW, h_dunW + 16);
+            qNorm = 2.0;
+        }
+        if (!c->d_rule) {
+            int rc0 = sih_dev_alloc(c, (void **)&c->d_rule, sizeof(double) * 3 * SIH_MAX_RULE);
+            if (rc0) return rc0;
+        }
+        HIPCHK(hipMemcpyAsync(c->d_rule, rule.data(), sizeof(double) * rule.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));  // `rule` is a local
+        a.nQ = nQ;
+        a.qNorm = qNorm;
+        a.qU = c->d_rule;
+        a.qV = c->d_rule + nQ;
+        a.qW = c->d_rule + 2 * nQ;
         long tot = (long)c->nCells * c->M;
         hipLaunchKernelGGL(k_wach_gradients, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, c->stream, a);
         hipLaunchKernelGGL(k_wach_integrals, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, c->stream, a);

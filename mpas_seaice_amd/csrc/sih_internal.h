@@ -10,6 +10,8 @@
 #include "seaice_hip.h"
 
 #define SIH_MAXE 10  // largest maxEdges the kernels are instantiated for
+#define SIH_MAX_TRAPEZOID 21  // largest trapezoidal integration order: (n+1)(n+2)/2 = 253 points
+#define SIH_MAX_RULE 256
 #define SIH_MAXCAT 32  // most thickness categories the column package's ice strength handles
 
 enum SihLoc { LOC_CELL = 0, LOC_VERTEX = 1, LOC_EDGE = 2 };
@@ -79,6 +81,7 @@ struct sih_ctx {
     bool splitCells = false;  // cell kernel with one thread per (cell, corner) instead of one per cell
     double minDvEdge = 0.0;
     SihDev dev{};
+    double *d_rule = nullptr;  // integration rule of the Wachspress integrals
     void *d_stage = nullptr;
     size_t stageBytes = 0;
     int nSend[2] = {0, 0}, nRecv[2] = {0, 0};

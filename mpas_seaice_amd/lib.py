@@ -55,6 +55,7 @@ class EvpConfig(ctypes.Structure):
         ("useColumnVerticalThermodynamics", ctypes.c_int32), ("iceStrengthFormulation", ctypes.c_int32),
         ("ridgingParticipation", ctypes.c_int32), ("ridgingRedistribution", ctypes.c_int32),
         ("ridgingEfoldingScale", ctypes.c_double), ("ridgingWorkRatio", ctypes.c_double),
+        ("wachspressIntegrationType", ctypes.c_int32),
     ]
 
 

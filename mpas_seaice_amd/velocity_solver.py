@@ -110,8 +110,6 @@ def _evp_config(domain, block):
     c.useSpecialBoundariesVelocityMasks = int(bool(cfg["config_use_special_boundaries_velocity_masks"]))
     basis = cfg["config_variational_basis"]
     if basis == "wachspress":
-        if cfg["config_wachspress_integration_type"] != "dunavant":
-            raise _lib.SeaiceHipError("only dunavant integration is implemented")
         c.variationalBasis = 1
     elif basis == "pwl":
         c.variationalBasis = 2
@@ -124,6 +122,11 @@ def _evp_config(domain, block):
         raise _lib.SeaiceHipError("Unknown variational denominator type: " + str(den))
     c.variationalDenominator = 1 if den == "alternate" else 0
     c.wachspressIntegrationOrder = int(cfg["config_wachspress_integration_order"])
+    itype = cfg["config_wachspress_integration_type"]
+    if itype not in ("dunavant", "trapezoidal"):  # get_integration_factors, wachspress.F:1250-1283
+        raise _lib.SeaiceHipError("Unknown Wachspress integration type (on the device: 'dunavant' order 8 or "
+                                  "'trapezoidal'): " + str(itype))
+    c.wachspressIntegrationType = 1 if itype == "dunavant" else 2
     c.rotateCartesianGrid = int(bool(cfg["config_rotate_cartesian_grid"]))
     c.includeMetricTerms = int(bool(cfg["config_include_metric_terms"]))
     c.useAirStress = int(bool(cfg["config_use_air_stress"]))

@@ -142,10 +142,9 @@ def seaice_init_velocity_solver(domain):
                  vv["basisIntegralsV"])
         else:
             assert cfg["config_variational_basis"] == "wachspress"
-            assert (cfg["config_wachspress_integration_type"] == "dunavant"
-                    and cfg["config_wachspress_integration_order"] == 8)
+            qu, qv, qw, qn = integration_rule(cfg)
             call("ora_wachspress_init", nC, M, m["nEdgesOnCell"], xl, yl, vv["basisGradientU"], vv["basisGradientV"],
-                 vv["basisIntegralsU"], vv["basisIntegralsV"], vv["basisIntegralsMetric"])
+                 vv["basisIntegralsU"], vv["basisIntegralsV"], vv["basisIntegralsMetric"], qu.size, qu, qv, qw, qn)
         call("ora_variational_denominator", vv["variationalDenominator"], nV, D, M, m["nEdgesOnCell"],
              m["areaTriangle"], m["cellsOnVertex"], vv["cellVerticesAtVertex"], vv["basisIntegralsMetric"],
              cfg["config_variational_denominator_type"] == "alternate")
@@ -167,6 +166,24 @@ def _interp_c2v(b, vert, cell):
     m = b.structs["mesh"]
     call("ora_interpolate_cell_to_vertex", vert, cell, d["nVerticesSolve"], d["vertexDegree"], m["cellsOnVertex"],
          m["areaCell"])
+
+
+def integration_rule(cfg):
+    """get_integration_factors (wachspress.F:1223-1285): points, weights and normalisation on the unit triangle"""
+    types = {"dunavant": 1, "trapezoidal": 2}
+    t = cfg["config_wachspress_integration_type"]
+    if t not in types:
+        raise ValueError("Unknown Wachspress integration type for the oracle: " + str(t))
+    u, v, w = np.zeros(256), np.zeros(256), np.zeros(256)
+    norm = np.zeros(1)
+    fn = lib().ora_integration_rule
+    fn.restype = ctypes.c_int
+    n = fn(ctypes.c_int(types[t]), ctypes.c_int(int(cfg["config_wachspress_integration_order"])),
+           ctypes.c_void_p(u.ctypes.data), ctypes.c_void_p(v.ctypes.data), ctypes.c_void_p(w.ctypes.data),
+           ctypes.c_void_p(norm.ctypes.data))
+    if n == 0:
+        raise ValueError("integration rule not restated: %s order %s" % (t, cfg["config_wachspress_integration_order"]))
+    return u[:n].copy(), v[:n].copy(), w[:n].copy(), float(norm[0])
 
 
 def column_strength_options(cfg):

@@ -323,9 +323,57 @@ static void wach_basis_derivative(const wach_cell *w, int i, double x, double y,
 
 /* seaice_init_velocity_solver_wachspress, wachspress.F:46-161 with calculate_wachspress_derivatives
  * (:1083-1206) and integrate_wachspress / integrate_wachspress_polygon (:179-467), Dunavant order 8. */
+/* get_integration_factors (:1223-1285): the rule on the unit triangle.  type 1 dunavant (order 8 only, the
+ * table above), type 2 trapezoidal (:1301-1387, any order up to 21 = 253 points).  u, v, w need 256 entries.
+ * Returns the number of points, 0 for a rule that is not restated. */
+int ora_integration_rule(int type, int order, double *u, double *v, double *w, double *normalizationFactor)
+{
+    if (type == 1) {
+        if (order != 8) return 0;
+        for (int p = 0; p < NQ; p++) {
+            u[p] = dunU[p];
+            v[p] = dunV[p];
+            w[p] = dunW[p];
+        }
+        *normalizationFactor = dunNorm;
+        return NQ;
+    }
+    if (type == 2) {
+        int n = order;
+        if (n < 1 || n > 21) return 0;
+        int nPoints = ((n + 1) * (n + 1) + (n + 1)) / 2;
+        int ij = 0;
+        for (int i = 0; i <= n; i++)
+            for (int j = 0; j <= n - i; j++) {
+                u[ij] = (double)i / (double)n;
+                v[ij] = (double)j / (double)n;
+                ij++;
+            }
+        ij = 0;
+        for (int i = 0; i <= n; i++)
+            for (int j = 0; j <= n - i; j++) {
+                w[ij] = 0.0;
+                if (i <= n - j) {
+                    if (i == n || j == n || (i == 0 && j == 0))
+                        w[ij] = 1.0;
+                    else if ((j == 0 && i != 0 && i != n) || (i == 0 && j != 0 && j != n) ||
+                             (i == n - j && i != 0 && j != 0))
+                        w[ij] = 3.0;
+                    else
+                        w[ij] = 6.0;
+                }
+                ij++;
+            }
+        *normalizationFactor = 6.0 * ((double)n * (double)n);
+        return nPoints;
+    }
+    return 0;
+}
+
 void ora_wachspress_init(int nCells, int maxEdges, const int *nEdgesOnCell, const double *xLocal,
                          const double *yLocal, double *basisGradientU, double *basisGradientV,
-                         double *basisIntegralsU, double *basisIntegralsV, double *basisIntegralsMetric)
+                         double *basisIntegralsU, double *basisIntegralsV, double *basisIntegralsMetric, int nq,
+                         const double *qU, const double *qV, const double *qW, double qNorm)
 {
     size_t mm = (size_t)maxEdges * (size_t)maxEdges;
     memset(basisGradientU, 0, sizeof(double) * mm * (size_t)nCells);
@@ -354,9 +402,11 @@ void ora_wachspress_init(int nCells, int maxEdges, const int *nEdgesOnCell, cons
                 basisGradientV[IX3(ib, ig, c, maxEdges)] = dv;
             }
         }
-        /* integrals: sub-triangles (centre, vertex t, vertex t+1) */
-        double N[MAXE + 1][MAXE + 1][NQ], dNu[MAXE + 1][MAXE + 1][NQ], dNv[MAXE + 1][MAXE + 1][NQ];
-        double jac[MAXE + 1];
+        /* integrals: sub-triangles (centre, vertex t, vertex t+1); for every pair (is, iv) the sum over the
+         * points of a sub-triangle first (in point order), then over the sub-triangles (:440-463) */
+        double SU[MAXE + 1][MAXE + 1], SV[MAXE + 1][MAXE + 1], SM[MAXE + 1][MAXE + 1];
+        for (int iv = 1; iv <= n; iv++)
+            for (int is = 1; is <= n; is++) SU[iv][is] = SV[iv][is] = SM[iv][is] = 0.0;
         for (int t = 1; t <= n; t++) {
             int i1 = t, i2 = wrapped_index(t + 1, n);
             /* get_triangle_mapping (:485-517) with (x1,y1)=(1,0), (x2,y2)=(0,1) */
@@ -366,36 +416,39 @@ void ora_wachspress_init(int nCells, int maxEdges, const int *nEdgesOnCell, cons
             double m12 = (u1 * x2 - u2 * x1) / (y1 * x2 - y2 * x1);
             double m21 = (v2 * y1 - v1 * y2) / (x2 * y1 - x1 * y2);
             double m22 = (v1 * x2 - v2 * x1) / (y1 * x2 - y2 * x1);
-            jac[t] = m11 * m22 - m12 * m21;
-            for (int p = 0; p < NQ; p++) {
-                double px = m11 * dunU[p] + m12 * dunV[p];
-                double py = m21 * dunU[p] + m22 * dunV[p];
+            double jac = m11 * m22 - m12 * m21;
+            double sU[MAXE + 1][MAXE + 1], sV[MAXE + 1][MAXE + 1], sM[MAXE + 1][MAXE + 1];
+            for (int iv = 1; iv <= n; iv++)
+                for (int is = 1; is <= n; is++) sU[iv][is] = sV[iv][is] = sM[iv][is] = 0.0;
+            for (int p = 0; p < nq; p++) {
+                double px = m11 * qU[p] + m12 * qV[p];
+                double py = m21 * qU[p] + m22 * qV[p];
+                double N[MAXE + 1], dNu[MAXE + 1], dNv[MAXE + 1];
                 for (int i = 1; i <= n; i++) {
-                    N[t][i][p] = wach_basis(&w, i, px, py);
-                    wach_basis_derivative(&w, i, px, py, &dNu[t][i][p], &dNv[t][i][p]);
+                    N[i] = wach_basis(&w, i, px, py);
+                    wach_basis_derivative(&w, i, px, py, &dNu[i], &dNv[i]);
                 }
-            }
-        }
-        for (int iv = 1; iv <= n; iv++) {
-            for (int is = 1; is <= n; is++) {
-                double SU = 0.0, SV = 0.0, SM = 0.0;
-                for (int t = 1; t <= n; t++) {
-                    double sU = 0.0, sV = 0.0, sM = 0.0;
-                    for (int p = 0; p < NQ; p++) {
-                        double tmp = jac[t] * dunW[p] * N[t][is][p];
-                        sU = sU + tmp * dNu[t][iv][p];
-                        sV = sV + tmp * dNv[t][iv][p];
-                        sM = sM + tmp * N[t][iv][p];
+                for (int iv = 1; iv <= n; iv++)
+                    for (int is = 1; is <= n; is++) {
+                        double tmp = jac * qW[p] * N[is];
+                        sU[iv][is] = sU[iv][is] + tmp * dNu[iv];
+                        sV[iv][is] = sV[iv][is] + tmp * dNv[iv];
+                        sM[iv][is] = sM[iv][is] + tmp * N[iv];
                     }
-                    SU = SU + sU / dunNorm;
-                    SV = SV + sV / dunNorm;
-                    SM = SM + sM / dunNorm;
-                }
-                basisIntegralsU[IX3(is, iv, c, maxEdges)] = SU;
-                basisIntegralsV[IX3(is, iv, c, maxEdges)] = SV;
-                basisIntegralsMetric[IX3(is, iv, c, maxEdges)] = SM;
             }
+            for (int iv = 1; iv <= n; iv++)
+                for (int is = 1; is <= n; is++) {
+                    SU[iv][is] = SU[iv][is] + sU[iv][is] / qNorm;
+                    SV[iv][is] = SV[iv][is] + sV[iv][is] / qNorm;
+                    SM[iv][is] = SM[iv][is] + sM[iv][is] / qNorm;
+                }
         }
+        for (int iv = 1; iv <= n; iv++)
+            for (int is = 1; is <= n; is++) {
+                basisIntegralsU[IX3(is, iv, c, maxEdges)] = SU[iv][is];
+                basisIntegralsV[IX3(is, iv, c, maxEdges)] = SV[iv][is];
+                basisIntegralsMetric[IX3(is, iv, c, maxEdges)] = SM[iv][is];
+            }
     }
 }
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_header_layout():
     # the ctypes mirrors must have the natural C layout of the header's structs
     assert ctypes.sizeof(lib.MeshDesc) == 8 * 4 + 4 + 4 + 8 + 18 * 8 + 8
-    assert ctypes.sizeof(lib.EvpConfig) == 8 + 15 * 4 + 4 + 8 + 6 * 4 + 4 * 4 + 2 * 8
+    assert ctypes.sizeof(lib.EvpConfig) == 8 + 15 * 4 + 4 + 8 + 6 * 4 + 4 * 4 + 2 * 8 + 8  # last: one int32 and padding
     assert ctypes.sizeof(lib.IrDesc) == 10 * 8 + 2 * 4
 
 

@@ -386,3 +386,38 @@ def test_column_package_ice_strength(oracle, strength, partic, redist):
         ta = dev.blocklist[0].structs["tracers_aggregate"]
         hib = 2.75e4 * ta["iceVolumeCell"] * np.exp(-20.0 * (1.0 - ta["iceAreaCell"]))
         assert np.abs(P - hib).max() > 1.0e2
+
+
+@pytest.mark.parametrize("order", [3, 12])
+def test_trapezoidal_wachspress_integration(oracle, order):
+    cfg = {"config_elastic_subcycle_number": 30, "config_wachspress_integration_type": "trapezoidal",
+           "config_wachspress_integration_order": order, "config_dt": 1800.0}
+    ref = cases.make_domain(get_mesh("var12"), None, configs=cfg, open_water_band=(-0.2, 0.3))
+    dev = cases.make_domain(get_mesh("var12"), None, configs=cfg, open_water_band=(-0.2, 0.3))
+    oracle.seaice_init_velocity_solver(ref)
+    oracle.seaice_run_velocity_solver(ref)
+    vs.seaice_mesh_pool_create(dev)
+    try:
+        vs.seaice_init_velocity_solver(dev)
+        vs.seaice_run_velocity_solver(dev)
+    finally:
+        vs.seaice_mesh_pool_destroy(dev)
+    static = [("velocity_variational", k) for k in ("basisIntegralsU", "basisIntegralsV", "basisIntegralsMetric",
+                                                    "variationalDenominator")]
+    compare_domains(dev, ref, static, 1e-13)
+    compare_domains(dev, ref, STATE, 1e-10)
+
+
+def test_unsupported_integration_rules_are_refused():
+    from mpas_seaice_amd.lib import SeaiceHipError
+    for cfg, msg in (({"config_wachspress_integration_type": "fekete"}, "integration type"),
+                     ({"config_wachspress_integration_order": 6}, "order 8"),
+                     ({"config_wachspress_integration_type": "trapezoidal", "config_wachspress_integration_order": 30},
+                      "between 1 and 21")):
+        dom = cases.make_domain(get_mesh("QU480"), "QU480", configs=cfg)
+        vs.seaice_mesh_pool_create(dom)
+        try:
+            with pytest.raises(SeaiceHipError, match=msg):
+                vs.seaice_init_velocity_solver(dom)
+        finally:
+            vs.seaice_mesh_pool_destroy(dom)

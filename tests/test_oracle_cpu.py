@@ -369,3 +369,27 @@ def test_column_package_ice_strength_known_values(oracle):
     weak = _column_strength(oracle, [0.3, 0.5], [0.3, 1.5], 0.2, (1, 1, 1, 3.0, Cf))
     strong = _column_strength(oracle, [0.375, 0.625], [0.375, 1.875], 0.0, (1, 1, 1, 3.0, Cf))
     assert 0.0 < weak < 0.1 * strong
+
+
+def test_trapezoidal_integration_rule(oracle):
+    """config_wachspress_integration_type = 'trapezoidal': the rule integrates constants and linear functions on
+    the unit triangle exactly, and the basis integrals it produces approach the order-8 Dunavant ones."""
+    for order in (1, 4, 9):
+        u, v, w, norm = oracle.integration_rule({"config_wachspress_integration_type": "trapezoidal",
+                                                 "config_wachspress_integration_order": order})
+        assert u.size == (order + 1) * (order + 2) // 2
+        assert abs(w.sum() / norm - 0.5) < 1e-14                 # area of the unit triangle
+        assert abs((w * u).sum() / norm - 1.0 / 6.0) < 1e-14     # integral of x
+        assert abs((w * v).sum() / norm - 1.0 / 6.0) < 1e-14
+    with pytest.raises(ValueError):
+        oracle.integration_rule({"config_wachspress_integration_type": "fekete", "config_wachspress_integration_order": 4})
+    mesh = get_mesh("QU480")
+    ref = _init(oracle, mesh)
+    SM8 = ref.blocklist[0].structs["velocity_variational"]["basisIntegralsMetric"]
+    err = []
+    for order in (4, 16):
+        dom = _init(oracle, mesh, {"config_wachspress_integration_type": "trapezoidal",
+                                   "config_wachspress_integration_order": order})
+        SM = dom.blocklist[0].structs["velocity_variational"]["basisIntegralsMetric"]
+        err.append(np.abs(SM - SM8).max() / np.abs(SM8).max())
+    assert err[1] < 0.25 * err[0] and err[1] < 5e-3, err
