@@ -20,6 +20,7 @@ import torch.distributed as dist  # noqa: E402
 from mpas_seaice_amd import cases, parallel  # noqa: E402
 from oracle import evp_flow as ora  # noqa: E402
 from oracle import ir_flow as ira  # noqa: E402
+from oracle import upwind_flow as upw  # noqa: E402
 from util import get_mesh  # noqa: E402
 
 
@@ -38,6 +39,11 @@ def main():
     ira.seaice_init_advection(ref)
     ora.seaice_run_velocity_solver(ref)
     ira.seaice_run_advection(ref)
+    upwind = "upwind" in sys.argv[3:]  # one more step with the upwind advection, surface temperature in kelvin
+    if upwind:
+        ref.blocklist[0].structs["tracers"]["surfaceTemperature"][..., :mesh.nCells] += 273.15
+        upw.seaice_init_advection_upwind(ref)
+        upw.seaice_run_advection_upwind(ref)
     dom, halo, _ = parallel.make_partitioned_domain(mesh, None, world, configs=cfg, only_block=rank,
                                                     open_water_band=(-0.2, 0.3))
     if mode == "cpu":
@@ -48,6 +54,10 @@ def main():
         ira.seaice_init_advection(dom)
         ora.seaice_run_velocity_solver(dom)
         ira.seaice_run_advection(dom)
+        if upwind:
+            dom.blocklist[0].structs["tracers"]["surfaceTemperature"][..., :dom.blocklist[0].dimensions["nCells"]] += 273.15
+            upw.seaice_init_advection_upwind(dom)
+            upw.seaice_run_advection_upwind(dom)
         tol = 0.0
     else:
         from mpas_seaice_amd import velocity_solver as vs
@@ -59,6 +69,11 @@ def main():
         adv.seaice_init_advection(dom)
         vs.seaice_run_velocity_solver(dom)
         adv.seaice_run_advection(dom)
+        if upwind:
+            from mpas_seaice_amd import advection_upwind
+            dom.blocklist[0].structs["tracers"]["surfaceTemperature"][..., :dom.blocklist[0].dimensions["nCells"]] += 273.15
+            advection_upwind.seaice_init_advection_upwind(dom)
+            advection_upwind.seaice_run_advection_upwind(dom)
         vs.seaice_mesh_pool_destroy(dom)
         tol = 1e-10
     b = dom.blocklist[0]
@@ -69,7 +84,8 @@ def main():
                             ("velocity_solver", "oceanStressCellU", "cell"), ("velocity_solver", "divergence", "cell"),
                             ("velocity_solver", "solveVelocity", "vertex"), ("tracers", "iceAreaCategory", "cell"),
                             ("tracers", "iceVolumeCategory", "cell"), ("tracers", "iceEnthalpy", "cell"),
-                            ("tracers", "snowEnthalpy", "cell"), ("tracers", "surfaceTemperature", "cell")):
+                            ("tracers", "snowEnthalpy", "cell"), ("tracers", "surfaceTemperature", "cell"),
+                            ("tracers", "snowVolumeCategory", "cell")):
         nown = halo.nOwned[loc]
         g = halo.globalID[loc][:nown]
         mine = b.structs[pool][name][..., :nown]

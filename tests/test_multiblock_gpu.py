@@ -46,7 +46,7 @@ def test_blocks_on_one_gpu_match_single_block_oracle(oracle, nblocks, interval):
         assert err <= TOL, (name, err)
 
 
-@pytest.mark.parametrize("extra", [[], ["overlap"]])
+@pytest.mark.parametrize("extra", [[], ["overlap"], ["upwind"]])
 def test_two_ranks_sharing_the_gpu_over_gloo(extra):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

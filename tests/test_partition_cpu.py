@@ -63,12 +63,14 @@ def test_multiblock_oracle_flow_is_bit_identical(oracle, nblocks):
         assert np.array_equal(g, r), name
 
 
-def test_two_process_gloo_halo_exchange():
-    """world_size 2 over gloo: each rank owns one block and runs the oracle flow on it."""
+@pytest.mark.parametrize("extra", [[], ["upwind"]])
+def test_two_process_gloo_halo_exchange(extra):
+    """world_size 2 over gloo: each rank owns one block and runs the oracle flow on it (velocity solver,
+    incremental remap; with "upwind" one more step of the upwind advection)."""
     port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "tests", "dist_worker.py"), "cpu", "geo8"]
+           os.path.join(ROOT, "tests", "dist_worker.py"), "cpu", "geo8"] + extra
     env = dict(os.environ, OMP_NUM_THREADS="2")
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
