@@ -173,6 +173,18 @@ def seaice_mesh_pool_destroy(domain):
             b.ctx = None
 
 
+def seaice_mesh_pool_update(domain):
+    """mesh_pool.F:261-281: in the reference's directive-based device builds this refreshes the device copies of
+    the masks, the ice strength, the velocities and the stresses from the pools before the subcycle loop
+    (velocity_solver.F:668).  Here those fields are computed or uploaded on the device already; the call is
+    kept for hosts that change them in the pools by hand between the pre-cycle and the loop."""
+    for b in domain.blocklist:
+        b.ctx.put_many(_items(domain, b, [
+            ("velocity_solver", "solveStress"), ("velocity_solver", "solveVelocity"), ("velocity_solver", "icePressure"),
+            ("velocity_solver", "uVelocity"), ("velocity_solver", "vVelocity"), ("velocity_variational", "stress11"),
+            ("velocity_variational", "stress12"), ("velocity_variational", "stress22")]))
+
+
 def seaice_init_velocity_solver(domain):
     cfg = domain.configs
     # global minimum edge length (mpas_dmpar_min_real in seaice_init_evp, constitutive_relation.F:132-149)

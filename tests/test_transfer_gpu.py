@@ -77,3 +77,21 @@ def test_pinned_pools_give_the_same_results():
     for pool, name in (("velocity_solver", "uVelocity"), ("velocity_variational", "stress12"),
                        ("velocity_solver", "solveVelocity")):
         assert np.array_equal(a.blocklist[0].structs[pool][name], b.blocklist[0].structs[pool][name]), name
+
+
+def test_mesh_pool_update_pushes_the_pools(oracle):
+    """seaice_mesh_pool_update: fields changed in the pools between the pre-cycle and the loop reach the device"""
+    cfg = {"config_elastic_subcycle_number": 10}
+    dom = cases.make_domain(get_mesh("QU480"), "QU480", configs=cfg)
+    vs.seaice_mesh_pool_create(dom)
+    try:
+        vs.seaice_init_velocity_solver(dom)
+        vs.seaice_run_velocity_solver(dom)
+        b = dom.blocklist[0]
+        b.structs["velocity_solver"]["uVelocity"][:] = 0.25
+        vs.seaice_mesh_pool_update(dom)
+        back = np.zeros_like(b.structs["velocity_solver"]["uVelocity"])
+        b.ctx.get("uVelocity", back)
+        assert np.all(back[:b.dimensions["nVertices"]] == 0.25)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
