@@ -411,3 +411,25 @@ def test_timestep_dynamics_loop(oracle, with_column):
         assert abs(dom.blocklist[0].structs["velocity_solver"]["dynamicsTimeStep"][0] - 0.5 * dom.configs["config_dt"]) < 1e-9
     finally:
         vs.seaice_mesh_pool_destroy(dom)
+
+
+def test_flux_kernel_variants_give_the_same_bits(oracle, monkeypatch):
+    """SIH_IR_FLUX_MODE=0 selects the flux kernel with one thread per (edge, category); the default has one per
+    (edge, tracer plane group).  Same sums in the same order."""
+    results = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SIH_IR_FLUX_MODE", mode)
+        dom = cases.make_domain(get_mesh("var12"), None, configs={"config_dt": 1800.0,
+                                                                  "config_elastic_subcycle_number": 20},
+                                open_water_band=(-0.2, 0.3))
+        vs.seaice_mesh_pool_create(dom)
+        try:
+            vs.seaice_init_velocity_solver(dom)
+            adv.seaice_init_advection(dom)
+            vs.seaice_run_velocity_solver(dom)
+            adv.seaice_run_advection(dom)
+        finally:
+            vs.seaice_mesh_pool_destroy(dom)
+        results.append(dom.blocklist[0].structs["tracers"])
+    for n in TRACERS:
+        assert np.array_equal(results[0][n], results[1][n]), n
