@@ -275,7 +275,8 @@ module seaice_hip_interface
      end function sih_ir_set_tracers
 
      ! checks: 1 = config_conservation_check, 2 = config_monotonicity_check (then sih_ir_check_monotonicity
-     ! must follow), 3 = both
+     ! must follow), 4 = config_recover_tracer_means_check (warnings counted in sih_get_info
+     ! "irRecoverMeansWarnings"), or their sum
      function sih_ir_run(ctx, dt, checks) bind(C, name="sih_ir_run") result(ierr)
        import :: c_int, c_ptr, c_double
        type(c_ptr), value :: ctx

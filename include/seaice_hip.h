@@ -316,8 +316,12 @@ int sih_ir_set_tracers(sih_ctx *ctx, int nTracers, const char *const *names, con
  * vectors).  `checks` is a bit set: 1 (config_conservation_check) also evaluates sum_tracers (:7998)
  * before and after the update; 2 (config_monotonicity_check) records the local minima and maxima of the
  * old values (tracer_local_min_max :8268) in the fields <tracer>LocalMin / <tracer>LocalMax and leaves
- * the thickness -> volume conversion to sih_ir_check_monotonicity, which must be called next. */
-enum { SIH_IR_CHECK_CONSERVATION = 1, SIH_IR_CHECK_MONOTONICITY = 2 };
+ * the thickness -> volume conversion to sih_ir_check_monotonicity, which must be called next; 4
+ * (config_recover_tracer_means_check) integrates every reconstruction over its cell (recover_tracer_means :7541),
+ * leaves the result in the fields <tracer>RecoveredProduct and counts the entries that differ from the product
+ * of the means by more than 1e-11 relative and absolute, where the reference logs a warning
+ * (sih_get_info "irRecoverMeansWarnings"). */
+enum { SIH_IR_CHECK_CONSERVATION = 1, SIH_IR_CHECK_MONOTONICITY = 2, SIH_IR_CHECK_RECOVER_MEANS = 4 };
 int sih_ir_run(sih_ctx *ctx, double dt, int checks);
 /* check_tracer_monotonicity (:8416-8749) after sih_ir_run(.., checks & 2): extends the local minima and
  * maxima by one layer of neighbours exactly as the reference's in-place loop does, compares every new
@@ -368,7 +372,7 @@ int sih_upwind_get_sums(sih_ctx *ctx, const char *tracer, double *initSums, doub
 
 /* introspection for tests and reports.  Keys: sparseGradient, splitCellKernel, dampingTimescale,
  * elasticTimeStep, dynamicsTimeStep, numericalInertiaCoefficient, padC, padV, minDvEdge, and
- * irCflWarnings: number of vertices whose departure distance in the last sih_ir_run exceeded the
+ * irRecoverMeansWarnings (see sih_ir_run), irCflWarnings: number of vertices whose departure distance in the last sih_ir_run exceeded the
  * shortest adjacent edge (the reference logs "Potential CFL violation in IR advection" and continues,
  * incremental_remap.F:5330-5345). */
 int sih_get_info(sih_ctx *ctx, const char *key, double *value);

@@ -10,6 +10,8 @@ sums, the optional final halo update.  There is no CPU path.
 """
 from __future__ import annotations
 
+import warnings
+
 import numpy as np
 
 from . import tracers as trc
@@ -81,9 +83,18 @@ def seaice_run_advection(domain, updateHaloInit=True, updateHaloFinal=False, upl
         comm.halo_exchange(domain, names)
     check = bool(cfg["config_conservation_check"])
     mono = bool(cfg["config_monotonicity_check"])
+    recover = bool(cfg["config_recover_tracer_means_check"])
+    if recover:
+        domain.solver_state["ir_recover_means_warnings"] = 0
     for b in domain.blocklist:
         dt = float(b.structs["velocity_solver"]["dynamicsTimeStep"][0])
-        b.ctx.ir_run(dt, check, mono)
+        b.ctx.ir_run(dt, check, mono, recover)
+        if recover:  # recover_tracer_means :7541-7982 only logs warnings; the count stands for them here
+            n = int(b.ctx.info("irRecoverMeansWarnings"))
+            domain.solver_state["ir_recover_means_warnings"] = \
+                domain.solver_state.get("ir_recover_means_warnings", 0) + n
+            if n:
+                warnings.warn(f"IR: Reconstructed tracer does not recover the mean in {n} entries")
     if check:  # check_tracer_conservation, :8126-8253 (global sums over blocks and ranks)
         nCat = domain.blocklist[0].dimensions["nCategories"]
         for t in tracersHead:

@@ -77,6 +77,7 @@ struct IrTracer {
     bool hasChild = false;
     double *val = nullptr, *rec = nullptr, *xB = nullptr, *yB = nullptr, *prod = nullptr, *flux = nullptr;
     double *center = nullptr, *gx = nullptr, *gy = nullptr;  // plane copies for inspection (sih_ir_unpack_reconstruction)
+    double *recovered = nullptr;  // mass*tracer product integrated from the reconstruction (recover-means check)
     std::vector<double> sumInit, sumFinal;
     // monotonicity check: min / max of the old values in the neighbourhood, whether the old parent value
     // exceeded 1e-11 (allocated on first use)
@@ -96,6 +97,7 @@ struct sih_ir_state {
     double *d_sums = nullptr;
     int iVol = -1, iSnow = -1;
     int cflWarnings = 0;
+    int recoverWarnings = 0;  // entries whose reconstruction did not recover the mean (last run with that check)
     bool monoReady = false, monoPending = false;
     double *monoTmp[4] = {nullptr, nullptr, nullptr, nullptr};  // ping-pong buffers of the extension sweeps
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1186,6 +1188,80 @@ __global__ void k_ir_zap(IrDev d, const IrTabEntry *__restrict__ tab, int nT)
     }
 }
 
+// recover_tracer_means :7541-7982 (config_recover_tracer_means_check): the product mass * tracer ... integrated
+// over the cell from the reconstructions, sub-triangle (centre, vertex i, vertex i+1) by sub-triangle with the
+// 6-point rule and the area fractions 0.25 dcEdge dvEdge / sum, against the product of the means.  One tracer per
+// launch; a diagnostic, so every thread recomputes what it needs.
+template <int M>
+__global__ void __launch_bounds__(256) k_ir_recover_means(IrDev d, const IrTabEntry *__restrict__ tab, int ti,
+                                                          double *recovered, int *count)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nCells) return;
+    const int cat = blockIdx.y;
+    const size_t pc = d.padC;
+    const IrTabEntry T = tab[ti];
+    const int n = d.nEdgesOnCell[c];
+    double frac[M], xv[M], yv[M];
+    double sumArea = 0.0;
+#pragma unroll
+    for (int ie = 0; ie < M; ie++) {
+        frac[ie] = 0.0;
+        xv[ie] = yv[ie] = 0.0;
+        if (ie < n) {
+            const int e = d.eoc[(size_t)ie * pc + c];
+            frac[ie] = 0.25 * d.dcEdge[e] * d.dvEdge[e];
+            sumArea = sumArea + frac[ie];
+            xv[ie] = d.xVOC[(size_t)ie * pc + c];
+            yv[ie] = d.yVOC[(size_t)ie * pc + c];
+        }
+    }
+    for (int layer = 0; layer < T.L; layer++) {
+        double cell = 0.0;
+#pragma unroll
+        for (int ie = 0; ie < M; ie++) {
+            if (ie < n) {
+                const double fr = frac[ie] / sumArea;
+                const int ip = ie + 1 < n ? ie + 1 : 0;
+                const double x1 = 0.0, y1 = 0.0, x2 = xv[ie], y2 = yv[ie];
+                double x3 = 0.0, y3 = 0.0;
+#pragma unroll
+                for (int k = 0; k < M; k++)
+                    if (k == ip) {
+                        x3 = xv[k];
+                        y3 = yv[k];
+                    }
+                double xq[6], yq[6];
+                xq[0] = Q1QP * x1 + Q1QP * x2 + Q2QP * x3;  yq[0] = Q1QP * y1 + Q1QP * y2 + Q2QP * y3;
+                xq[1] = Q1QP * x1 + Q2QP * x2 + Q1QP * x3;  yq[1] = Q1QP * y1 + Q2QP * y2 + Q1QP * y3;
+                xq[2] = Q2QP * x1 + Q1QP * x2 + Q1QP * x3;  yq[2] = Q2QP * y1 + Q1QP * y2 + Q1QP * y3;
+                xq[3] = Q3QP * x1 + Q4QP * x2 + Q4QP * x3;  yq[3] = Q3QP * y1 + Q4QP * y2 + Q4QP * y3;
+                xq[4] = Q4QP * x1 + Q3QP * x2 + Q4QP * x3;  yq[4] = Q4QP * y1 + Q3QP * y2 + Q4QP * y3;
+                xq[5] = Q4QP * x1 + Q4QP * x2 + Q3QP * x3;  yq[5] = Q4QP * y1 + Q4QP * y2 + Q3QP * y3;
+                double val[6] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (j < T.nLev) {
+                        const IrTabEntry &A = tab[T.chain[j]];
+                        const double *r = A.rec + IR_REC(A, cat, pc, c, A.L == 1 ? 0 : layer);
+                        const double cj = r[0], gxj = r[1], gyj = r[2];
+#pragma unroll
+                        for (int q = 0; q < 6; q++) val[q] = (cj + gxj * xq[q] + gyj * yq[q]) * val[q];
+                    }
+                }
+                double tri = 0.0;
+#pragma unroll
+                for (int q = 0; q < 6; q++) tri = tri + (q < 3 ? W1QP : W2QP) * val[q];
+                cell = cell + fr * tri;
+            }
+        }
+        const size_t k = (size_t)(cat * T.L + layer) * pc + c;
+        recovered[k] = cell;
+        const double mean = T.prod[k], difference = cell - mean;
+        if (fabs(difference) > EPS11 * fabs(mean) && fabs(difference) > EPS11) atomicAdd(count, 1);
+    }
+}
+
 // sum_tracers :7998-8111: one block per plane of tracer ti, sum over the owned cells of areaCell * (product
 // of the chain's values); the order of additions differs from the reference's serial loop (tree reduction)
 __global__ void k_ir_sum(IrDev d, const IrTabEntry *__restrict__ tab, int ti, double *out)
@@ -1696,6 +1772,25 @@ static int irRun(sih_ctx *c, double dt, int checks, bool timed, double *totalMs,
     mark(1);
     // construct_linear_tracer_fields :3580-4189, compute_mass_tracer_products :6982
     launchCells(ir, s, false);
+    if (checks & SIH_IR_CHECK_RECOVER_MEANS) {
+        for (size_t i = 0; i < ir->tracers.size(); i++) {
+            IrTracer &t = ir->tracers[i];
+            if (!t.recovered) {
+                const std::string fn = t.name + "RecoveredProduct";
+                int rc0 = sih_add_field(c, fn.c_str(), LOC_CELL, t.L * d.nCat, false);
+                if (rc0) return rc0;
+                t.recovered = (double *)sih_find_field(c, fn.c_str())->d;
+            }
+            const dim3 g(gC, d.nCat);
+            if (d.M <= 6)
+                hipLaunchKernelGGL(k_ir_recover_means<6>, g, blk, 0, s, d, ir->d_tab, (int)i, t.recovered, c->d_flag + 3);
+            else if (d.M <= 8)
+                hipLaunchKernelGGL(k_ir_recover_means<8>, g, blk, 0, s, d, ir->d_tab, (int)i, t.recovered, c->d_flag + 3);
+            else
+                hipLaunchKernelGGL(k_ir_recover_means<SIH_MAXE>, g, blk, 0, s, d, ir->d_tab, (int)i, t.recovered,
+                                   c->d_flag + 3);
+        }
+    }
     mark(2);
     hipLaunchKernelGGL(k_ir_departure_points, dim3(gV), blk, 0, s, d, dt);
     hipLaunchKernelGGL(k_ir_triangles, dim3((d.nEdges + 127) / 128), dim3(128), 0, s, d);
@@ -1717,10 +1812,11 @@ static int irRun(sih_ctx *c, double dt, int checks, bool timed, double *totalMs,
     if (!monotonicity) irToVolume(c);
     mark(5);
     HIPCHK(hipGetLastError());
-    int flags[2] = {0, 0};
+    int flags[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(flags, c->d_flag, sizeof(flags), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     ir->cflWarnings = flags[1];
+    ir->recoverWarnings = flags[3];
     if (timed) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, ir->ev[0], ir->ev[5]));
@@ -1876,3 +1972,4 @@ extern "C" int sih_ir_get_sums(sih_ctx *c, const char *tracer, double *initSums,
 }
 
 int sih_ir_cfl_warnings(sih_ctx *c) { return c && c->ir ? c->ir->cflWarnings : 0; }
+int sih_ir_recover_warnings(sih_ctx *c) { return c && c->ir ? c->ir->recoverWarnings : 0; }

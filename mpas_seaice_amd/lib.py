@@ -381,8 +381,9 @@ class BlockContext:
         check(self._lib.sih_ir_set_tracers(self.handle, len(names), self._names(names), self._names(parents),
                                            _ptr(nl)), "sih_ir_set_tracers")
 
-    def ir_run(self, dt, check_conservation=False, check_monotonicity=False):
-        checks = (1 if check_conservation else 0) | (2 if check_monotonicity else 0)
+    def ir_run(self, dt, check_conservation=False, check_monotonicity=False, check_recover_means=False):
+        checks = ((1 if check_conservation else 0) | (2 if check_monotonicity else 0)
+                  | (4 if check_recover_means else 0))
         check(self._lib.sih_ir_run(self.handle, float(dt), checks), "sih_ir_run")
 
     def ir_unpack_reconstruction(self):

@@ -68,6 +68,7 @@ DEFAULT_CONFIGS = {
     "config_conservation_check": False,
     "config_monotonicity_check": False,
     "config_recover_tracer_means_check": False,
+    "config_recover_tracer_means_check": False,
     "config_nIceLayers": 7,
     "config_nSnowLayers": 1,
     "config_earth_radius": 6371229.0,

@@ -269,6 +269,22 @@ def incremental_remap_block(domain, b, dt, tracersHead, diagnostics=None):
         pp = W[t.parent.tracerName].prod if t.parent is not None else None
         Lp = t.parent.nLayers if t.parent is not None else 1
         calli("ira_mass_tracer_product", nC, t.nLayers, nCat, Lp, pp, tp[t.tracerName], w.prod)
+    # recover_tracer_means :3233-3252 (a debugging option: the reference only logs warnings)
+    if cfg.get("config_recover_tracer_means_check", False):
+        total = 0
+        for t in tracersHead:
+            chain = []
+            p = t
+            while p is not None:
+                chain.insert(0, p)
+                p = p.parent
+            rec = np.zeros((t.nLayers, nCat, nC + 1), order="F")
+            total += _recover_means(nC, M, t.nLayers, nCat, m, ir, chain, W, W[t.tracerName].prod, rec)
+            if diagnostics is not None:
+                diagnostics[t.tracerName + "RecoveredProduct"] = rec
+        b._ir_recover_warnings = total
+        if diagnostics is not None:
+            diagnostics["recoverMeansWarnings"] = total
     sums = {}
     if cfg["config_conservation_check"]:
         for t in tracersHead:
@@ -312,6 +328,24 @@ def call_masks(nC, t, nCat, tp, parent, threshold, mask, maskCell):
     Lp = parent.nLayers if parent is not None else 1
     parr = tp[parent.tracerName] if parent is not None else None
     calli("ira_make_masks", nC, t.nLayers, nCat, Lp, tp[t.tracerName], parr, float(threshold), mask, maskCell)
+
+
+def _recover_means(nC, M, L, nCat, m, ir, chain, W, prod, rec):
+    n = len(chain)
+    Lk = np.array([p.nLayers for p in chain], dtype=np.int32)
+    PtrArr = ctypes.c_void_p * n
+
+    def ptrs(get):
+        return PtrArr(*[get(W[p.tracerName]).ctypes.data for p in chain])
+
+    def vp(a):
+        return ctypes.c_void_p(a.ctypes.data)
+    fn = evp_flow.lib().ira_recover_tracer_means
+    fn.restype = ctypes.c_int
+    return int(fn(ctypes.c_int(nC), ctypes.c_int(M), ctypes.c_int(L), ctypes.c_int(nCat), vp(m["nEdgesOnCell"]),
+                  vp(m["edgesOnCell"]), vp(ir["xVertexOnCell"]), vp(ir["yVertexOnCell"]), vp(m["dcEdge"]),
+                  vp(m["dvEdge"]), ctypes.c_int(n), vp(Lk), ptrs(lambda w: w.center), ptrs(lambda w: w.xGrad),
+                  ptrs(lambda w: w.yGrad), vp(prod), vp(rec)))
 
 
 def _barycenter(nC, L, nCat, geom, maskCell, chain, tp, W, w):

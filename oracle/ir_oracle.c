@@ -1019,6 +1019,65 @@ void ira_zap_tracer(int nCellsSolve, int L, int nCat, const int *maskCategoryCel
                 for (int l = 1; l <= L; l++) array[F3(l, cat, c, L, nCat)] = 0.0;
 }
 
+/* recover_tracer_means :7541-7982 for one tracer (config_recover_tracer_means_check): integrates the product
+ * mass * tracer ... of the reconstructions over each cell, one sub-triangle (centre, vertex i, vertex i+1) per
+ * edge with the 6-point rule, weighted by 0.25 dcEdge dvEdge / sum.  nLev levels, the mass-like field first and
+ * this tracer last; level k has Lk[k] layers.  recovered(L, nCat, nCells+1) receives the integrals; returns the
+ * number of entries for which the reference logs "Reconstructed tracer does not recover the mean". */
+int ira_recover_tracer_means(int nCells, int M, int L, int nCat, const int *nEdgesOnCell, const int *edgesOnCell,
+                             const double *xVOC, const double *yVOC, const double *dcEdge, const double *dvEdge,
+                             int nLev, const int *Lk, const double *const *cen, const double *const *gx,
+                             const double *const *gy, const double *prod, double *recovered)
+{
+    int warnings = 0;
+    for (int c = 1; c <= nCells; c++) {
+        int n = nEdgesOnCell[c - 1];
+        double frac[64], sumArea = 0.0;
+        for (int ie = 1; ie <= n; ie++) {
+            int e = edgesOnCell[I2(ie, c, M)];
+            frac[ie - 1] = 0.25 * dcEdge[e - 1] * dvEdge[e - 1];
+            sumArea = sumArea + frac[ie - 1];
+        }
+        for (int cat = 1; cat <= nCat; cat++)
+            for (int l = 1; l <= L; l++) recovered[F3(l, cat, c, L, nCat)] = 0.0;
+        for (int ie = 1; ie <= n; ie++) {
+            double fr = frac[ie - 1] / sumArea;
+            int ip = ie + 1 > n ? 1 : ie + 1;
+            double x1 = 0.0, y1 = 0.0;
+            double x2 = xVOC[I2(ie, c, M)], y2 = yVOC[I2(ie, c, M)];
+            double x3 = xVOC[I2(ip, c, M)], y3 = yVOC[I2(ip, c, M)];
+            double xq[NQP], yq[NQP], wq[NQP];
+            xq[0] = q1QP * x1 + q1QP * x2 + q2QP * x3;  yq[0] = q1QP * y1 + q1QP * y2 + q2QP * y3;
+            xq[1] = q1QP * x1 + q2QP * x2 + q1QP * x3;  yq[1] = q1QP * y1 + q2QP * y2 + q1QP * y3;
+            xq[2] = q2QP * x1 + q1QP * x2 + q1QP * x3;  yq[2] = q2QP * y1 + q1QP * y2 + q1QP * y3;
+            xq[3] = q3QP * x1 + q4QP * x2 + q4QP * x3;  yq[3] = q3QP * y1 + q4QP * y2 + q4QP * y3;
+            xq[4] = q4QP * x1 + q3QP * x2 + q4QP * x3;  yq[4] = q4QP * y1 + q3QP * y2 + q4QP * y3;
+            xq[5] = q4QP * x1 + q4QP * x2 + q3QP * x3;  yq[5] = q4QP * y1 + q4QP * y2 + q3QP * y3;
+            for (int q = 0; q < NQP; q++) wq[q] = q < 3 ? w1QP : w2QP;
+            for (int cat = 1; cat <= nCat; cat++)
+                for (int l = 1; l <= L; l++) {
+                    double tri = 0.0;
+                    for (int q = 0; q < NQP; q++) {
+                        double v = 1.0; /* the dummy parent of the mass-like field :7619-7626 */
+                        for (int k = 0; k < nLev; k++) {
+                            size_t j = P3(l, cat, c, Lk[k], nCat);
+                            v = (cen[k][j] + gx[k][j] * xq[q] + gy[k][j] * yq[q]) * v;
+                        }
+                        tri = tri + wq[q] * v;
+                    }
+                    recovered[F3(l, cat, c, L, nCat)] = recovered[F3(l, cat, c, L, nCat)] + fr * tri;
+                }
+        }
+        for (int cat = 1; cat <= nCat; cat++)
+            for (int l = 1; l <= L; l++) {
+                double mean = prod[F3(l, cat, c, L, nCat)];
+                double difference = recovered[F3(l, cat, c, L, nCat)] - mean;
+                if (fabs(difference) > eps11 * fabs(mean) && fabs(difference) > eps11) warnings++;
+            }
+    }
+    return warnings;
+}
+
 /* sum_tracers :7998-8111 for one tracer: sums(L, nCat) over the owned cells */
 void ira_sum_tracer(int nCellsSolve, int L, int nCat, const double *areaCell, const double *prod, double *sums)
 {

@@ -433,3 +433,73 @@ def test_flux_kernel_variants_give_the_same_bits(oracle, monkeypatch):
         results.append(dom.blocklist[0].structs["tracers"])
     for n in TRACERS:
         assert np.array_equal(results[0][n], results[1][n]), n
+
+
+@pytest.mark.parametrize("meshname,name,cfg", [
+    ("hex_24_20", None, {"config_dt": 600.0, "config_elastic_subcycle_number": 60}),
+    ("QU480", "QU480", {}),
+])
+def test_recover_tracer_means_check(oracle, meshname, name, cfg):
+    """config_recover_tracer_means_check: the integrals of the reconstructions and the number of entries the
+    reference would warn about are those of the oracle; the check changes nothing in the advection."""
+    cfg = dict(cfg, config_recover_tracer_means_check=True)
+    dom, ref = make_pair(oracle, meshname, name, configs=cfg)
+    try:
+        oracle.seaice_run_velocity_solver(ref)
+        copy_velocity(ref, dom)
+        diag = {}
+        _ir().seaice_run_advection(ref, diagnostics=diag)
+        with pytest.warns(UserWarning) if diag["recoverMeansWarnings"] else _nullcontext():
+            adv.seaice_run_advection(dom)
+        assert dom.solver_state["ir_recover_means_warnings"] == diag["recoverMeansWarnings"]
+        compare_tracers(dom, ref)
+        b = dom.blocklist[0]
+        nC, nCat = b.dimensions["nCells"], b.dimensions["nCategories"]
+        for t in dom.solver_state["tracersHead"]:
+            want = diag[t.tracerName + "RecoveredProduct"][..., :nC].reshape(t.nLayers * nCat, nC, order="F")
+            got = dget(b, t.tracerName + "RecoveredProduct", t.nLayers * nCat, nC)
+            # device planes are (category, layer); the oracle's leading index is (layer, category)
+            got = got.reshape(nCat, t.nLayers, nC).transpose(1, 0, 2).reshape(t.nLayers * nCat, nC, order="F")
+            assert rel_linf(got, want) <= TOL, (t.tracerName, rel_linf(got, want))
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+def test_recover_tracer_means_counts_warnings(oracle):
+    """Enthalpies of 0 between neighbours of +-3e8 J/m3: the products of the means are 0, the integrals of the
+    (steep) reconstructions are roundoff of 1e-8, which the reference reports.  Device and oracle do the same
+    operations in the same order, so they count the same entries."""
+    mesh = get_mesh("hex_12_10")
+    cfg = {"config_dt": 600.0, "config_elastic_subcycle_number": 60, "config_recover_tracer_means_check": True}
+    ref = cases.make_domain(mesh, None, configs=cfg)
+    dom = cases.make_domain(mesh, None, configs=cfg)
+    rng = np.random.default_rng(11)
+    e = ref.blocklist[0].structs["tracers"]["iceEnthalpy"]
+    e[...] = rng.uniform(-3e8, 3e8, e.shape)
+    e[..., rng.uniform(size=e.shape[-1]) < 0.3] = 0.0
+    dom.blocklist[0].structs["tracers"]["iceEnthalpy"][...] = e
+    oracle.seaice_init_velocity_solver(ref)
+    _ir().seaice_init_advection(ref)
+    vs.seaice_mesh_pool_create(dom)
+    try:
+        vs.seaice_init_velocity_solver(dom)
+        adv.seaice_init_advection(dom)
+        oracle.seaice_run_velocity_solver(ref)
+        copy_velocity(ref, dom)
+        for _ in range(2):  # the count starts from zero in every step
+            diag = {}
+            _ir().seaice_run_advection(ref, diagnostics=diag)
+            assert diag["recoverMeansWarnings"] > 0
+            with pytest.warns(UserWarning, match="does not recover the mean"):
+                adv.seaice_run_advection(dom)
+            assert dom.solver_state["ir_recover_means_warnings"] == diag["recoverMeansWarnings"]
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
