@@ -38,3 +38,19 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(lib.SeaiceHipError):
         lib.load()
+
+
+def test_fortran_shims_typecheck():
+    """The MPAS-side shim modules (fortran/shim/*.F) pass flang's semantic analysis against the interface
+    module of the library and declarations of the framework procedures they call."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fc = "/opt/rocm/lib/llvm/bin/amdflang"
+    if not os.path.exists(fc) or shutil.which("make") is None:
+        pytest.skip("amdflang or make not available")
+    r = subprocess.run(["make", "-C", os.path.join(root, "fortran"), "check-shims"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "error" not in r.stderr.lower(), r.stderr[-2000:]
