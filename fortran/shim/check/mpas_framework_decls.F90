@@ -25,9 +25,13 @@ module mpass_derived_types
      type(MPAS_pool_type), pointer :: structs => null(), dimensions => null(), configs => null()
      type(block_type), pointer :: prev => null(), next => null()
   end type block_type
+  type dm_info
+     integer :: nprocs = 1, my_proc_id = 0
+  end type dm_info
   type domain_type
      type(block_type), pointer :: blocklist => null()
      type(MPAS_pool_type), pointer :: configs => null()
+     type(dm_info), pointer :: dminfo => null()
   end type domain_type
 end module mpass_derived_types
 
@@ -173,6 +177,11 @@ contains
     integer, intent(in), optional :: timeLevel
     integer, dimension(:), intent(in), optional :: haloLayers
   end subroutine MPAS_dmpar_field_halo_exch
+  subroutine mpas_dmpar_min_real(dminfo, r, global_min)
+    type(dm_info), intent(in) :: dminfo
+    real(kind=RKIND), intent(in) :: r
+    real(kind=RKIND), intent(out) :: global_min
+  end subroutine mpas_dmpar_min_real
   subroutine exch_r3(field, haloLayersIn)
     type(field3DReal), pointer :: field
     integer, dimension(:), intent(in), optional :: haloLayersIn
