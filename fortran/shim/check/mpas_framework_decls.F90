@@ -182,6 +182,11 @@ contains
     real(kind=RKIND), intent(in) :: r
     real(kind=RKIND), intent(out) :: global_min
   end subroutine mpas_dmpar_min_real
+  subroutine mpas_dmpar_sum_real(dminfo, r, global_sum)
+    type(dm_info), intent(in) :: dminfo
+    real(kind=RKIND), intent(in) :: r
+    real(kind=RKIND), intent(out) :: global_sum
+  end subroutine mpas_dmpar_sum_real
   subroutine exch_r3(field, haloLayersIn)
     type(field3DReal), pointer :: field
     integer, dimension(:), intent(in), optional :: haloLayersIn
