@@ -123,6 +123,20 @@ module seaice_hip_interface
        integer(c_int) :: ierr
      end function sih_evp_set_special_boundaries
 
+     ! several blocks: velocity boundaries after the host's halo update instead of inside the iteration
+     function sih_evp_defer_special_boundaries(ctx, on) bind(C, name="sih_evp_defer_special_boundaries") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: on
+       integer(c_int) :: ierr
+     end function sih_evp_defer_special_boundaries
+
+     function sih_evp_apply_special_boundaries(ctx) bind(C, name="sih_evp_apply_special_boundaries") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int) :: ierr
+     end function sih_evp_apply_special_boundaries
+
      function sih_evp_overlap_setup(ctx) bind(C, name="sih_evp_overlap_setup") result(ierr)
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx

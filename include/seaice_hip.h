@@ -168,6 +168,13 @@ int sih_evp_set_special_boundaries(sih_ctx *ctx, const int32_t *vertexBoundaryTy
                                    const int32_t *vertexBoundarySourceLocal,
                                    const int32_t *solveVelocitySpecialBoundaries,
                                    const int32_t *solveStressSpecialBoundaries);
+/* Several blocks: seaice_set_special_boundaries_velocity follows the halo update that ends an iteration
+ * (velocity_solver.F:2449-2456).  sih_evp_defer_special_boundaries(ctx, 1) takes the application out of
+ * sih_evp_subcycle; the host then exchanges uVelocity, vVelocity after every iteration and calls
+ * sih_evp_apply_special_boundaries.  A marked vertex whose vertexBoundarySourceLocal is 0 (its source is not in
+ * this block) is left as the exchange delivered it. */
+int sih_evp_defer_special_boundaries(sih_ctx *ctx, int on);
+int sih_evp_apply_special_boundaries(sih_ctx *ctx);
 
 /* ---- fields --------------------------------------------------------------------------------- */
 /* Copy a named field host -> device (put) or device -> host (get) in the reference layout.

@@ -40,10 +40,13 @@ def fill_idealised_state(block, time=0.0, open_water_band=None, rotate=True):
         X = (lon + np.pi) / (2.0 * np.pi)
         Y = (lat + 0.5 * np.pi) / np.pi
     else:
-        Lx = mesh["xCell"][:nC].max() - mesh["xCell"][:nC].min() + 1e-30
-        Ly = mesh["yCell"][:nC].max() - mesh["yCell"][:nC].min() + 1e-30
-        X = (mesh["xCell"][:nC] - mesh["xCell"][:nC].min()) / Lx
-        Y = (mesh["yCell"][:nC] - mesh["yCell"][:nC].min()) / Ly
+        # a block of a partitioned planar mesh carries the extent of the whole domain
+        x0, x1, y0, y1 = mesh.get("planarExtent", (mesh["xCell"][:nC].min(), mesh["xCell"][:nC].max(),
+                                                   mesh["yCell"][:nC].min(), mesh["yCell"][:nC].max()))
+        Lx = x1 - x0 + 1e-30
+        Ly = y1 - y0 + 1e-30
+        X = (mesh["xCell"][:nC] - x0) / Lx
+        Y = (mesh["yCell"][:nC] - y0) / Ly
         lon = (X * 2.0 - 1.0) * np.pi
         lat = (Y - 0.5) * np.pi
     area = 0.95 - 0.15 * np.cos(lat) ** 2

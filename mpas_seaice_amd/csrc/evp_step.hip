@@ -1182,7 +1182,33 @@ static void launchVertexKernel(sih_ctx *c, bool last, int subset = -1)
         hipLaunchKernelGGL((k_sub_vertices<true, false>), g, b, 0, c->stream, c->dev, list, nList);
     else
         hipLaunchKernelGGL((k_sub_vertices<false, false>), g, b, 0, c->stream, c->dev, list, nList);
-    applySpecialBoundaryVelocity(c);  // velocity_solver.F:2454-2456
+    if (!c->sbDeferred) applySpecialBoundaryVelocity(c);  // velocity_solver.F:2454-2456
+}
+
+// Several blocks: the reference applies the special boundaries after the halo update that ends an iteration
+// (velocity_solver.F:2449-2456), so the host switches the application inside the iteration off and asks for it
+// after its exchange.
+extern "C" int sih_evp_defer_special_boundaries(sih_ctx *c, int on)
+{
+    int rc = checkInit(c, "sih_evp_defer_special_boundaries");
+    if (rc) return rc;
+    c->sbDeferred = on != 0;
+    if (c->graphExec) {  // a captured graph holds the launches of the other mode
+        (void)hipGraphExecDestroy(c->graphExec);
+        c->graphExec = nullptr;
+        c->graphN = 0;
+    }
+    return SIH_OK;
+}
+
+extern "C" int sih_evp_apply_special_boundaries(sih_ctx *c)
+{
+    int rc = checkInit(c, "sih_evp_apply_special_boundaries");
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    applySpecialBoundaryVelocity(c);
+    HIPCHK(hipGetLastError());
+    return SIH_OK;
 }
 
 extern "C" int sih_evp_subcycle(sih_ctx *c, int n, int last)
@@ -1321,6 +1347,7 @@ extern "C" int sih_evp_set_special_boundaries(sih_ctx *c, const int32_t *type, c
             const int t = type[h];
             if (t == 1 || t == 2) {
                 const int s = source[h];
+                if (s == 0) continue;  // source outside this block: the vertex keeps what the exchange brought
                 if (s < 1 || s > nV) {
                     sih_set_error("sih_evp_set_special_boundaries: vertexBoundarySourceLocal out of range");
                     return SIH_ERR_ARG;

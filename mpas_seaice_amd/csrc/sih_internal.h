@@ -112,6 +112,7 @@ struct sih_ctx {
     int *d_sbIdx = nullptr, *d_sbOrigin = nullptr, *d_sbSign = nullptr, *d_sbMaskV = nullptr, *d_sbMaskC = nullptr;
     double *d_sbTmp = nullptr;
     bool sbVelocity = false, sbMasks = false, sbPending = false;
+    bool sbDeferred = false;  // velocity boundaries applied by sih_evp_apply_special_boundaries, not inside the iteration
     std::map<std::vector<int>, hipGraphExec_t> partGraphs;
     std::map<std::string, HaloTable> haloTables;  // plane-pointer tables of the field groups exchanged so far
     hipGraphExec_t graphExec = nullptr;

@@ -78,6 +78,7 @@ EXPORTS = [
     "sih_fields_put", "sih_fields_get", "sih_evp_overlap_setup", "sih_evp_subcycle_parts",
     "sih_evp_set_special_boundaries", "sih_ir_check_monotonicity", "sih_evp_set_edge_mesh",
     "sih_ir_unpack_reconstruction", "sih_host_alloc", "sih_host_free", "sih_upwind_init", "sih_upwind_prepare", "sih_upwind_advect", "sih_upwind_run", "sih_upwind_get_sums",
+    "sih_evp_defer_special_boundaries", "sih_evp_apply_special_boundaries",
 ]
 
 
@@ -119,6 +120,8 @@ def load():
     lib.sih_evp_subcycle_graph.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.sih_evp_set_special_boundaries.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4
     lib.sih_evp_overlap_setup.argtypes = [ctypes.c_void_p]
+    lib.sih_evp_defer_special_boundaries.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.sih_evp_apply_special_boundaries.argtypes = [ctypes.c_void_p]
     lib.sih_evp_subcycle_parts.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int32),
                                            ctypes.c_int]
     lib.sih_evp_run.argtypes = [ctypes.c_void_p]
@@ -291,6 +294,13 @@ class BlockContext:
             assert a is None or (a.dtype == np.int32 and a.ndim == 1), "int32 vectors expected"
         check(self._lib.sih_evp_set_special_boundaries(self.handle, *[_ptr(a) for a in arrs]),
               "sih_evp_set_special_boundaries")
+
+    def defer_special_boundaries(self, on=True):
+        check(self._lib.sih_evp_defer_special_boundaries(self.handle, int(bool(on))),
+              "sih_evp_defer_special_boundaries")
+
+    def apply_special_boundaries(self):
+        check(self._lib.sih_evp_apply_special_boundaries(self.handle), "sih_evp_apply_special_boundaries")
 
     def overlap_setup(self):
         check(self._lib.sih_evp_overlap_setup(self.handle), "sih_evp_overlap_setup")

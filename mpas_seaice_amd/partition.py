@@ -136,6 +136,9 @@ def partition_mesh(mesh: Mesh, nblocks: int, num_halos: int = 2, cell_owner=None
             m["coeffs_reconstruct"] = np.asfortranarray(mesh["coeffs_reconstruct"][:, :, cells])
         for k in ("xEdge", "yEdge", "zEdge", "latEdge", "lonEdge", "dcEdge", "dvEdge", "fEdge"):
             m[k] = np.ascontiguousarray(mesh[k][edges])
+        if not mesh["on_a_sphere"]:  # extent of the whole planar domain, for test cases defined on it
+            m["planarExtent"] = (float(mesh["xCell"].min()), float(mesh["xCell"].max()),
+                                 float(mesh["yCell"].min()), float(mesh["yCell"].max()))
         m["indexToCellID"] = (cells + 1).astype(np.int32)
         m["indexToVertexID"] = (verts + 1).astype(np.int32)
         meshes.append(m)

@@ -110,6 +110,8 @@ class Block:
             return np.zeros(tuple(lead) + (nV + 1,), dtype=np.int32, order="F")
 
         meshp = {"on_a_sphere": mesh["on_a_sphere"], "sphere_radius": mesh["sphere_radius"]}
+        if "planarExtent" in mesh:  # block of a partitioned planar mesh (test cases are defined on the whole domain)
+            meshp["planarExtent"] = mesh["planarExtent"]
 
         def pad1(a, fill):
             out = np.full(a.shape[:-1] + (a.shape[-1] + 1,), fill, dtype=a.dtype, order="F")

@@ -19,12 +19,14 @@ def seaice_init_special_boundaries(domain):
     cfg = domain.configs
     use_vel = bool(cfg["config_use_special_boundaries_velocity"])
     use_masks = bool(cfg["config_use_special_boundaries_velocity_masks"])
-    if use_vel and getattr(domain, "comm", None) is not None and any(
-            getattr(b, "ctx", None) is not None for b in domain.blocklist):
-        # the reference applies them after the halo update of every iteration; the library applies them right
-        # after its vertex loop, which is the same thing only when no halo update lies in between
+    several = use_vel and getattr(domain, "comm", None) is not None and any(
+        getattr(b, "ctx", None) is not None for b in domain.blocklist)
+    if several and (int(cfg.get("config_halo_exchange_interval", 1)) != 1
+                    or cfg.get("config_overlap_halo_exchange", False)):
+        # the reference applies them after the halo update that ends every iteration (velocity_solver.F:2449-2456)
         from .lib import SeaiceHipError
-        raise SeaiceHipError("special velocity boundaries are implemented for single-block domains only")
+        raise SeaiceHipError("special velocity boundaries on several blocks need one plain halo exchange per "
+                             "subcycle (config_halo_exchange_interval = 1, no overlap)")
     if bool(cfg.get("config_use_special_boundaries_tracers", False)):  # init_special_boundaries_tracers, :169-239
         for b in domain.blocklist:
             sb = b.structs["special_boundaries"]
@@ -45,7 +47,10 @@ def seaice_init_special_boundaries(domain):
             typ = sb["vertexBoundaryType"][:nV]
             marked = typ != VELOCITY_BOUNDARY_NONE
             src = sb["vertexBoundarySource"][:nV]
-            sb["vertexBoundarySourceLocal"][:nV][marked] = g2l[np.clip(src[marked], 0, g2l.size - 1)]
+            # a source that is not in this block maps to 0: only an outermost halo vertex can have one when the
+            # sources are neighbours, and the library leaves such a vertex as the exchange delivered it
+            inside = (src[marked] >= 0) & (src[marked] < g2l.size)
+            sb["vertexBoundarySourceLocal"][:nV][marked] = np.where(inside, g2l[np.clip(src[marked], 0, g2l.size - 1)], 0)
         ctx = getattr(b, "ctx", None)
         if ctx is not None and (use_vel or use_masks):
             nC = b.dimensions["nCells"]
@@ -54,6 +59,8 @@ def seaice_init_special_boundaries(domain):
                 np.ascontiguousarray(sb["vertexBoundarySourceLocal"][:nV]) if use_vel else None,
                 np.ascontiguousarray(sb["solveVelocitySpecialBoundaries"][:nV]) if use_masks else None,
                 np.ascontiguousarray(sb["solveStressSpecialBoundaries"][:nC]) if use_masks else None)
+            if several:
+                ctx.defer_special_boundaries(True)
 
 
 def seaice_set_special_boundaries_tracers(domain):

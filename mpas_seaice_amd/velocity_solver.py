@@ -289,6 +289,7 @@ def subcycle_velocity_solver(domain, clock=None):
             b.ctx.subcycle(1, last=True)
         comm.halo_exchange(domain, names)
         return
+    sb = bool(domain.configs["config_use_special_boundaries_velocity"])
     done = 0
     while done < n:
         m = min(k, n - done)
@@ -296,6 +297,9 @@ def subcycle_velocity_solver(domain, clock=None):
             b.ctx.subcycle(m, last=(done + m == n))
         done += m
         comm.halo_exchange(domain, names)
+        if sb:  # seaice_set_special_boundaries_velocity after the halo update, velocity_solver.F:2449-2456
+            for b in domain.blocklist:
+                b.ctx.apply_special_boundaries()
 
 
 def subcycle_overlapped(domain, comm, n, k, names, use_graph=False):

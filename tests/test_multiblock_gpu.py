@@ -166,3 +166,72 @@ def test_strain_averaging_on_three_blocks_follows_the_reference_per_block_loop(o
         r = parallel.gather_global(ref.blocklist, rhalos, pool, name, n, loc).astype(np.float64)
         err = np.abs(g - r).max() / max(np.abs(r).max(), 1e-300)
         assert err <= TOL, (name, err)
+
+
+def test_special_velocity_boundaries_on_three_blocks(oracle):
+    """seaice_set_special_boundaries_velocity follows the halo update of every iteration
+    (velocity_solver.F:2449-2456): on several blocks the library's application inside the iteration is switched
+    off and the host calls it after its exchange.  Sources are neighbouring vertices, so every vertex that
+    matters finds its source in its block; the result is the single-block oracle's."""
+    mesh = get_mesh("hex_24_20")
+    nV, nC = mesh.nVertices, mesh.nCells
+    cov = mesh["cellsOnVertex"]
+    rim = (cov > nC).any(axis=0)
+    voe = mesh["verticesOnEdge"] - 1
+    typ_g = np.zeros(nV, dtype=np.int32)
+    src_g = np.zeros(nV, dtype=np.int32)
+    typ_g[rim] = 3
+    rng = np.random.default_rng(3)
+    inner = np.flatnonzero(~rim)
+    picked = set()
+    for k, v in enumerate(rng.choice(inner, size=50, replace=False)):
+        nbs = [int(b if a == v else a) for a, b in voe.T if a == v or b == v]
+        nbs = [w for w in nbs if not rim[w] and w not in picked and typ_g[w] == 0]
+        if not nbs or any(src_g[w] == v + 1 for w in range(nV) if typ_g[w] in (1, 2)):
+            continue
+        typ_g[v] = 1 if k % 2 == 0 else 2
+        src_g[v] = nbs[0] + 1
+        picked.add(v)
+        picked.add(nbs[0])        # a source is never marked itself: no chains, whose order would be per block
+    assert (typ_g == 1).sum() > 5 and (typ_g == 2).sum() > 5
+    mv_g = np.where(rim, 0, 1).astype(np.int32)
+    mc_g = np.ones(nC, dtype=np.int32)
+    mc_g[::17] = 0
+    cfg = {"config_elastic_subcycle_number": 20, "config_dt": 600.0, "config_use_special_boundaries_velocity": True,
+           "config_use_special_boundaries_velocity_masks": True}
+
+    def mark(b, gv, gc):
+        sb = b.structs["special_boundaries"]
+        n_v, n_c = b.dimensions["nVertices"], b.dimensions["nCells"]
+        sb["vertexBoundaryType"][:n_v] = typ_g[gv]
+        sb["vertexBoundarySource"][:n_v] = src_g[gv]
+        sb["solveVelocitySpecialBoundaries"][:n_v] = mv_g[gv]
+        sb["solveStressSpecialBoundaries"][:n_c] = mc_g[gc]
+
+    ref = cases.make_domain(mesh, None, configs=cfg, open_water_band=None)
+    mark(ref.blocklist[0], np.arange(nV), np.arange(nC))
+    oracle.seaice_init_velocity_solver(ref)
+    oracle.seaice_run_velocity_solver(ref)
+    dom, halos, _ = parallel.make_partitioned_domain(mesh, None, 3, configs=cfg, open_water_band=None)
+    for b, h in zip(dom.blocklist, halos):
+        mark(b, h.globalID["vertex"], h.globalID["cell"])
+    vs.seaice_mesh_pool_create(dom, device=0)
+    try:
+        dom.comm = parallel.LocalComm(dom, halos, 3)
+        vs.seaice_init_velocity_solver(dom)
+        vs.seaice_run_velocity_solver(dom)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+    u = ref.blocklist[0].structs["velocity_solver"]["uVelocity"][:nV]
+    assert np.abs(u).max() > 0 and np.all(u[typ_g == 3] == 0.0)
+    sel = np.flatnonzero(typ_g == 2)
+    assert np.abs(u[sel]).max() > 0 and np.allclose(u[sel], -u[src_g[sel] - 1], rtol=0, atol=0)
+    for pool, name, loc, n in (("velocity_solver", "uVelocity", "vertex", nV),
+                               ("velocity_solver", "vVelocity", "vertex", nV),
+                               ("velocity_variational", "stress11", "cell", nC),
+                               ("velocity_variational", "stress12", "cell", nC),
+                               ("velocity_solver", "solveVelocity", "vertex", nV)):
+        g = parallel.gather_global(dom.blocklist, halos, pool, name, n, loc).astype(np.float64)
+        r = ref.blocklist[0].structs[pool][name][..., :n].astype(np.float64)
+        err = np.abs(g - r).max() / max(np.abs(r).max(), 1e-300)
+        assert err <= TOL, (name, err)
