@@ -379,7 +379,8 @@ int sih_upwind_get_sums(sih_ctx *ctx, const char *tracer, double *initSums, doub
 
 /* introspection for tests and reports.  Keys: sparseGradient, splitCellKernel, dampingTimescale,
  * elasticTimeStep, dynamicsTimeStep, numericalInertiaCoefficient, padC, padV, minDvEdge, and
- * irRecoverMeansWarnings (see sih_ir_run), irCflWarnings: number of vertices whose departure distance in the last sih_ir_run exceeded the
+ * irRecoverMeansWarnings (see sih_ir_run), irFluxWalk (1 when the flux kernel that walks the tracer tree is in use:
+ * every tracer with children has one layer and there are at most 32 layer fields), irCflWarnings: number of vertices whose departure distance in the last sih_ir_run exceeded the
  * shortest adjacent edge (the reference logs "Potential CFL violation in IR advection" and continues,
  * incremental_remap.F:5330-5345). */
 int sih_get_info(sih_ctx *ctx, const char *key, double *value);

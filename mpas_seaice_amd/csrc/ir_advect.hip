@@ -93,7 +93,12 @@ struct sih_ir_state {
     IrTabEntry *d_tab = nullptr;
     struct IrPlane *d_planes = nullptr;
     int nPlanes = 0;
-    int fluxMode = 1;  // 1: one thread per (edge, plane); 0: one thread per (edge, category)
+    // 2: one thread per (edge, category) walking the tracer tree (needs walkOk); 1: one thread per (edge, plane);
+    // 0: one thread per (edge, category), every tracer from scratch
+    int fluxMode = 2;
+    struct IrStep *d_steps = nullptr;
+    int nSteps = 0, nSlots = 0;
+    bool walkOk = false;
     double *d_sums = nullptr;
     int iVol = -1, iSnow = -1;
     int cflWarnings = 0;
@@ -108,6 +113,7 @@ void sih_ir_destroy(sih_ctx *c)
     if (!c->ir) return;
     if (c->ir->d_tab) (void)hipFree(c->ir->d_tab);
     if (c->ir->d_planes) (void)hipFree(c->ir->d_planes);
+    if (c->ir->d_steps) (void)hipFree(c->ir->d_steps);
     if (c->ir->d_sums) (void)hipFree(c->ir->d_sums);
     for (hipEvent_t e : c->ir->ev)
         if (e) (void)hipEventDestroy(e);
@@ -1122,6 +1128,100 @@ __global__ void __launch_bounds__(256) k_ir_flux_planes(IrDev d, const IrTabEntr
         if (ly < nl) T.flux[(size_t)(cat * T.L + layer0 + ly) * pe + e] = flux[ly];
 }
 
+// The same fluxes with one thread per (edge, category) that walks the tracer tree depth first, triangle by
+// triangle: the quadrature points of a triangle are formed once, and the value of every tracer with children
+// at those points is kept (one set of six per level of the tree) for its children to multiply on, as the
+// reference keeps triangleValue for them (:6820-6900) - here in registers instead of memory.  A tracer with
+// children must have one layer for that.  The partial sums of all fluxes sit in LDS, one row of 256 per
+// layer field; each is still the sum over triangles, in their order, of area * (sum over quadrature points).
+struct IrStep {
+    int ti, level, keep, slot;  // tracer, depth in the tree, has children, first row of its fluxes in LDS
+};
+#define IR_WALK_MAXSLOTS 32
+
+__global__ void __launch_bounds__(256) k_ir_flux_walk(IrDev d, const IrTabEntry *__restrict__ tab,
+                                                      const IrStep *__restrict__ steps, int nSteps, int nSlots)
+{
+    extern __shared__ double fl[];  // [nSlots][256]
+    unsigned eb, ucat;
+    if (!xcdTile((d.nEdges + 255u) / 256u, (unsigned)d.nCat, eb, ucat)) return;
+    const int tid = threadIdx.x;
+    const int e = eb * blockDim.x + tid;
+    const int cat = (int)ucat;
+    const size_t pe = d.padE, pc = d.padC;
+    for (int sl = 0; sl < nSlots; sl++) fl[sl * 256 + tid] = 0.0;
+    const int cnt = e < d.nEdges ? d.triCount[e] : 0;
+    for (int t = 0; t < cnt; t++) {
+        const double area = d.triArea[(size_t)t * pe + e];
+        if (area == 0.0) continue;
+        const int c = d.triCell[(size_t)t * pe + e];
+        const double x1 = d.xTri[(size_t)(t * 3) * pe + e], x2 = d.xTri[(size_t)(t * 3 + 1) * pe + e],
+                     x3 = d.xTri[(size_t)(t * 3 + 2) * pe + e];
+        const double y1 = d.yTri[(size_t)(t * 3) * pe + e], y2 = d.yTri[(size_t)(t * 3 + 1) * pe + e],
+                     y3 = d.yTri[(size_t)(t * 3 + 2) * pe + e];
+        double xq[6], yq[6];  // get_triangle_quadrature_points :6605-6644
+        xq[0] = Q1QP * x1 + Q1QP * x2 + Q2QP * x3;  yq[0] = Q1QP * y1 + Q1QP * y2 + Q2QP * y3;
+        xq[1] = Q1QP * x1 + Q2QP * x2 + Q1QP * x3;  yq[1] = Q1QP * y1 + Q2QP * y2 + Q1QP * y3;
+        xq[2] = Q2QP * x1 + Q1QP * x2 + Q1QP * x3;  yq[2] = Q2QP * y1 + Q1QP * y2 + Q1QP * y3;
+        xq[3] = Q3QP * x1 + Q4QP * x2 + Q4QP * x3;  yq[3] = Q3QP * y1 + Q4QP * y2 + Q4QP * y3;
+        xq[4] = Q4QP * x1 + Q3QP * x2 + Q4QP * x3;  yq[4] = Q4QP * y1 + Q3QP * y2 + Q4QP * y3;
+        xq[5] = Q4QP * x1 + Q4QP * x2 + Q3QP * x3;  yq[5] = Q4QP * y1 + Q4QP * y2 + Q3QP * y3;
+        double lv0[6], lv1[6], lv2[6];  // values of the current ancestors at the quadrature points, by level
+#pragma unroll
+        for (int q = 0; q < 6; q++) lv0[q] = lv1[q] = lv2[q] = 1.0;
+        for (int si = 0; si < nSteps; si++) {
+            const IrStep S = steps[si];  // the same for every lane
+            const IrTabEntry T = tab[S.ti];
+            const double *rec = T.rec + IR_REC(T, cat, pc, c, 0);
+            for (int ly = 0; ly < T.L; ly++) {
+                const double cj = rec[ly * 3], gxj = rec[ly * 3 + 1], gyj = rec[ly * 3 + 2];
+                double val[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) val[q] = cj + gxj * xq[q] + gyj * yq[q];
+                if (S.level == 1) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) val[q] = lv0[q] * val[q];
+                } else if (S.level == 2) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) val[q] = lv1[q] * val[q];
+                } else if (S.level == 3) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) val[q] = lv2[q] * val[q];
+                }
+                if (S.ti == 0) {  // "IR negative reconstructed ice area", :6903-6951
+                    bool neg = false;
+#pragma unroll
+                    for (int q = 0; q < 6; q++) neg = neg || (val[q] < 0.0);
+                    if (neg) atomicOr(d.flag, FLAG_NEGAREA);
+                }
+                double integral = 0.0;
+#pragma unroll
+                for (int q = 0; q < 6; q++) integral = integral + (q < 3 ? W1QP : W2QP) * val[q];
+                double *f = fl + (S.slot + ly) * 256 + tid;
+                *f = *f + area * integral;
+                if (S.keep) {  // one layer (checked when the steps were made)
+                    if (S.level == 0) {
+#pragma unroll
+                        for (int q = 0; q < 6; q++) lv0[q] = val[q];
+                    } else if (S.level == 1) {
+#pragma unroll
+                        for (int q = 0; q < 6; q++) lv1[q] = val[q];
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 6; q++) lv2[q] = val[q];
+                    }
+                }
+            }
+        }
+    }
+    if (e >= d.nEdges) return;
+    for (int si = 0; si < nSteps; si++) {
+        const IrStep S = steps[si];
+        const IrTabEntry T = tab[S.ti];
+        for (int ly = 0; ly < T.L; ly++) T.flux[(size_t)(cat * T.L + ly) * pe + e] = fl[(S.slot + ly) * 256 + tid];
+    }
+}
+
 // update_mass_and_tracers :7125-7523, all tracers of one (owned cell, category), followed by
 // zap_small_mass :8764-8886 for that cell and category
 template <int M>
@@ -1643,8 +1743,32 @@ extern "C" int sih_ir_set_tracers(sih_ctx *c, int nTracers, const char *const *n
         HIPCHK(hipMalloc((void **)&ir->d_planes, sizeof(IrPlane) * pls.size()));
         HIPCHK(hipMemcpy(ir->d_planes, pls.data(), sizeof(IrPlane) * pls.size(), hipMemcpyHostToDevice));
         ir->nPlanes = (int)pls.size();
+        // the tracer tree depth first, siblings in list order (for k_ir_flux_walk)
+        std::vector<IrStep> steps;
+        int slots = 0;
+        bool ok = true;
+        std::vector<std::pair<int, int>> stack;  // (tracer, level), visited last-in first-out
+        for (int i = nTracers - 1; i >= 0; i--)
+            if (list[i].parent < 0) stack.push_back({i, 0});
+        while (!stack.empty()) {
+            const int i = stack.back().first, lev = stack.back().second;
+            stack.pop_back();
+            if (lev > 3 || (list[i].hasChild && (list[i].L != 1 || lev > 2))) ok = false;
+            steps.push_back(IrStep{i, lev, list[i].hasChild ? 1 : 0, slots});
+            slots += list[i].L;
+            for (int j = nTracers - 1; j >= 0; j--)
+                if (list[j].parent == i) stack.push_back({j, lev + 1});
+        }
+        if ((int)steps.size() != nTracers || slots > IR_WALK_MAXSLOTS || steps.empty() || steps[0].ti != 0) ok = false;
+        if (ir->d_steps) HIPCHK(hipFree(ir->d_steps));
+        ir->d_steps = nullptr;
+        HIPCHK(hipMalloc((void **)&ir->d_steps, sizeof(IrStep) * steps.size()));
+        HIPCHK(hipMemcpy(ir->d_steps, steps.data(), sizeof(IrStep) * steps.size(), hipMemcpyHostToDevice));
+        ir->nSteps = (int)steps.size();
+        ir->nSlots = slots;
+        ir->walkOk = ok;
         const char *fm = getenv("SIH_IR_FLUX_MODE");
-        if (fm) ir->fluxMode = atoi(fm);
+        ir->fluxMode = fm ? atoi(fm) : 2;
     }
     if (ir->d_sums) HIPCHK(hipFree(ir->d_sums));
     HIPCHK(hipMalloc((void **)&ir->d_sums, sizeof(double) * maxLead));
@@ -1795,7 +1919,10 @@ static int irRun(sih_ctx *c, double dt, int checks, bool timed, double *totalMs,
     hipLaunchKernelGGL(k_ir_departure_points, dim3(gV), blk, 0, s, d, dt);
     hipLaunchKernelGGL(k_ir_triangles, dim3((d.nEdges + 127) / 128), dim3(128), 0, s, d);
     mark(3);
-    if (ir->fluxMode == 1)
+    if (ir->fluxMode == 2 && ir->walkOk)
+        hipLaunchKernelGGL(k_ir_flux_walk, dim3(xcdGrid(gE, d.nCat)), blk, sizeof(double) * 256 * ir->nSlots, s, d,
+                           ir->d_tab, ir->d_steps, ir->nSteps, ir->nSlots);
+    else if (ir->fluxMode >= 1)
         hipLaunchKernelGGL(k_ir_flux_planes, dim3(xcdGrid(gE, ir->nPlanes)), blk, 0, s, d, ir->d_tab, ir->d_planes,
                            ir->nPlanes);
     else
@@ -1973,3 +2100,4 @@ extern "C" int sih_ir_get_sums(sih_ctx *c, const char *tracer, double *initSums,
 
 int sih_ir_cfl_warnings(sih_ctx *c) { return c && c->ir ? c->ir->cflWarnings : 0; }
 int sih_ir_recover_warnings(sih_ctx *c) { return c && c->ir ? c->ir->recoverWarnings : 0; }
+int sih_ir_flux_walk(sih_ctx *c) { return c && c->ir && c->ir->fluxMode == 2 && c->ir->walkOk ? 1 : 0; }

@@ -945,6 +945,7 @@ extern "C" int sih_get_info(sih_ctx *c, const char *key, double *value)
     else if (k == "minDvEdge") *value = c->minDvEdge;
     else if (k == "irCflWarnings") *value = sih_ir_cfl_warnings(c);
     else if (k == "irRecoverMeansWarnings") *value = sih_ir_recover_warnings(c);
+    else if (k == "irFluxWalk") *value = sih_ir_flux_walk(c);
     else if (k == "splitCellKernel") *value = c->splitCells ? 1.0 : 0.0;
     else {
         sih_set_error("sih_get_info: unknown key " + k);

@@ -137,6 +137,7 @@ void sih_weak_launch_hybrid_strain(sih_ctx *c);
 void sih_weak_launch_post(sih_ctx *c);
 int sih_ir_cfl_warnings(sih_ctx *c);
 int sih_ir_recover_warnings(sih_ctx *c);
+int sih_ir_flux_walk(sih_ctx *c);
 int sih_hip_fail(hipError_t e, const char *what, const char *file, int line);
 #define HIPCHK(x)                                                             \
     do {                                                                      \

@@ -325,7 +325,7 @@ def test_more_layers_than_one_chunk(oracle):
         vs.seaice_mesh_pool_destroy(dom)
 
 
-def _add_optional_tracers(dom, seed=7):
+def _add_optional_tracers(dom, seed=7, vertical=True):
     """Optional tracers of the reference's list, three parents deep, with and without layers."""
     rng = np.random.Generator(np.random.PCG64(seed))
     for b in dom.blocklist:
@@ -342,9 +342,10 @@ def _add_optional_tracers(dom, seed=7):
         tr["pondArea"] = field(1, 0.0, 0.5)            # child of levelIceArea with config_use_level_meltponds
         tr["pondDepth"] = field(1, 0.0, 0.3)           # three parents: pondArea, levelIceArea, iceAreaCategory
         tr["brineFraction"] = field(1, 0.5, 1.0)
-        tr["verticalNitrateIce"] = field(8, 0.0, 5.0)  # layers under a parent without layers, three parents
-        tr["verticalNitrateSnow"] = field(2, 0.0, 5.0)
-        tr["snowScatteringAerosol"] = field(2, 0.0, 1.0e-6)
+        if vertical:
+            tr["verticalNitrateIce"] = field(8, 0.0, 5.0)  # layers under a parent without layers, three parents
+            tr["verticalNitrateSnow"] = field(2, 0.0, 5.0)
+            tr["snowScatteringAerosol"] = field(2, 0.0, 1.0e-6)
 
 
 def test_optional_tracers_three_parents_deep(oracle):
@@ -413,26 +414,38 @@ def test_timestep_dynamics_loop(oracle, with_column):
         vs.seaice_mesh_pool_destroy(dom)
 
 
-def test_flux_kernel_variants_give_the_same_bits(oracle, monkeypatch):
-    """SIH_IR_FLUX_MODE=0 selects the flux kernel with one thread per (edge, category); the default has one per
-    (edge, tracer plane group).  Same sums in the same order."""
+@pytest.mark.parametrize("optional", [False, True])
+def test_flux_kernel_variants_give_the_same_bits(oracle, monkeypatch, optional):
+    """SIH_IR_FLUX_MODE: 2 (default) one thread per (edge, category) walking the tracer tree with the ancestors'
+    values at the quadrature points kept, 1 one thread per (edge, tracer plane group), 0 one thread per (edge,
+    category) with every tracer from scratch.  Same sums in the same order.  With the optional tracers the tree
+    is three parents deep and has siblings with children on two levels."""
     results = []
-    for mode in ("1", "0"):
+    cfg = {"config_dt": 1800.0, "config_elastic_subcycle_number": 20}
+    if optional:
+        cfg["config_use_level_meltponds"] = True
+    names = None
+    for mode in ("2", "1", "0"):
         monkeypatch.setenv("SIH_IR_FLUX_MODE", mode)
-        dom = cases.make_domain(get_mesh("var12"), None, configs={"config_dt": 1800.0,
-                                                                  "config_elastic_subcycle_number": 20},
-                                open_water_band=(-0.2, 0.3))
+        dom = cases.make_domain(get_mesh("var12"), None, configs=cfg, open_water_band=(-0.2, 0.3))
+        if optional:
+            _add_optional_tracers(dom, vertical=False)
         vs.seaice_mesh_pool_create(dom)
         try:
             vs.seaice_init_velocity_solver(dom)
             adv.seaice_init_advection(dom)
+            if mode == "2":
+                assert dom.blocklist[0].ctx.info("irFluxWalk") == 1.0
             vs.seaice_run_velocity_solver(dom)
             adv.seaice_run_advection(dom)
+            names = [t.tracerName for t in dom.solver_state["tracersHead"]]
         finally:
             vs.seaice_mesh_pool_destroy(dom)
         results.append(dom.blocklist[0].structs["tracers"])
-    for n in TRACERS:
+    assert len(names) == (13 if optional else 7)
+    for n in names:
         assert np.array_equal(results[0][n], results[1][n]), n
+        assert np.array_equal(results[0][n], results[2][n]), n
 
 
 @pytest.mark.parametrize("meshname,name,cfg", [
