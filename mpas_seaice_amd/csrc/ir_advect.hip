@@ -1139,6 +1139,38 @@ struct IrStep {
 };
 #define IR_WALK_MAXSLOTS 32
 
+// one tracer (all its layers) on one triangle: value at the quadrature points times the parent's (level > 0),
+// the integral added to the tracer's rows in LDS, the values left for the children if it has any
+template <int LEVEL>
+__device__ __forceinline__ void irWalkStep(const IrDev &d, const double *__restrict__ rec, int L, double *f, double area,
+                                           const double (&xq)[6], const double (&yq)[6], const double (&par)[6],
+                                           double (&own)[6], bool keep, bool first)
+{
+    for (int ly = 0; ly < L; ly++) {
+        const double cj = rec[ly * 3], gxj = rec[ly * 3 + 1], gyj = rec[ly * 3 + 2];
+        double val[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            val[q] = cj + gxj * xq[q] + gyj * yq[q];
+            if (LEVEL > 0) val[q] = par[q] * val[q];
+        }
+        if (first) {  // "IR negative reconstructed ice area", :6903-6951
+            bool neg = false;
+#pragma unroll
+            for (int q = 0; q < 6; q++) neg = neg || (val[q] < 0.0);
+            if (neg) atomicOr(d.flag, FLAG_NEGAREA);
+        }
+        double integral = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) integral = integral + (q < 3 ? W1QP : W2QP) * val[q];
+        f[ly * 256] = f[ly * 256] + area * integral;
+        if (LEVEL < 3 && keep) {  // one layer (checked when the steps were made)
+#pragma unroll
+            for (int q = 0; q < 6; q++) own[q] = val[q];
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_ir_flux_walk(IrDev d, const IrTabEntry *__restrict__ tab,
                                                       const IrStep *__restrict__ steps, int nSteps, int nSlots)
 {
@@ -1170,47 +1202,23 @@ __global__ void __launch_bounds__(256) k_ir_flux_walk(IrDev d, const IrTabEntry 
 #pragma unroll
         for (int q = 0; q < 6; q++) lv0[q] = lv1[q] = lv2[q] = 1.0;
         for (int si = 0; si < nSteps; si++) {
-            const IrStep S = steps[si];  // the same for every lane
+            const IrStep S = steps[si];  // the same for every lane: the branches below are scalar
             const IrTabEntry T = tab[S.ti];
             const double *rec = T.rec + IR_REC(T, cat, pc, c, 0);
-            for (int ly = 0; ly < T.L; ly++) {
-                const double cj = rec[ly * 3], gxj = rec[ly * 3 + 1], gyj = rec[ly * 3 + 2];
-                double val[6];
-#pragma unroll
-                for (int q = 0; q < 6; q++) val[q] = cj + gxj * xq[q] + gyj * yq[q];
-                if (S.level == 1) {
-#pragma unroll
-                    for (int q = 0; q < 6; q++) val[q] = lv0[q] * val[q];
-                } else if (S.level == 2) {
-#pragma unroll
-                    for (int q = 0; q < 6; q++) val[q] = lv1[q] * val[q];
-                } else if (S.level == 3) {
-#pragma unroll
-                    for (int q = 0; q < 6; q++) val[q] = lv2[q] * val[q];
-                }
-                if (S.ti == 0) {  // "IR negative reconstructed ice area", :6903-6951
-                    bool neg = false;
-#pragma unroll
-                    for (int q = 0; q < 6; q++) neg = neg || (val[q] < 0.0);
-                    if (neg) atomicOr(d.flag, FLAG_NEGAREA);
-                }
-                double integral = 0.0;
-#pragma unroll
-                for (int q = 0; q < 6; q++) integral = integral + (q < 3 ? W1QP : W2QP) * val[q];
-                double *f = fl + (S.slot + ly) * 256 + tid;
-                *f = *f + area * integral;
-                if (S.keep) {  // one layer (checked when the steps were made)
-                    if (S.level == 0) {
-#pragma unroll
-                        for (int q = 0; q < 6; q++) lv0[q] = val[q];
-                    } else if (S.level == 1) {
-#pragma unroll
-                        for (int q = 0; q < 6; q++) lv1[q] = val[q];
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 6; q++) lv2[q] = val[q];
-                    }
-                }
+            double *f = fl + S.slot * 256 + tid;
+            const bool first = S.ti == 0;
+            switch (S.level) {
+            case 0:
+                irWalkStep<0>(d, rec, T.L, f, area, xq, yq, lv0, lv0, S.keep != 0, first);
+                break;
+            case 1:
+                irWalkStep<1>(d, rec, T.L, f, area, xq, yq, lv0, lv1, S.keep != 0, first);
+                break;
+            case 2:
+                irWalkStep<2>(d, rec, T.L, f, area, xq, yq, lv1, lv2, S.keep != 0, first);
+                break;
+            default:
+                irWalkStep<3>(d, rec, T.L, f, area, xq, yq, lv2, lv2, false, first);
             }
         }
     }
