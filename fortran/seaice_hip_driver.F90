@@ -20,6 +20,8 @@ program seaice_hip_driver
   integer(c_int32_t) :: nCells, nVertices, nEdges, maxEdges, nCategories, nSubcycles, onASphere, vertexDegree
   integer(c_int32_t) :: nIceLayers, nSnowLayers
   real(kind=RKIND) :: sphereRadius, config_dt
+  real(c_double) :: infoValue
+  real(kind=RKIND), dimension(:), allocatable, target :: sumsInit, sumsFinal
 
   ! mesh pool
   integer(c_int32_t), dimension(:), allocatable, target :: nEdgesOnCell
@@ -196,7 +198,20 @@ program seaice_hip_driver
   call put_r3("iceEnthalpy", iceEnthalpy)
   call put_r3("iceSalinity", iceSalinity)
   call put_r3("snowEnthalpy", snowEnthalpy)
-  call check(sih_ir_run(ctx, config_dt, 0_c_int), "sih_ir_run")
+  ! all three run-time checks of the remap: conservation (sums fetched below), monotonicity, recovered means
+  call check(sih_ir_run(ctx, config_dt, 7_c_int), "sih_ir_run")
+  call check(sih_ir_check_monotonicity(ctx), "sih_ir_check_monotonicity")
+  call check(sih_get_info(ctx, "irRecoverMeansWarnings"//c_null_char, infoValue), "sih_get_info")
+  if (infoValue /= 0.0_c_double) then
+     write(*,*) "recover-means warnings: ", infoValue
+     stop 1
+  endif
+  allocate(sumsInit(nCategories), sumsFinal(nCategories))
+  call check(sih_ir_get_sums(ctx, "iceAreaCategory"//c_null_char, c_loc(sumsInit), c_loc(sumsFinal)), "sih_ir_get_sums")
+  if (any(abs(sumsFinal - sumsInit) > 1.0e-11_RKIND * abs(sumsInit))) then
+     write(*,*) "ice area not conserved: ", sumsInit, sumsFinal
+     stop 1
+  endif
   call get_r3("iceAreaCategory", iceAreaCategory)
   call get_r3("iceVolumeCategory", iceVolumeCategory)
   call get_r3("snowVolumeCategory", snowVolumeCategory)
