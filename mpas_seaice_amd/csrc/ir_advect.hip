@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(256) k_ir_reconstruct(IrDev d, const IrTabEntr
     const int n = d.nEdgesOnCell[c];
     int nb[M];
     double rdc[M], cf0[M], cf1[M], cf2[M], xv[M], yv[M];
-    unsigned plus = 0;
+    unsigned plus = 0, valid = 0;  // per edge slot: the cell is the edge's first cell; the slot has a neighbour cell
     double t11 = 0, t12 = 0, t13 = 0, t21 = 0, t22 = 0, t23 = 0;
     if (ice) {
 #pragma unroll
@@ -613,6 +613,7 @@ __global__ void __launch_bounds__(256) k_ir_reconstruct(IrDev d, const IrTabEntr
             cf0[ie] = cf1[ie] = cf2[ie] = xv[ie] = yv[ie] = 0.0;
             if (ie < n) {
                 nb[ie] = d.coc[(size_t)ie * pc + c];
+                if (nb[ie] < d.nCells) valid |= 1u << ie;
                 int e = d.eoc[(size_t)ie * pc + c];
                 rdc[ie] = d.dcEdge[e];
                 if (c == d.coe[e]) plus |= 1u << ie;
@@ -678,27 +679,23 @@ __global__ void __launch_bounds__(256) k_ir_reconstruct(IrDev d, const IrTabEntr
             if (ice) {
                 const bool mc = !hasParent ? true : (sharedMask ? mcS : (P->val[lp + c] > EPS11));
                 double g0 = 0.0, g1 = 0.0, g2 = 0.0, mx = f, mn = f;
+                // No branches per neighbour: a slot without a neighbour (past the cell's last edge, or a boundary)
+                // reads the cell itself, counts as masked out and adds +0 to sums that cannot be -0.
 #pragma unroll
                 for (int ie = 0; ie < M; ie++) {
-                    if (ie < n) {
-                        double ng = 0.0;
-                        if (nb[ie] < d.nCells) {
-                            bool mnb = !hasParent ? true
-                                                  : (sharedMask ? ((mnbS >> ie) & 1u) != 0 : (P->val[lp + nb[ie]] > EPS11));
-                            double fnb = T.val[k - c + nb[ie]];
-                            if (mc && mnb) {
-                                double sg = (plus >> ie) & 1u ? 1.0 : -1.0;
-                                ng = sg * (fnb - f) / rdc[ie];
-                            }
-                            if (mnb) {
-                                mx = fmax(mx, fnb);
-                                mn = fmin(mn, fnb);
-                            }
-                        }
-                        g0 = g0 + cf0[ie] * ng;
-                        g1 = g1 + cf1[ie] * ng;
-                        g2 = g2 + cf2[ie] * ng;
-                    }
+                    const bool has = ((valid >> ie) & 1u) != 0;
+                    const int nbi = has ? nb[ie] : c;
+                    const double fnb = T.val[k - c + nbi];
+                    bool mnb = has;
+                    if (hasParent) mnb = mnb && (sharedMask ? ((mnbS >> ie) & 1u) != 0 : (P->val[lp + nbi] > EPS11));
+                    // sg * (fnb - f) with sg = +-1 is the difference taken one way or the other
+                    const double diff = (plus >> ie) & 1u ? fnb - f : -(fnb - f);
+                    const double ng = (mc && mnb) ? diff / rdc[ie] : 0.0;
+                    mx = mnb ? fmax(mx, fnb) : mx;
+                    mn = mnb ? fmin(mn, fnb) : mn;
+                    g0 = g0 + cf0[ie] * ng;
+                    g1 = g1 + cf1[ie] * ng;
+                    g2 = g2 + cf2[ie] * ng;
                 }
                 if (d.rotate && d.onSphere) {  // :4353-4359
                     double t = g0;
