@@ -256,7 +256,8 @@ int sih_evp_subcycle_parts(sih_ctx *ctx, int nParts, const int32_t *parts, int u
  *   stage 0: final_divergence_shear, principal stresses, ocean stress on vertices -> halo oceanStressU/V
  *   stage 1: ocean stress vertex->cell, rescale;  stage -1: both */
 int sih_evp_post_subcycle(sih_ctx *ctx, int stage);
-/* whole seaice_run_velocity_solver for a block that needs no halo exchange */
+/* whole seaice_run_velocity_solver for a block that needs no halo exchange; all iterations but the last are
+ * replayed from a HIP graph captured at the first call (environment SIH_EVP_GRAPH=0: every launch separate) */
 int sih_evp_run(sih_ctx *ctx);
 
 /* ---- measurement ---------------------------------------------------------------------------- */

@@ -15,6 +15,8 @@ real MPAS build; it is written in Python here because the MPAS framework the For
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import lib as _lib
@@ -277,8 +279,14 @@ def subcycle_velocity_solver(domain, clock=None):
     comm = getattr(domain, "comm", None)
     ex = comm is not None and domain.configs["config_use_halo_exch"]
     if not ex:
+        # as sih_evp_run does: all iterations but the last replayed from a captured graph (SIH_EVP_GRAPH=0: not)
+        graph = n > 2 and os.environ.get("SIH_EVP_GRAPH", "1") != "0"
         for b in domain.blocklist:
-            b.ctx.subcycle(n, last=True)
+            if graph:
+                b.ctx.subcycle_graph(n - 1)
+                b.ctx.subcycle(1, last=True)
+            else:
+                b.ctx.subcycle(n, last=True)
         return
     k = int(domain.configs.get("config_halo_exchange_interval", 1))
     names = ["uVelocity", "vVelocity"] if k == 1 else ["uVelocity", "vVelocity", "stress11", "stress22", "stress12"]
