@@ -214,6 +214,7 @@ def main():
                        f"uVelocity/vVelocity/stress every {res['interval']} subcycles"
                        + (", transfer overlapped with interior work" if res.get("overlap") else ""))
         block_cells = res["n_block_cells"]
+        args.graph = int(res.get("graph", False))  # the chunks between two exchanges are replayed from a graph
         if rank != 0:
             return
 

@@ -495,4 +495,4 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
     dist.barrier()
     dist.destroy_process_group()
     return {"wall": wall, "pre_ms": pre_ms, "post_ms": post_ms, "cell_ms": cell_ms, "vert_ms": vert_ms,
-            "n_cells_total": int(mesh.nCells), "n_block_cells": int(n_block_cells), "interval": interval, "overlap": overlap}
+            "n_cells_total": int(mesh.nCells), "n_block_cells": int(n_block_cells), "interval": interval, "overlap": overlap, "graph": bool(use_graph)}
