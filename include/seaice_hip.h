@@ -252,6 +252,16 @@ enum {
 };
 int sih_evp_overlap_setup(sih_ctx *ctx);
 int sih_evp_subcycle_parts(sih_ctx *ctx, int nParts, const int32_t *parts, int useGraph);
+/* The reference's two public operators on their own, as its operator test cases
+ * (testing_and_setup/testcases/spherical_operators/{strain,stress_divergence}, square/operators_strain) drive them:
+ *   sih_evp_strain_tensor      seaice_strain_tensor_variational (velocity_solver_variational.F:575-670): strain11,
+ *                              strain22, strain12 at the corners of every cell with solveStress = 1, from
+ *                              uVelocity / vVelocity
+ *   sih_evp_stress_divergence  seaice_stress_divergence_variational (:1064-1184): stressDivergenceU / V at the owned
+ *                              vertices with solveVelocity = 1, from stress11, stress22, stress12 as they are
+ * Both are asynchronous on the context's stream; the masks are whatever the fields hold. */
+int sih_evp_strain_tensor(sih_ctx *ctx);
+int sih_evp_stress_divergence(sih_ctx *ctx);
 /* velocity_solver_post_subcycle (velocity_solver.F:3360-3380):
  *   stage 0: final_divergence_shear, principal stresses, ocean stress on vertices -> halo oceanStressU/V
  *   stage 1: ocean stress vertex->cell, rescale;  stage -1: both */

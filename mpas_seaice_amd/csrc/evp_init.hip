@@ -771,11 +771,7 @@ extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
         sih_set_error("evp_revised needs dvEdge (minEdgeLengthGlobal)");
         return SIH_ERR_ARG;
     }
-    if (c->graphExec) {
-        (void)hipGraphExecDestroy(c->graphExec);
-        c->graphExec = nullptr;
-        c->graphN = 0;
-    }
+    sih_drop_graphs(c);  // whatever was captured holds launches of the previous kernel variants
     return SIH_OK;
 }
 
@@ -788,10 +784,6 @@ extern "C" int sih_evp_static_changed(sih_ctx *c)
     HIPCHK(hipSetDevice(c->device));
     InitArgs a = makeInitArgs(c);
     int rc = packStatic(c, a);
-    if (c->graphExec) {
-        (void)hipGraphExecDestroy(c->graphExec);
-        c->graphExec = nullptr;
-        c->graphN = 0;
-    }
+    sih_drop_graphs(c);  // whatever was captured holds launches of the previous kernel variants
     return rc;
 }

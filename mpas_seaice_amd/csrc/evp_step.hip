@@ -433,7 +433,8 @@ __global__ void k_pre4_cells(SihDev d)
 // cellsOnVertex order exactly as the reference loop does (:1172-1173), so no rounding changes.
 // MODE 0: all of it in one pass.  With config_average_variational_strain the strains must pass through
 // memory and a vertex loop in between (seaice_average_strains_on_vertex): MODE 1 stops after storing the
-// strains, MODE 2 starts from the stored (averaged) strains.
+// strains, MODE 2 starts from the stored (averaged) strains.  MODE 3 is the inner part of the divergence
+// operator on its own: the stresses are read from memory as they are, for every cell of the block.
 template <int M, bool SPARSE, bool LAST, int MODE>
 __global__ void __launch_bounds__(256) k_sub_cells(SihDev d, const int *__restrict__ list, int nList)
 {
@@ -446,7 +447,7 @@ __global__ void __launch_bounds__(256) k_sub_cells(SihDev d, const int *__restri
         return;
     }
     const int P = d.padC;
-    if (d.solveStress[c] != 1) {
+    if (MODE != 3 && d.solveStress[c] != 1) {
         if (LAST && MODE != 1 && d.relation == 1) {
 #pragma unroll
             for (int s = 0; s < M; s++) d.Prep[(size_t)s * P + c] = 0.0;
@@ -482,6 +483,14 @@ __global__ void __launch_bounds__(256) k_sub_cells(SihDev d, const int *__restri
         s11[g] = 0.0;
         s22[g] = 0.0;
         s12[g] = 0.0;
+        if (MODE == 3) {
+            if (g < E) {
+                s11[g] = d.stress11[(size_t)g * P + c];
+                s22[g] = d.stress22[(size_t)g * P + c];
+                s12[g] = d.stress12[(size_t)g * P + c];
+            }
+            continue;
+        }
         if (g < E) {
             double e11 = 0.0, e22 = 0.0, e12 = 0.0;
             const size_t k = (size_t)g * P + c;
@@ -892,6 +901,25 @@ __global__ void __launch_bounds__(256) k_sub_vertices(SihDev d, const int *__res
     }
 }
 
+// The outer part of seaice_stress_divergence_variational (variational.F:1135-1178) on its own: owned vertices
+// with solveVelocity = 1, the three partial sums in cellsOnVertex order, the division by the denominator.
+__global__ void __launch_bounds__(256) k_div_vertices(SihDev d)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= d.nVerticesSolve || d.solveVelocity[v] != 1) return;
+    const int PV = d.padV;
+    double dU = 0.0, dV = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int g = d.gidx[k * PV + v];
+        dU = dU + d.partU[g];
+        dV = dV + d.partV[g];
+    }
+    const double den0 = d.varDenom[v];
+    d.divU[v] = dU / den0;
+    d.divV[v] = dV / den0;
+}
+
 // =========================================================================== post-subcycle kernels
 
 // seaice_final_divergence_shear_variational (variational.F:1198-1330) and principal_stresses
@@ -1091,6 +1119,8 @@ static void launchCells(sih_ctx *c, bool last, const int *list, int nList, int m
     }
     if (mode == 1) {
         hipLaunchKernelGGL((k_sub_cells<M, false, false, 1>), g, b, 0, c->stream, d, list, nList);
+    } else if (mode == 3) {
+        hipLaunchKernelGGL((k_sub_cells<M, false, false, 3>), g, b, 0, c->stream, d, list, nList);
     } else if (mode == 2) {
         if (last)
             hipLaunchKernelGGL((k_sub_cells<M, false, true, 2>), g, b, 0, c->stream, d, list, nList);
@@ -1225,6 +1255,36 @@ extern "C" int sih_evp_subcycle(sih_ctx *c, int n, int last)
         launchCellKernel(c, l);
         launchVertexKernel(c, l);
     }
+    HIPCHK(hipGetLastError());
+    return SIH_OK;
+}
+
+// The reference's two public operators on their own, as its operator test cases drive them.
+extern "C" int sih_evp_strain_tensor(sih_ctx *c)
+{
+    int rc = checkInit(c, "sih_evp_strain_tensor");
+    if (rc) return rc;
+    if (c->cfg.strainScheme != 0) {
+        sih_set_error("sih_evp_strain_tensor: variational scheme only");
+        return SIH_ERR_UNSUPPORTED;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    launchCellsM(c, false, nullptr, 0, 1);
+    HIPCHK(hipGetLastError());
+    return SIH_OK;
+}
+
+extern "C" int sih_evp_stress_divergence(sih_ctx *c)
+{
+    int rc = checkInit(c, "sih_evp_stress_divergence");
+    if (rc) return rc;
+    if (c->cfg.stressDivergenceScheme != 0) {
+        sih_set_error("sih_evp_stress_divergence: variational scheme only");
+        return SIH_ERR_UNSUPPORTED;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    launchCellsM(c, false, nullptr, 0, 3);
+    hipLaunchKernelGGL(k_div_vertices, gridFor(c->nVerticesSolve), dim3(256), 0, c->stream, c->dev);
     HIPCHK(hipGetLastError());
     return SIH_OK;
 }

@@ -167,12 +167,14 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
         sih_set_error("sih_block_create: null argument");
         return SIH_ERR_ARG;
     }
+    *out = nullptr;  // the caller's handle is defined on every return
     if (m->maxEdges < 3 || m->maxEdges > SIH_MAXE || m->vertexDegree != 3) {
         sih_set_error("sih_block_create: maxEdges must be in [3,10] and vertexDegree 3");
         return SIH_ERR_UNSUPPORTED;
     }
     if (m->nCells < 1 || m->nVertices < 1 || m->nCellsSolve > m->nCells || m->nVerticesSolve > m->nVertices ||
-        !m->nEdgesOnCell || !m->verticesOnCell || !m->cellsOnCell || !m->cellsOnVertex || !m->xCell || !m->yCell ||
+        m->nCellsSolve < 0 || m->nVerticesSolve < 0 || m->nEdges < 0 || m->nEdgesSolve < 0 ||
+        m->nEdgesSolve > m->nEdges || !m->nEdgesOnCell || !m->verticesOnCell || !m->cellsOnCell || !m->cellsOnVertex || !m->xCell || !m->yCell ||
         !m->zCell || !m->xVertex || !m->yVertex || !m->zVertex || !m->areaCell || !m->areaTriangle || !m->fVertex) {
         sih_set_error("sih_block_create: inconsistent mesh description");
         return SIH_ERR_ARG;
@@ -388,7 +390,6 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
         HIPCHK(hipMemcpyAsync(c->fields["_cov"].d, cov.data(), cov.size() * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
-    *out = nullptr;
     struct G {
         const char *n;
         const double *p;
@@ -566,10 +567,25 @@ static int putget(sih_ctx *c, const char *name, void *host, size_t count, bool p
     return putgetMany(c, 1, &name, &host, &count, put);
 }
 
+void sih_drop_graphs(sih_ctx *c)
+{
+    if (c->graphExec) {
+        (void)hipGraphExecDestroy(c->graphExec);
+        c->graphExec = nullptr;
+        c->graphN = 0;
+    }
+    for (auto &kv : c->partGraphs) (void)hipGraphExecDestroy(kv.second);
+    c->partGraphs.clear();
+}
+
 static void notePut(sih_ctx *c, const char *name)
 {
-    if (c->inited && (!strncmp(name, "basisGradient", 13) || !strncmp(name, "basisIntegrals", 14)))
-        c->sparseGrad = false;  // stale until sih_evp_static_changed()
+    if (c->inited && (!strncmp(name, "basisGradient", 13) || !strncmp(name, "basisIntegrals", 14)) && c->sparseGrad) {
+        // the compact gradients are stale until sih_evp_static_changed(); the dense kernel variant reads what the
+        // host has just put.  Captured graphs hold launches of the compact variant: they go too.
+        c->sparseGrad = false;
+        sih_drop_graphs(c);
+    }
 }
 
 extern "C" int sih_field_put(sih_ctx *c, const char *name, const void *host, size_t count)

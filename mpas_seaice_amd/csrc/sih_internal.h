@@ -122,6 +122,7 @@ struct sih_ctx {
 };
 
 void sih_set_error(const std::string &s);
+void sih_drop_graphs(sih_ctx *c);  // captured graphs no longer match what a launch would queue
 SihField *sih_find_field(sih_ctx *c, const char *name);
 int sih_add_field(sih_ctx *c, const char *name, SihLoc loc, int lead, bool isInt);
 int sih_dev_alloc(sih_ctx *c, void **p, size_t bytes);

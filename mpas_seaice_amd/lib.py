@@ -79,6 +79,7 @@ EXPORTS = [
     "sih_evp_set_special_boundaries", "sih_ir_check_monotonicity", "sih_evp_set_edge_mesh",
     "sih_ir_unpack_reconstruction", "sih_host_alloc", "sih_host_free", "sih_upwind_init", "sih_upwind_prepare", "sih_upwind_advect", "sih_upwind_run", "sih_upwind_get_sums",
     "sih_evp_defer_special_boundaries", "sih_evp_apply_special_boundaries",
+    "sih_evp_strain_tensor", "sih_evp_stress_divergence",
 ]
 
 
@@ -125,6 +126,8 @@ def load():
     lib.sih_evp_subcycle_parts.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int32),
                                            ctypes.c_int]
     lib.sih_evp_run.argtypes = [ctypes.c_void_p]
+    lib.sih_evp_strain_tensor.argtypes = [ctypes.c_void_p]
+    lib.sih_evp_stress_divergence.argtypes = [ctypes.c_void_p]
     lib.sih_evp_subcycle_timed.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                            ctypes.POINTER(ctypes.c_double)]
@@ -309,6 +312,12 @@ class BlockContext:
         arr = (ctypes.c_int32 * len(parts))(*parts)
         check(self._lib.sih_evp_subcycle_parts(self.handle, len(parts), arr, int(bool(use_graph))),
               "sih_evp_subcycle_parts")
+
+    def strain_tensor(self):
+        check(self._lib.sih_evp_strain_tensor(self.handle), "sih_evp_strain_tensor")
+
+    def stress_divergence(self):
+        check(self._lib.sih_evp_stress_divergence(self.handle), "sih_evp_stress_divergence")
 
     def post_subcycle(self, stage=-1):
         check(self._lib.sih_evp_post_subcycle(self.handle, stage), "sih_evp_post_subcycle")

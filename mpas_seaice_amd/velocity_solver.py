@@ -298,11 +298,15 @@ def subcycle_velocity_solver(domain, clock=None):
         comm.halo_exchange(domain, names)
         return
     sb = bool(domain.configs["config_use_special_boundaries_velocity"])
+    graph = k > 1 and bool(domain.configs.get("config_subcycle_graph", False))
     done = 0
     while done < n:
         m = min(k, n - done)
         for b in domain.blocklist:
-            b.ctx.subcycle(m, last=(done + m == n))
+            if graph and m == k and done + m < n:
+                b.ctx.subcycle_graph(m)  # the k iterations between two exchanges as one graph launch
+            else:
+                b.ctx.subcycle(m, last=(done + m == n))
         done += m
         comm.halo_exchange(domain, names)
         if sb:  # seaice_set_special_boundaries_velocity after the halo update, velocity_solver.F:2449-2456

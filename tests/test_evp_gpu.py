@@ -421,3 +421,40 @@ def test_unsupported_integration_rules_are_refused():
                 vs.seaice_init_velocity_solver(dom)
         finally:
             vs.seaice_mesh_pool_destroy(dom)
+
+
+def test_put_of_a_basis_array_drops_the_captured_graph():
+    """A host that overwrites basisGradientU through sih_field_put and does not call sih_evp_static_changed
+    gets the dense kernel variant from then on; a graph captured earlier holds launches of the compact
+    variant, whose gradients are stale, and must not be replayed."""
+    import os
+    mesh = get_mesh("QU480")
+    cfg = {"config_elastic_subcycle_number": 12}
+
+    def run(graph):
+        old = os.environ.get("SIH_EVP_GRAPH")
+        os.environ["SIH_EVP_GRAPH"] = "1" if graph else "0"
+        try:
+            dom = cases.make_domain(mesh, "QU480", configs=cfg)
+            vs.seaice_mesh_pool_create(dom)
+            try:
+                vs.seaice_init_velocity_solver(dom)
+                b = dom.blocklist[0]
+                for _ in range(2):  # the first run captures the graph (compact gradients)
+                    vs.seaice_run_velocity_solver(dom)
+                assert b.ctx.info("sparseGradient") == 1.0
+                g = b.structs["velocity_variational"]["basisGradientU"].copy(order="F")
+                g *= 1.25
+                b.ctx.put("basisGradientU", g)  # no static_changed()
+                assert b.ctx.info("sparseGradient") == 0.0
+                vs.seaice_run_velocity_solver(dom)
+            finally:
+                vs.seaice_mesh_pool_destroy(dom)
+        finally:
+            if old is None:
+                os.environ.pop("SIH_EVP_GRAPH", None)
+            else:
+                os.environ["SIH_EVP_GRAPH"] = old
+        return dom.blocklist[0].structs["velocity_solver"]["uVelocity"].copy()
+    a, b = run(True), run(False)
+    assert np.abs(b).max() > 0 and np.array_equal(a, b)

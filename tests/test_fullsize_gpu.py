@@ -105,3 +105,127 @@ def test_qu60_two_blocks_with_deep_halos_and_overlap_equal_one_block(qu60, devic
                                ("velocity_solver", "shear", "cell", qu60.nCells)):
         g = parallel.gather_global(dom.blocklist, halos, pool, name, n, loc)
         assert np.array_equal(g, b0.structs[pool][name][..., :n]), name
+
+
+# ------------------------------------------------------------------------------------------------
+# The other benchmark configurations at their named sizes
+
+def _gathered(dom, halos, mesh, fields):
+    out = {}
+    for pool, name in fields:
+        loc = parallel.field_loc(name)
+        n = mesh.nVertices if loc == "vertex" else mesh.nCells
+        out[(pool, name)] = parallel.gather_global(dom.blocklist, halos, pool, name, n, loc)
+    return out
+
+
+def test_qu120_velocity_solver_matches_oracle(oracle):
+    """QU120 (40 962 cells), variational EVP, 120 subcycles, one block: every state field within 1e-10."""
+    mesh = get_mesh("QU120")
+    ref = cases.make_domain(mesh, "QU120")
+    oracle.seaice_init_velocity_solver(ref)
+    oracle.seaice_run_velocity_solver(ref)
+    dom = cases.make_domain(mesh, "QU120")
+    vs.seaice_mesh_pool_create(dom)
+    try:
+        vs.seaice_init_velocity_solver(dom)
+        vs.seaice_run_velocity_solver(dom)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+    assert dom.configs["config_elastic_subcycle_number"] == 120 and dom.configs["config_dt"] == 1800.0
+    worst = compare_domains(dom, ref, STATE, 1e-10)
+    u = dom.blocklist[0].structs["velocity_solver"]["uVelocity"]
+    assert np.abs(u).max() > 1e-3
+    print("QU120, 120 subcycles: worst rel Linf", worst)
+
+
+def test_qu120_velocity_solver_and_incremental_remap_match_oracle(oracle):
+    """QU120, EVP + incremental remap of 5 thickness categories and the 7 standard tracers (95 scalars per
+    cell), each side advecting with its own velocities: every tracer within 1e-10 of the oracle, and every
+    mass-weighted sum conserved to the reference's 1e-11 (check_tracer_conservation)."""
+    from oracle import ir_flow
+    mesh = get_mesh("QU120")
+    cfg = {"config_conservation_check": True, "config_monotonicity_check": True}
+    ref = cases.make_domain(mesh, "QU120", configs=cfg)
+    oracle.seaice_init_velocity_solver(ref)
+    ir_flow.seaice_init_advection(ref)
+    oracle.seaice_run_velocity_solver(ref)
+    ir_flow.seaice_run_advection(ref)
+    dom = cases.make_domain(mesh, "QU120", configs=cfg)
+    vs.seaice_mesh_pool_create(dom)
+    try:
+        vs.seaice_init_velocity_solver(dom)
+        adv.seaice_init_advection(dom)
+        vs.seaice_run_velocity_solver(dom)
+        adv.seaice_run_advection(dom)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+    b, r = dom.blocklist[0], ref.blocklist[0]
+    assert b.dimensions["nCategories"] == 5
+    compare_domains(dom, ref, STATE[:2], 1e-10)
+    worst = 0.0
+    for n in TRACERS:
+        x, y = b.structs["tracers"][n][..., :mesh.nCells], r.structs["tracers"][n][..., :mesh.nCells]
+        assert np.isfinite(x).all(), n
+        e = np.abs(x - y).max() / np.abs(y).max()
+        assert e <= 1e-10, (n, e)
+        worst = max(worst, e)
+        s0, s1 = dom.solver_state["ir_sums"][n]
+        big = np.abs(s0) > 1e-11
+        assert np.abs((s1 - s0)[big] / s0[big]).max() <= 1e-11, n
+    moved = np.abs(b.structs["tracers"]["iceAreaCategory"] - cases.make_domain(mesh, "QU120").blocklist[0]
+                   .structs["tracers"]["iceAreaCategory"]).max()
+    assert moved > 1e-6  # the advection did something
+    print("QU120 EVP + IR: worst tracer rel Linf", worst)
+
+
+def test_qu60_eight_blocks_as_the_benchmark_partitions_them_equal_one_block(qu60, device_qu60):
+    """The 8-GPU benchmark configuration on one GPU: QU60 cut into 8 blocks along the space-filling curve,
+    16 halo layers, uVelocity / vVelocity / stresses exchanged every 16 subcycles, the chunks between two
+    exchanges replayed from a graph (the settings bench.py uses at 8 ranks), through the in-process transport:
+    bit-identical to the one-block run."""
+    cfg = {"config_num_halos": 16, "config_halo_exchange_interval": 16, "config_subcycle_graph": True}
+    dom, halos, _ = parallel.make_partitioned_domain(qu60, "QU60", 8, configs=cfg)
+    vs.seaice_mesh_pool_create(dom, device=0)
+    try:
+        dom.comm = parallel.LocalComm(dom, halos, 8)
+        vs.seaice_init_velocity_solver(dom)
+        vs.seaice_run_velocity_solver(dom)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+    b0 = device_qu60.blocklist[0]
+    fields = STATE[:5] + [("velocity_solver", "shear"), ("velocity_solver", "solveVelocity")]
+    for (pool, name), g in _gathered(dom, halos, qu60, fields).items():
+        n = g.shape[-1]
+        assert np.array_equal(g, b0.structs[pool][name][..., :n]), name
+
+
+def test_variable_resolution_mesh_in_eight_blocks_960_subcycles_matches_oracle(oracle):
+    """The irregular-degree / long-subcycling configuration: a 3:1 variable-resolution sphere (23 042 cells with
+    5-, 6- and 7-sided cells, maxEdges 7) in 8 blocks, 960 EVP subcycles with an exchange after every one of
+    them as in the reference, against the single-block oracle."""
+    mesh = get_mesh("var48")
+    assert int(mesh.maxEdges) == 7 and (mesh["nEdgesOnCell"] == 7).any() and (mesh["nEdgesOnCell"] == 5).any()
+    cfg = {"config_elastic_subcycle_number": 960, "config_dt": 900.0}
+    ref = cases.make_domain(mesh, None, configs=cfg)
+    oracle.seaice_init_velocity_solver(ref)
+    oracle.seaice_run_velocity_solver(ref)
+    for extra in ({}, {"config_num_halos": 8, "config_halo_exchange_interval": 8, "config_subcycle_graph": True}):
+        dom, halos, _ = parallel.make_partitioned_domain(mesh, None, 8, configs=dict(cfg, **extra))
+        vs.seaice_mesh_pool_create(dom, device=0)
+        try:
+            dom.comm = parallel.LocalComm(dom, halos, 8)
+            vs.seaice_init_velocity_solver(dom)
+            vs.seaice_run_velocity_solver(dom)
+        finally:
+            vs.seaice_mesh_pool_destroy(dom)
+        worst = 0.0
+        for (pool, name), g in _gathered(dom, halos, mesh, STATE).items():
+            r = ref.blocklist[0].structs[pool][name][..., :g.shape[-1]]
+            if g.dtype.kind == "i":
+                assert np.array_equal(g, r), name
+                continue
+            e = np.abs(g - r).max() / max(np.abs(r).max(), 1e-300)
+            assert e <= 1e-10, (name, e, extra)
+            worst = max(worst, e)
+        print("var48 in 8 blocks, 960 subcycles", extra, "worst rel Linf", worst)
