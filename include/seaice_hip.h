@@ -45,7 +45,8 @@ enum {
     SIH_ERR_HIP = 2,        /* HIP runtime failure */
     SIH_ERR_STATE = 3,      /* call out of order (e.g. run before init) */
     SIH_ERR_UNSUPPORTED = 4, /* option of the reference that is outside this library's scope */
-    SIH_ERR_IR = 5          /* a run-time abort of the advection (negative mass / area, degenerate geometry) */
+    SIH_ERR_IR = 5,         /* a run-time abort of the advection (negative mass / area, degenerate geometry) */
+    SIH_ERR_COMM = 6        /* a neighbour's halo message did not arrive within the time limit */
 };
 
 /* Mesh description of one block: the `mesh` pool fields the dynamics read
@@ -294,6 +295,40 @@ int sih_halo_set_lists(sih_ctx *ctx, int location, int nSend, const int32_t *sen
  * Both are asynchronous on the context's stream. */
 int sih_halo_pack(sih_ctx *ctx, int location, int nFields, const char *const *names, void *deviceBuf);
 int sih_halo_unpack(sih_ctx *ctx, int location, int nFields, const char *const *names, const void *deviceBuf);
+
+/* ---- halo exchange inside the library -----------------------------------------------------------
+ * The transport of mpas_dmpar_exch_group_full_halo_exch for blocks that live in different processes (one block
+ * per GPU) or on different devices of one process: the per-subcycle update of uVelocity / vVelocity
+ * (velocity_solver.F:2543-2584), the once-per-step updates of the pre- and post-cycle (:842-937, :1298-1317,
+ * :1480-1616, :3764-3783) and the tracer halo of the advection (incremental_remap.F:2456-2484).  A block's
+ * neighbours store their messages straight into its receive buffer (mapped through HIP IPC, over xGMI between
+ * GPUs) and raise a sequence number there; the receiver waits for those numbers on the device.  Nothing
+ * synchronises with the host, and both launches of an exchange can be captured in a HIP graph.
+ *
+ * Set-up: sih_halo_set_lists for cells and vertices with nPeers = nRanks (entry p = rank p, zero counts where
+ * nothing is exchanged), then sih_comm_create (maxCellPlanes / maxVertexPlanes: the largest number of values
+ * per cell / per vertex any one exchange will carry, e.g. 3 * maxEdges cell planes for the three stress
+ * fields, nLayers * nCategories summed over the tracers for the tracer halo), then every rank's handle
+ * (sih_comm_handle_size bytes, from sih_comm_get_handle) is gathered by whatever the host has -- MPI_Allgather in
+ * an MPAS host, a file, a socket -- and the table, in rank order, is given to sih_comm_connect.  All ranks
+ * must make the same sequence of exchanges. */
+size_t sih_comm_handle_size(void);
+int sih_comm_create(sih_ctx *ctx, int rank, int nRanks, int maxCellPlanes, int maxVertexPlanes);
+int sih_comm_get_handle(sih_ctx *ctx, void *handle);
+int sih_comm_connect(sih_ctx *ctx, const void *allHandles);
+int sih_comm_destroy(sih_ctx *ctx);
+/* One halo update of the named fields (cell and vertex fields may be mixed; all float64 or all int32),
+ * asynchronous on the context's stream.  _start sends only, _finish waits for the neighbours and fills the halo:
+ * work queued between the two runs while the messages travel and must not touch halo entries of the fields. */
+int sih_halo_exchange(sih_ctx *ctx, int nFields, const char *const *names);
+int sih_halo_exchange_start(sih_ctx *ctx, int nFields, const char *const *names);
+int sih_halo_exchange_finish(sih_ctx *ctx, int nFields, const char *const *names);
+/* The device-side wait is bounded (default 10 s, environment SIH_HALO_TIMEOUT_MS): when a neighbour's message does
+ * not arrive the halo is left as it was and the failure is recorded.  sih_comm_status waits for the stream and
+ * returns SIH_ERR_COMM if that has happened since sih_comm_create (the reference's counterpart is an MPI error
+ * in the framework's exchange, fatal there too). */
+int sih_comm_set_timeout(sih_ctx *ctx, double milliseconds);
+int sih_comm_status(sih_ctx *ctx);
 
 /* ---- incremental-remap advection ---------------------------------------------------------------
  * Replaces, for one block, seaice_init_advection_incremental_remap and the per-block part of

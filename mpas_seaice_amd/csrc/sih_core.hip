@@ -414,6 +414,7 @@ extern "C" int sih_block_destroy(sih_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->graphExec) (void)hipGraphExecDestroy(c->graphExec);
+    sih_comm_free(c);
     sih_ir_destroy(c);
     sih_weak_destroy(c);
     sih_upwind_destroy(c);

@@ -72,6 +72,7 @@ struct sih_ctx {
     struct sih_ir_state *ir = nullptr;                       // incremental-remap advection state
     struct sih_weak_state *weak = nullptr;                   // weak strain / stress-divergence scheme
     struct sih_upwind_state *upwind = nullptr;               // upwind advection state
+    struct sih_comm_state *comm = nullptr;                   // halo exchange with blocks of other processes / devices
     std::map<std::string, SihField> fields;
     std::vector<void *> allocs;
     char *arenaBase = nullptr;  // current chunk of the device arena
@@ -129,6 +130,9 @@ int sih_dev_alloc(sih_ctx *c, void **p, size_t bytes);
 void sih_ir_destroy(sih_ctx *c);
 void sih_weak_destroy(sih_ctx *c);
 void sih_upwind_destroy(sih_ctx *c);
+void sih_comm_free(sih_ctx *c);
+int sih_comm_push(sih_ctx *c, int nFields, const char *const *names, hipStream_t stream);
+int sih_comm_pull(sih_ctx *c, int nFields, const char *const *names, hipStream_t stream);
 int sih_setup_edges(sih_ctx *c, const sih_ir_desc *m, const char *who);
 int sih_weak_init(sih_ctx *c);
 void sih_weak_bind(sih_ctx *c);

@@ -80,6 +80,9 @@ EXPORTS = [
     "sih_ir_unpack_reconstruction", "sih_host_alloc", "sih_host_free", "sih_upwind_init", "sih_upwind_prepare", "sih_upwind_advect", "sih_upwind_run", "sih_upwind_get_sums",
     "sih_evp_defer_special_boundaries", "sih_evp_apply_special_boundaries",
     "sih_evp_strain_tensor", "sih_evp_stress_divergence",
+    "sih_comm_handle_size", "sih_comm_create", "sih_comm_get_handle", "sih_comm_connect", "sih_comm_destroy",
+    "sih_halo_exchange", "sih_halo_exchange_start", "sih_halo_exchange_finish", "sih_comm_set_timeout",
+    "sih_comm_status",
 ]
 
 
@@ -138,6 +141,16 @@ def load():
     lib.sih_halo_unpack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                     ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
     lib.sih_get_info.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]
+    lib.sih_comm_handle_size.restype = ctypes.c_size_t
+    lib.sih_comm_handle_size.argtypes = []
+    lib.sih_comm_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.sih_comm_get_handle.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.sih_comm_connect.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.sih_comm_destroy.argtypes = [ctypes.c_void_p]
+    for fn in (lib.sih_halo_exchange, lib.sih_halo_exchange_start, lib.sih_halo_exchange_finish):
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)]
+    lib.sih_comm_set_timeout.argtypes = [ctypes.c_void_p, ctypes.c_double]
+    lib.sih_comm_status.argtypes = [ctypes.c_void_p]
     lib.sih_ir_init.argtypes = [ctypes.c_void_p, ctypes.POINTER(IrDesc)]
     lib.sih_evp_set_edge_mesh.argtypes = [ctypes.c_void_p, ctypes.POINTER(IrDesc)]
     lib.sih_ir_set_tracers.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
@@ -366,6 +379,42 @@ class BlockContext:
     def halo_unpack(self, location, names, device_ptr):
         check(self._lib.sih_halo_unpack(self.handle, int(location), len(names), self._names(names),
                                         ctypes.c_void_p(device_ptr)), "sih_halo_unpack")
+
+    # -- halo exchange inside the library --------------------------------------------------------
+    def comm_create(self, rank, nranks, max_cell_planes, max_vertex_planes):
+        check(self._lib.sih_comm_create(self.handle, int(rank), int(nranks), int(max_cell_planes),
+                                        int(max_vertex_planes)), "sih_comm_create")
+
+    def comm_handle(self):
+        buf = ctypes.create_string_buffer(self._lib.sih_comm_handle_size())
+        check(self._lib.sih_comm_get_handle(self.handle, buf), "sih_comm_get_handle")
+        return buf.raw
+
+    def comm_connect(self, handles):
+        """handles: the comm_handle() bytes of every rank, in rank order"""
+        blob = b"".join(handles)
+        assert len(blob) == len(handles) * self._lib.sih_comm_handle_size()
+        check(self._lib.sih_comm_connect(self.handle, blob), "sih_comm_connect")
+
+    def comm_destroy(self):
+        check(self._lib.sih_comm_destroy(self.handle), "sih_comm_destroy")
+
+    def comm_set_timeout(self, ms):
+        check(self._lib.sih_comm_set_timeout(self.handle, float(ms)), "sih_comm_set_timeout")
+
+    def comm_status(self):
+        check(self._lib.sih_comm_status(self.handle), "sih_comm_status")
+
+    def halo_exchange(self, names):
+        check(self._lib.sih_halo_exchange(self.handle, len(names), self._names(names)), "sih_halo_exchange")
+
+    def halo_exchange_start(self, names):
+        check(self._lib.sih_halo_exchange_start(self.handle, len(names), self._names(names)),
+              "sih_halo_exchange_start")
+
+    def halo_exchange_finish(self, names):
+        check(self._lib.sih_halo_exchange_finish(self.handle, len(names), self._names(names)),
+              "sih_halo_exchange_finish")
 
     # -- incremental remap ---------------------------------------------------------------------
     @staticmethod

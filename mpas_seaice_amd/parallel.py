@@ -370,6 +370,49 @@ class DistComm(CommBase):
                 hf.unpack(L, ns, rt.numpy())
 
 
+class PeerComm(DistComm):
+    """One block per process; the halo messages travel inside the library (sih_halo_exchange): every neighbour
+    stores its message straight into this block's receive buffer, mapped through HIP IPC (over xGMI between
+    GPUs), and the receiver waits for it on the device.  ``torch.distributed`` only carries the 1.2 KB handles
+    at set-up and the scalar reductions; no collective and no host synchronisation is on the data path."""
+
+    def __init__(self, domain, halo, nblocks, rank, max_cell_planes=None, max_vertex_planes=4):
+        super().__init__(domain, halo, nblocks, rank)
+        if not self.device:
+            raise RuntimeError("PeerComm needs device blocks")
+        b = domain.blocklist[0]
+        if max_cell_planes is None:
+            tracer_planes = sum(int(np.prod(a.shape[:-1])) for a in b.structs["tracers"].values()
+                                if isinstance(a, np.ndarray) and a.ndim >= 2)
+            max_cell_planes = max(3 * int(b.dimensions["maxEdges"]) + 4, tracer_planes)
+        b.ctx.comm_create(rank, nblocks, max_cell_planes, max_vertex_planes)
+        mine = b.ctx.comm_handle()
+        if nblocks > 1:
+            handles = [None] * nblocks
+            self.dist.all_gather_object(handles, mine)
+        else:
+            handles = [mine]
+        b.ctx.comm_connect(handles)
+        if nblocks > 1:
+            self.dist.barrier()  # every rank has mapped its neighbours before the first message
+
+    def _steps(self, domain, names):
+        b = domain.blocklist[0]
+        groups = {}
+        for n in names:
+            groups.setdefault(n in INT_FIELDS, []).append(n)
+        groups = list(groups.values())
+        for ns in groups[:-1]:
+            b.ctx.halo_exchange(ns)
+        b.ctx.halo_exchange_start(groups[-1])
+        yield
+        b.ctx.halo_exchange_finish(groups[-1])
+
+    def check(self, domain):
+        """raises if a neighbour's message ever failed to arrive (waits for the block's stream)"""
+        domain.blocklist[0].ctx.comm_status()
+
+
 # ----------------------------------------------------------------------------------------------
 def make_partitioned_domain(mesh, name, nblocks, configs=None, only_block=None, cell_owner=None, **case_kw):
     """Domain holding all blocks of the partition (only_block=None) or just one of them.  ``cell_owner``:

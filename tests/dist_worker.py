@@ -2,7 +2,8 @@
 
 mode cpu : every rank runs the CPU oracle flow on its own block, exchanging halos over gloo.
 mode gpu : every rank drives the HIP library on its own block (all ranks share GPU 0), exchanging
-           halos over gloo through host staging.
+           halos over gloo through host staging, or with "p2p" through the library's own transport
+           (receive buffers mapped into the neighbours through HIP IPC; gloo only carries the handles).
 Each rank also computes the single-block oracle answer and checks its owned entities against it.
 """
 import os
@@ -63,7 +64,8 @@ def main():
         from mpas_seaice_amd import velocity_solver as vs
         torch.cuda.set_device(0)
         vs.seaice_mesh_pool_create(dom, device=0)
-        dom.comm = parallel.DistComm(dom, halo, world, rank)
+        peer = "p2p" in sys.argv[3:]  # the library's own transport: messages stored into the neighbour's buffer
+        dom.comm = (parallel.PeerComm if peer else parallel.DistComm)(dom, halo, world, rank)
         from mpas_seaice_amd import advection as adv
         vs.seaice_init_velocity_solver(dom)
         adv.seaice_init_advection(dom)
@@ -74,6 +76,9 @@ def main():
             dom.blocklist[0].structs["tracers"]["surfaceTemperature"][..., :dom.blocklist[0].dimensions["nCells"]] += 273.15
             advection_upwind.seaice_init_advection_upwind(dom)
             advection_upwind.seaice_run_advection_upwind(dom)
+        if peer:
+            dom.comm.check(dom)
+            dist.barrier()  # no rank unmaps its buffer while a neighbour may still write to it
         vs.seaice_mesh_pool_destroy(dom)
         tol = 1e-10
     b = dom.blocklist[0]

@@ -46,7 +46,7 @@ def test_blocks_on_one_gpu_match_single_block_oracle(oracle, nblocks, interval):
         assert err <= TOL, (name, err)
 
 
-@pytest.mark.parametrize("extra", [[], ["overlap"], ["upwind"]])
+@pytest.mark.parametrize("extra", [[], ["overlap"], ["upwind"], ["p2p"], ["p2p", "overlap"], ["p2p", "upwind"]])
 def test_two_ranks_sharing_the_gpu_over_gloo(extra):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -235,3 +235,84 @@ def test_special_velocity_boundaries_on_three_blocks(oracle):
         r = ref.blocklist[0].structs[pool][name][..., :n].astype(np.float64)
         err = np.abs(g - r).max() / max(np.abs(r).max(), 1e-300)
         assert err <= TOL, (name, err)
+
+
+def _two_connected_blocks(max_cell_planes=24):
+    mesh = get_mesh("QU480")
+    dom, halos, _ = parallel.make_partitioned_domain(mesh, "QU480", 2, configs={"config_elastic_subcycle_number": 6})
+    vs.seaice_mesh_pool_create(dom, device=0)
+    parallel.CommBase(dom, halos, 2)  # gives the exchange lists to the two contexts
+    for r, b in enumerate(dom.blocklist):
+        b.ctx.comm_create(r, 2, max_cell_planes, 4)
+    handles = [b.ctx.comm_handle() for b in dom.blocklist]
+    for b in dom.blocklist:
+        b.ctx.comm_connect(handles)
+    return mesh, dom, halos
+
+
+def test_library_exchange_between_two_blocks_of_one_process():
+    """sih_halo_exchange_start / _finish (messages stored straight into the neighbour's receive buffer, sequence
+    numbers awaited on the device) fill the halos with the owners' values: floats and ints, cell and vertex
+    fields in one message, several exchanges in a row so that both parities of the buffers are used."""
+    mesh, dom, halos = _two_connected_blocks()
+    try:
+        rng = np.random.default_rng(5)
+        glob = {"uVelocity": rng.standard_normal(mesh.nVertices), "vVelocity": rng.standard_normal(mesh.nVertices),
+                "stress11": rng.standard_normal((6, mesh.nCells)), "icePressure": rng.standard_normal(mesh.nCells)}
+        gint = rng.integers(0, 5, mesh.nVertices).astype(np.int32)
+        for rep in range(5):
+            for b, h in zip(dom.blocklist, halos):
+                d = b.dimensions
+                for name, g in glob.items():
+                    loc = parallel.field_loc(name)
+                    n, nown = d["nVertices" if loc == "vertex" else "nCells"], h.nOwned[loc]
+                    a = np.full(g.shape[:-1] + (n + 1,), -777.0, order="F")  # halo entries hold rubbish
+                    a[..., :nown] = (g + rep)[..., h.globalID[loc][:nown]]
+                    b.ctx.put(name, a)
+                a = np.full(d["nVertices"] + 1, -7, dtype=np.int32)
+                a[:h.nOwned["vertex"]] = (gint + rep)[h.globalID["vertex"][:h.nOwned["vertex"]]]
+                b.ctx.put("solveVelocity", a)
+            groups = (["uVelocity", "vVelocity", "stress11", "icePressure"], ["solveVelocity"])
+            for ns in groups:
+                for b in dom.blocklist:
+                    b.ctx.halo_exchange_start(ns)
+                for b in dom.blocklist:
+                    b.ctx.halo_exchange_finish(ns)
+            for b, h in zip(dom.blocklist, halos):
+                b.ctx.comm_status()
+                d = b.dimensions
+                for name, g in glob.items():
+                    loc = parallel.field_loc(name)
+                    n = d["nVertices" if loc == "vertex" else "nCells"]
+                    a = np.zeros(g.shape[:-1] + (n + 1,), order="F")
+                    b.ctx.get(name, a)
+                    assert np.array_equal(a[..., :n], (g + rep)[..., h.globalID[loc][:n]]), (rep, name)
+                a = np.zeros(d["nVertices"] + 1, dtype=np.int32)
+                b.ctx.get("solveVelocity", a)
+                assert np.array_equal(a[:d["nVertices"]], (gint + rep)[h.globalID["vertex"][:d["nVertices"]]]), rep
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+
+
+def test_a_silent_neighbour_is_reported_and_every_kernel_still_ends():
+    """The device-side wait for a neighbour's message is bounded: with a limit of 20 ms and a neighbour that
+    never sends, the halo stays as it was, sih_comm_status reports it, and the stream drains normally."""
+    from mpas_seaice_amd import lib as sihlib
+    mesh, dom, halos = _two_connected_blocks()
+    try:
+        b0 = dom.blocklist[0]
+        n = b0.dimensions["nVertices"]
+        u = np.arange(n + 1, dtype=np.float64)
+        b0.ctx.put("uVelocity", u)
+        b0.ctx.comm_set_timeout(20.0)
+        b0.ctx.halo_exchange(["uVelocity", "vVelocity"])  # block 1 never starts its side
+        with pytest.raises(sihlib.SeaiceHipError, match="did not arrive"):
+            b0.ctx.comm_status()
+        back = np.zeros(n + 1)
+        b0.ctx.get("uVelocity", back)
+        assert np.array_equal(back[:n], u[:n])
+        with pytest.raises(sihlib.SeaiceHipError, match="larger than the plane counts"):
+            b0.ctx.halo_exchange(["stress11", "stress22", "stress12", "strain11", "strain22", "strain12",
+                                  "replacementPressure", "principalStress1", "principalStress2"])
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
