@@ -323,6 +323,16 @@ int sih_comm_destroy(sih_ctx *ctx);
 int sih_halo_exchange(sih_ctx *ctx, int nFields, const char *const *names);
 int sih_halo_exchange_start(sih_ctx *ctx, int nFields, const char *const *names);
 int sih_halo_exchange_finish(sih_ctx *ctx, int nFields, const char *const *names);
+/* single_subcycle_velocity_solver with its halo update (velocity_solver.F:2478-2592) n times, everything on the
+ * device: the iterations and, after every `interval` of them, the update of uVelocity / vVelocity through
+ * sih_halo_exchange.  interval = 1 is the reference's order.  interval = k > 1 needs computeHaloVertices and k halo
+ * layers in the block: stress11 / stress22 / stress12 then travel with the velocities and the results are the
+ * same.  last != 0: the n-th iteration is the final one of the dynamics step (see sih_evp_subcycle) and is
+ * followed by an update of its own.  overlap != 0 (after sih_evp_overlap_setup): the vertices the neighbours need
+ * are updated first and sent from a second stream while the context's stream finishes the other vertices and
+ * the next iteration's interior cells.  useGraph != 0: every distinct chunk (iterations + exchange) is captured
+ * once and replayed as one graph launch.  Asynchronous; check sih_comm_status at the end of the step. */
+int sih_evp_subcycle_exchange(sih_ctx *ctx, int n, int last, int interval, int overlap, int useGraph);
 /* The device-side wait is bounded (default 10 s, environment SIH_HALO_TIMEOUT_MS): when a neighbour's message does
  * not arrive the halo is left as it was and the failure is recorded.  sih_comm_status waits for the stream and
  * returns SIH_ERR_COMM if that has happened since sih_comm_create (the reference's counterpart is an MPI error

@@ -1589,6 +1589,133 @@ extern "C" int sih_evp_subcycle_parts(sih_ctx *c, int nParts, const int32_t *par
     return SIH_OK;
 }
 
+// ---------------------------------------------------------------------------- subcycles with the halo update inside
+// One chunk of `m` iterations (none the last of the dynamics step) followed by the halo update of `names`, as a
+// sequence of launches on the context's stream.  Plain order: (cells, vertices) x m, push, pull.  Overlapped order
+// (the subsets of sih_evp_overlap_setup): the vertices the neighbours need are updated first and pushed from a
+// second stream while this stream finishes the other vertices and, if more iterations follow, runs the next
+// iteration's cell kernel on the cells that touch no halo vertex; the pull and the rim cells open the next chunk.
+static int queueChunk(sih_ctx *c, int m, bool overlap, bool pendingIn, bool more, int nNames, const char *const *names)
+{
+    int rc;
+    if (!overlap) {
+        for (int it = 0; it < m; it++) {
+            launchCellKernel(c, false);
+            launchVertexKernel(c, false);
+        }
+        if ((rc = sih_comm_push(c, nNames, names, c->stream))) return rc;
+        if ((rc = sih_comm_pull(c, nNames, names, c->stream))) return rc;
+        if (c->sbDeferred) applySpecialBoundaryVelocity(c);  // velocity_solver.F:2449-2456
+        return SIH_OK;
+    }
+    int first = 0;
+    if (pendingIn) {  // the first iteration of this chunk already has its interior cells
+        if ((rc = sih_comm_pull(c, nNames, names, c->stream))) return rc;
+        launchCellKernel(c, false, 1);
+        if (m == 1) {
+            launchVertexKernel(c, false, 2);
+        } else {
+            launchVertexKernel(c, false);
+        }
+        first = 1;
+    }
+    for (int it = first; it < m; it++) {
+        if (pendingIn && m == 1) break;
+        launchCellKernel(c, false);
+        if (it == m - 1)
+            launchVertexKernel(c, false, 2);
+        else
+            launchVertexKernel(c, false);
+    }
+    hipStream_t side = sih_comm_stream(c);
+    hipEvent_t evFork, evJoin;
+    sih_comm_events(c, &evFork, &evJoin);
+    HIPCHK(hipEventRecord(evFork, c->stream));
+    HIPCHK(hipStreamWaitEvent(side, evFork, 0));
+    if ((rc = sih_comm_push(c, nNames, names, side))) return rc;
+    HIPCHK(hipEventRecord(evJoin, side));
+    launchVertexKernel(c, false, 3);
+    // the interior cells of the next iteration rewrite their stresses: when the stresses travel with the
+    // velocities (more than two fields), the push must have read them first
+    const bool pushReadsStress = nNames > 2;
+    if (pushReadsStress) HIPCHK(hipStreamWaitEvent(c->stream, evJoin, 0));
+    if (more) launchCellKernel(c, false, 0);
+    if (!pushReadsStress) HIPCHK(hipStreamWaitEvent(c->stream, evJoin, 0));
+    return SIH_OK;
+}
+
+extern "C" int sih_evp_subcycle_exchange(sih_ctx *c, int n, int last, int interval, int overlap, int useGraph)
+{
+    int rc = checkInit(c, "sih_evp_subcycle_exchange");
+    if (rc) return rc;
+    if (n < 0 || interval < 1) {
+        sih_set_error("sih_evp_subcycle_exchange: n must be >= 0 and interval >= 1");
+        return SIH_ERR_ARG;
+    }
+    if (!sih_comm_ready(c)) {
+        sih_set_error("sih_evp_subcycle_exchange: call sih_comm_create and sih_comm_connect first");
+        return SIH_ERR_STATE;
+    }
+    if (interval > 1 && !c->cfg.computeHaloVertices) {
+        sih_set_error("sih_evp_subcycle_exchange: an interval above 1 needs computeHaloVertices (and as many halo layers)");
+        return SIH_ERR_ARG;
+    }
+    if (overlap && !c->partsReady) {
+        sih_set_error("sih_evp_subcycle_exchange: call sih_evp_overlap_setup first");
+        return SIH_ERR_STATE;
+    }
+    if (c->sbVelocity && (!c->sbDeferred || interval > 1 || overlap)) {
+        sih_set_error("sih_evp_subcycle_exchange: with special velocity boundaries: deferred application, interval 1, no overlap");
+        return SIH_ERR_UNSUPPORTED;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    static const char *uv[2] = {"uVelocity", "vVelocity"};
+    static const char *uvs[5] = {"uVelocity", "vVelocity", "stress11", "stress22", "stress12"};
+    const char *const *names = interval == 1 ? uv : uvs;
+    const int nNames = interval == 1 ? 2 : 5;
+    beginSubcycles(c);
+    const int nMain = last ? n - 1 : n;
+    int done = 0;
+    bool pending = false;
+    while (done < nMain) {
+        const int m = std::min(interval, nMain - done);
+        const bool more = done + m < nMain;
+        if (useGraph) {
+            std::vector<int> key = {-1000, m, overlap ? 1 : 0, pending ? 1 : 0, more ? 1 : 0, c->sparseGrad ? 1 : 0};
+            auto it = c->partGraphs.find(key);
+            if (it == c->partGraphs.end()) {
+                hipGraph_t graph;
+                hipGraphExec_t exec;
+                // the tables of the field group are built (and copied to the device) before the capture begins
+                if ((rc = sih_comm_prepare(c, nNames, names))) return rc;
+                HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                rc = queueChunk(c, m, overlap != 0, pending, more, nNames, names);
+                hipError_t e = hipStreamEndCapture(c->stream, &graph);
+                if (rc) return rc;
+                HIPCHK(e);
+                HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                HIPCHK(hipGraphDestroy(graph));
+                it = c->partGraphs.emplace(key, exec).first;
+            }
+            HIPCHK(hipGraphLaunch(it->second, c->stream));
+        } else if ((rc = queueChunk(c, m, overlap != 0, pending, more, nNames, names))) {
+            return rc;
+        }
+        pending = overlap != 0;
+        done += m;
+    }
+    if (pending && (rc = sih_comm_pull(c, nNames, names, c->stream))) return rc;
+    if (last && n > 0) {
+        launchCellKernel(c, true);
+        launchVertexKernel(c, true);
+        if ((rc = sih_comm_push(c, nNames, names, c->stream))) return rc;
+        if ((rc = sih_comm_pull(c, nNames, names, c->stream))) return rc;
+        if (c->sbDeferred) applySpecialBoundaryVelocity(c);
+    }
+    HIPCHK(hipGetLastError());
+    return SIH_OK;
+}
+
 extern "C" int sih_evp_subcycle_timed(sih_ctx *c, int n, int useGraph, int sampleEvery, double *totalMs, double *cellMs,
                                       double *vertexMs)
 {

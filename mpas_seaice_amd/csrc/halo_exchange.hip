@@ -532,6 +532,19 @@ static int checkComm(sih_ctx *c, const char *who, int nFields, const char *const
     return SIH_OK;
 }
 
+bool sih_comm_ready(sih_ctx *c) { return c && c->comm && c->comm->connected; }
+hipStream_t sih_comm_stream(sih_ctx *c) { return c->comm->commStream; }
+void sih_comm_events(sih_ctx *c, hipEvent_t *fork, hipEvent_t *join)
+{
+    *fork = c->comm->evFork;
+    *join = c->comm->evJoin;
+}
+int sih_comm_prepare(sih_ctx *c, int nFields, const char *const *names)
+{
+    CommTable *tb;
+    return commTable(c, nFields, names, &tb);
+}
+
 int sih_comm_push(sih_ctx *c, int nFields, const char *const *names, hipStream_t stream)
 {
     sih_comm_state *s = c->comm;

@@ -133,6 +133,10 @@ void sih_upwind_destroy(sih_ctx *c);
 void sih_comm_free(sih_ctx *c);
 int sih_comm_push(sih_ctx *c, int nFields, const char *const *names, hipStream_t stream);
 int sih_comm_pull(sih_ctx *c, int nFields, const char *const *names, hipStream_t stream);
+int sih_comm_prepare(sih_ctx *c, int nFields, const char *const *names);  // builds the group's tables (not capturable)
+bool sih_comm_ready(sih_ctx *c);
+hipStream_t sih_comm_stream(sih_ctx *c);
+void sih_comm_events(sih_ctx *c, hipEvent_t *fork, hipEvent_t *join);
 int sih_setup_edges(sih_ctx *c, const sih_ir_desc *m, const char *who);
 int sih_weak_init(sih_ctx *c);
 void sih_weak_bind(sih_ctx *c);

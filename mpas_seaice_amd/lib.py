@@ -82,7 +82,7 @@ EXPORTS = [
     "sih_evp_strain_tensor", "sih_evp_stress_divergence",
     "sih_comm_handle_size", "sih_comm_create", "sih_comm_get_handle", "sih_comm_connect", "sih_comm_destroy",
     "sih_halo_exchange", "sih_halo_exchange_start", "sih_halo_exchange_finish", "sih_comm_set_timeout",
-    "sih_comm_status",
+    "sih_comm_status", "sih_evp_subcycle_exchange",
 ]
 
 
@@ -151,6 +151,7 @@ def load():
         fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)]
     lib.sih_comm_set_timeout.argtypes = [ctypes.c_void_p, ctypes.c_double]
     lib.sih_comm_status.argtypes = [ctypes.c_void_p]
+    lib.sih_evp_subcycle_exchange.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5
     lib.sih_ir_init.argtypes = [ctypes.c_void_p, ctypes.POINTER(IrDesc)]
     lib.sih_evp_set_edge_mesh.argtypes = [ctypes.c_void_p, ctypes.POINTER(IrDesc)]
     lib.sih_ir_set_tracers.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
@@ -415,6 +416,11 @@ class BlockContext:
     def halo_exchange_finish(self, names):
         check(self._lib.sih_halo_exchange_finish(self.handle, len(names), self._names(names)),
               "sih_halo_exchange_finish")
+
+    def subcycle_exchange(self, n, last=False, interval=1, overlap=False, use_graph=True):
+        check(self._lib.sih_evp_subcycle_exchange(self.handle, int(n), int(bool(last)), int(interval),
+                                                  int(bool(overlap)), int(bool(use_graph))),
+              "sih_evp_subcycle_exchange")
 
     # -- incremental remap ---------------------------------------------------------------------
     @staticmethod

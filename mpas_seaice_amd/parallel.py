@@ -375,6 +375,7 @@ class PeerComm(DistComm):
     stores its message straight into this block's receive buffer, mapped through HIP IPC (over xGMI between
     GPUs), and the receiver waits for it on the device.  ``torch.distributed`` only carries the 1.2 KB handles
     at set-up and the scalar reductions; no collective and no host synchronisation is on the data path."""
+    in_library = True  # the subcycle loop can run with its exchanges inside the library
 
     def __init__(self, domain, halo, nblocks, rank, max_cell_planes=None, max_vertex_planes=4):
         super().__init__(domain, halo, nblocks, rank)

@@ -290,6 +290,14 @@ def subcycle_velocity_solver(domain, clock=None):
         return
     k = int(domain.configs.get("config_halo_exchange_interval", 1))
     names = ["uVelocity", "vVelocity"] if k == 1 else ["uVelocity", "vVelocity", "stress11", "stress22", "stress12"]
+    if getattr(comm, "in_library", False) and not _weak_strain(domain) \
+            and not domain.configs["config_average_variational_strain"]:
+        # the whole loop, exchanges included, runs inside the library (sih_evp_subcycle_exchange)
+        for b in domain.blocklist:
+            b.ctx.subcycle_exchange(n, last=True, interval=k,
+                                    overlap=bool(domain.configs.get("config_overlap_halo_exchange", False)),
+                                    use_graph=bool(domain.configs.get("config_subcycle_graph", False)))
+        return
     if domain.configs.get("config_overlap_halo_exchange", False) and hasattr(comm, "start_exchange"):
         subcycle_overlapped(domain, comm, n - 1, k, names,
                             use_graph=bool(domain.configs.get("config_subcycle_graph", False)))

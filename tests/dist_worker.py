@@ -35,6 +35,11 @@ def main():
     cfg = {"config_elastic_subcycle_number": 12, "config_dt": 7200.0}
     if "overlap" in sys.argv[3:]:  # exchange hidden behind interior work; only the device path has it
         cfg["config_overlap_halo_exchange"] = True
+    if "graph" in sys.argv[3:]:  # chunks of the subcycle loop (iterations + exchange) replayed from HIP graphs
+        cfg["config_subcycle_graph"] = True
+    pcfg = dict(cfg)
+    if "deep" in sys.argv[3:]:  # three halo layers, one exchange per three iterations
+        pcfg.update(config_num_halos=3, config_halo_exchange_interval=3)
     ref = cases.make_domain(mesh, None, configs=cfg, open_water_band=(-0.2, 0.3))
     ora.seaice_init_velocity_solver(ref)
     ira.seaice_init_advection(ref)
@@ -45,7 +50,7 @@ def main():
         ref.blocklist[0].structs["tracers"]["surfaceTemperature"][..., :mesh.nCells] += 273.15
         upw.seaice_init_advection_upwind(ref)
         upw.seaice_run_advection_upwind(ref)
-    dom, halo, _ = parallel.make_partitioned_domain(mesh, None, world, configs=cfg, only_block=rank,
+    dom, halo, _ = parallel.make_partitioned_domain(mesh, None, world, configs=pcfg, only_block=rank,
                                                     open_water_band=(-0.2, 0.3))
     if mode == "cpu":
         comm = parallel.DistComm(dom, halo, world, rank)

@@ -46,7 +46,9 @@ def test_blocks_on_one_gpu_match_single_block_oracle(oracle, nblocks, interval):
         assert err <= TOL, (name, err)
 
 
-@pytest.mark.parametrize("extra", [[], ["overlap"], ["upwind"], ["p2p"], ["p2p", "overlap"], ["p2p", "upwind"]])
+@pytest.mark.parametrize("extra", [[], ["overlap"], ["upwind"], ["p2p"], ["p2p", "overlap"], ["p2p", "upwind"],
+                                   ["p2p", "graph"], ["p2p", "graph", "overlap"], ["p2p", "graph", "deep"],
+                                   ["p2p", "graph", "deep", "overlap"]])
 def test_two_ranks_sharing_the_gpu_over_gloo(extra):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
