@@ -208,6 +208,13 @@ int sih_field_get(sih_ctx *ctx, const char *name, void *host, size_t count);
 int sih_fields_put(sih_ctx *ctx, int nFields, const char *const *names, const void *const *hosts,
                    const size_t *counts);
 int sih_fields_get(sih_ctx *ctx, int nFields, const char *const *names, void *const *hosts, const size_t *counts);
+/* sih_field_get for callers that cannot allocate: code under HIP graph capture elsewhere in the process, tight
+ * serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  The layout conversion is
+ * staged in a 16 MiB array that is part of the library's code object on every GPU, so the call makes no
+ * hipMalloc / hipFree (sih_field_get grows its staging buffer on demand); a field of more than 16 MiB is refused
+ * with SIH_ERR_ARG.  All calls on one GPU share that array: calls that overlap on one GPU (two host threads, two
+ * contexts) race. */
+int sih_field_get_noalloc(sih_ctx *ctx, const char *name, void *host, size_t count);
 /* logical element count of a field, and 8 (float64) or 4 (int32) in *elemSize; 0 if unknown */
 size_t sih_field_count(sih_ctx *ctx, const char *name, int *elemSize);
 

@@ -160,6 +160,7 @@ static uint64_t mortonKey(double x, double y, double z)
 }
 
 extern "C" int sih_block_destroy(sih_ctx *c);
+static int resolveScratch(int device);
 
 extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **out)
 {
@@ -180,6 +181,10 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
         return SIH_ERR_ARG;
     }
     HIPCHK(hipSetDevice(device));
+    {
+        int rcs = resolveScratch(device);
+        if (rcs) return rcs;
+    }
     sih_ctx *c = new sih_ctx();
     struct Guard {  // any early return below releases what has been created so far
         sih_ctx *c;
@@ -577,6 +582,75 @@ void sih_drop_graphs(sih_ctx *c)
     }
     for (auto &kv : c->partGraphs) (void)hipGraphExecDestroy(kv.second);
     c->partGraphs.clear();
+}
+
+// ------------------------------------------------------------------------------------------
+// Staging memory that exists without any allocation call: one array in the code object, 16 MiB on every GPU the
+// library runs on, for the entry point that must not allocate (sih_field_get_noalloc).  Host code never uses
+// the array's name as an address: the per-device address comes from hipGetSymbolAddress, once per device.
+#define SIH_STATIC_STAGE_BYTES (16u << 20)
+#define SIH_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[SIH_STATIC_STAGE_BYTES];
+static void *g_scratchPtr[SIH_MAX_DEVICES];
+
+// with `device` current; called from sih_block_create, so every context's device has its address before the
+// first sih_field_get_noalloc
+static int resolveScratch(int device)
+{
+    if (device < 0 || device >= SIH_MAX_DEVICES) {
+        sih_set_error("device ordinal out of range");
+        return SIH_ERR_ARG;
+    }
+    if (g_scratchPtr[device]) return SIH_OK;
+    void *p = nullptr;
+    HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    g_scratchPtr[device] = p;
+    return SIH_OK;
+}
+
+extern "C" int sih_field_get_noalloc(sih_ctx *c, const char *name, void *host, size_t count)
+{
+    if (!c || !name || !host) {
+        sih_set_error("sih_field_get_noalloc: null argument");
+        return SIH_ERR_ARG;
+    }
+    SihField *f = nullptr;
+    for (auto &kv : c->fields)  // no temporary string: this path allocates nothing, on the host either
+        if (!strcmp(kv.first.c_str(), name)) {
+            f = &kv.second;
+            break;
+        }
+    if (!f) {
+        sih_set_error("sih_field_get_noalloc: unknown field");
+        return SIH_ERR_ARG;
+    }
+    const int n = locCount(c, f->loc), pad = locPad(c, f->loc), L = f->lead;
+    if (count != (size_t)n * L) {
+        sih_set_error("sih_field_get_noalloc: element count mismatch");
+        return SIH_ERR_ARG;
+    }
+    const size_t bytes = count * (f->isInt ? 4 : 8);
+    if (bytes > SIH_STATIC_STAGE_BYTES) {
+        sih_set_error("sih_field_get_noalloc: the field is larger than the static staging buffer (16 MiB); use sih_field_get");
+        return SIH_ERR_ARG;
+    }
+    void *stage = g_scratchPtr[c->device];
+    if (!stage) {
+        sih_set_error("sih_field_get_noalloc: the staging buffer of this device was not resolved");
+        return SIH_ERR_STATE;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    if (count == 0) return SIH_OK;
+    const int *perm = c->renumber ? locPerm(c, f->loc) : nullptr;
+    dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    if (f->isInt)
+        hipLaunchKernelGGL(k_get<int>, grid, block, 0, c->stream, (int *)stage, (const int *)f->d, perm, n, L, pad);
+    else
+        hipLaunchKernelGGL(k_get<double>, grid, block, 0, c->stream, (double *)stage, (const double *)f->d, perm, n, L, pad);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(host, stage, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));  // the staging buffer is free for the next call, the host array is the caller's
+    return SIH_OK;
 }
 
 static void notePut(sih_ctx *c, const char *name)

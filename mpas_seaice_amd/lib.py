@@ -82,7 +82,7 @@ EXPORTS = [
     "sih_evp_strain_tensor", "sih_evp_stress_divergence",
     "sih_comm_handle_size", "sih_comm_create", "sih_comm_get_handle", "sih_comm_connect", "sih_comm_destroy",
     "sih_halo_exchange", "sih_halo_exchange_start", "sih_halo_exchange_finish", "sih_comm_set_timeout",
-    "sih_comm_status", "sih_evp_subcycle_exchange",
+    "sih_comm_status", "sih_evp_subcycle_exchange", "sih_field_get_noalloc",
 ]
 
 
@@ -115,6 +115,7 @@ def load():
     lib.sih_evp_static_changed.argtypes = [ctypes.c_void_p]
     lib.sih_field_put.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t]
     lib.sih_field_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t]
+    lib.sih_field_get_noalloc.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t]
     for fn in (lib.sih_fields_put, lib.sih_fields_get):
         fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
                        ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
