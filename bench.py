@@ -43,6 +43,51 @@ def b_alg_cell_kernel(M):
     return 16 * M * M + 24 * M * M + 48 * M + 8 * M + (4 * M + 8) + 8 + 24 * 2
 
 
+def b_layout_cell_kernel(M):
+    """Bytes per cell this library's layout makes the cell kernel move: like b_alg_cell_kernel, but the basis
+    gradients are stored compactly (three non-zeros per column: 48 M instead of 16 M^2 bytes) and the per-corner
+    partial sums of the stress divergence are written (16 M)."""
+    return 48 * M + 24 * M * M + 48 * M + 16 * M + (4 * M + 8) + 8 + 24 * 2
+
+
+def kernel_source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("evp_step.hip", "sih_internal.h"):
+        with open(os.path.join(ROOT, "mpas_seaice_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def hbm_only_pass(local_rank, nsub=24, steps=5):
+    """The same subcycle on QU30 (655 362 cells, 1.4 GB touched per subcycle: nothing survives in the 256 MB
+    Infinity Cache from one subcycle to the next), so that the line carries what the access pattern gets from
+    HBM alone next to the QU60 figure."""
+    from mpas_seaice_amd import cases, mesh as meshmod, velocity_solver as vs
+    mesh = meshmod.make_named_mesh("QU30")
+    dom = cases.make_domain(mesh, "QU30", configs={"config_elastic_subcycle_number": nsub})
+    vs.seaice_mesh_pool_create(dom, device=local_rank)
+    try:
+        vs.seaice_init_velocity_solver(dom)
+        ctx = dom.blocklist[0].ctx
+        vs._upload(dom, dom.blocklist[0])
+        vs.velocity_solver_pre_subcycle(dom)
+        ctx.subcycle_timed(nsub, use_graph=False, sample_every=0)
+        tot = cell = vert = 0.0
+        for _ in range(steps):
+            t, tc, tv = ctx.subcycle_timed(nsub, use_graph=False, sample_every=4)
+            tot, cell, vert = tot + t, cell + tc, vert + tv
+        M = int(mesh.maxEdges)
+        cell /= steps
+        b = b_alg_cell_kernel(M) * mesh.nCells
+        return {"workload": f"QU30 ({mesh.nCells} cells), {nsub} subcycles x {steps}", "kernel_ms": cell,
+                "vertex_kernel_ms": vert / steps, "achieved": b / (cell * 1e-3) / 1e9,
+                "frac": b / (cell * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "updates_per_s": mesh.nCells * nsub * steps / (tot * 1e-3)}
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+
+
 def cpu_baseline(mesh, name, max_seconds=25.0):
     """The CPU oracle (a restatement of the reference loops, OpenMP where the reference has it) timed
     on this host: whole-mesh subcycles until ~max_seconds of work."""
@@ -128,6 +173,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-renumber", action="store_true")
     ap.add_argument("--no-advection", action="store_true", help="skip the incremental-remap timing")
+    ap.add_argument("--no-hbm-only", action="store_true", help="skip the QU30 pass (HBM-only rate of the cell kernel)")
     args = ap.parse_args()
 
     import torch
@@ -210,9 +256,10 @@ def main():
                                        renumber=not args.no_renumber, cell_owner=cell_owner)
         wall, pre_ms, post_ms, cell_ms, vert_ms, n_cells_total = (res[k] for k in (
             "wall", "pre_ms", "post_ms", "cell_ms", "vert_ms", "n_cells_total"))
-        parallelism = (f"{world} MPAS blocks, one per GPU, {res['interval']} halo layers, RCCL exchange of "
-                       f"uVelocity/vVelocity/stress every {res['interval']} subcycles"
-                       + (", transfer overlapped with interior work" if res.get("overlap") else ""))
+        parallelism = (f"{world} MPAS blocks, one per GPU, {res['interval']} halo layers, uVelocity/vVelocity/stress "
+                       f"exchanged every {res['interval']} subcycles: {res['transport_text']}"
+                       + (", the push on a second stream beside interior work" if res.get("overlap") else "")
+                       + (f" [{res['transport_note']}]" if res.get("transport_note") else ""))
         block_cells = res["n_block_cells"]
         args.graph = int(res.get("graph", False))  # the chunks between two exchanges are replayed from a graph
         if rank != 0:
@@ -224,13 +271,22 @@ def main():
     cells_per_launch = n_cells_total if world == 1 else block_cells
     roof_bytes = b_alg_cell_kernel(M) * cells_per_launch
     achieved = roof_bytes / (cell_ms * 1e-3) / 1e9 if cell_ms > 0 else 0.0
-    traffic = None
+    # HBM bytes per launch from the PMC counters: they are collected in passes of their own (rocprofv3 --pmc,
+    # scripts/refresh_traffic.py) and kept under profiles/ with a hash of the kernel source they were taken with;
+    # a figure taken with other kernels is not reported
+    traffic, traffic_note = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if world == 1 and mesh_label == "QU60" and os.path.exists(tpath):  # the counters were collected on this workload
         try:
-            traffic = json.load(open(tpath)).get("cell_kernel_hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            if tj.get("kernel_source_hash") == kernel_source_hash():
+                traffic = tj.get("cell_kernel_hbm_bytes_per_launch")
+                traffic_note = tj.get("source")
+            else:
+                traffic_note = "profiles/traffic_latest.json was taken with other kernel sources: not reported"
         except Exception:
             traffic = None
+    layout_bytes = b_layout_cell_kernel(M) * cells_per_launch
     out = {
         "metric": "EVP cell-subcycle-updates/sec at " + mesh_label, "value": value, "unit": "cell-subcycle-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -241,12 +297,23 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_sub_cells_split (fused strain + EVP stress + stress-divergence partial sums, one thread per cell corner)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_launch": roof_bytes,
-                     "kernel_ms": cell_ms, "vertex_kernel_ms": vert_ms},
+                     "kernel_ms": cell_ms, "vertex_kernel_ms": vert_ms,
+                     # the same kernel time against the bytes this layout really has to move (compact gradients)
+                     # and, when the counters are current, against the bytes they counted
+                     "layout_bytes_per_launch": layout_bytes,
+                     "frac_layout": (layout_bytes / (cell_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if cell_ms > 0 else 0.0,
+                     "frac_counter": (traffic / (cell_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and cell_ms > 0 else None,
+                     "traffic_source": traffic_note},
         "subcycle_hbm": {"algorithmic_bytes_per_cell_subcycle": b_cell + b_vert,
                          "achieved_GBps": (b_cell + b_vert) * value / 1e9,
                          "frac_of_peak": (b_cell + b_vert) * value / 1e9 / HBM_PEAK_GBS},
         "pre_ms": pre_ms, "post_ms": post_ms,
     }
+    if world > 1:
+        out["exchange"] = {"transport": res["transport"], "rendezvous_backend": res["rendezvous_backend"],
+                           "us_per_exchange_in_a_chain_of_50": res["exchange_us"], "block_cells_with_halo": block_cells}
+    if world == 1 and not args.no_hbm_only and mesh_label == "QU60":
+        out["roofline"]["hbm_only"] = hbm_only_pass(local_rank)
     if world == 1 and advection is not None:
         out["advection"] = advection
     if world == 1 and not args.no_cpu_baseline:

@@ -446,9 +446,40 @@ def oracle_halo_callback(comm):
     return halo
 
 
+def link_self_test(dom, halo, comm, rounds=3):
+    """Push known patterns through the transport and compare every halo entry with what its owner holds.
+    Returns the number of wrong entries on this rank (0 on a working link)."""
+    b = dom.blocklist[0]
+    nV, nC, M = b.dimensions["nVertices"], b.dimensions["nCells"], b.dimensions["maxEdges"]
+    gv, gc = halo.globalID["vertex"], halo.globalID["cell"]
+    bad = 0
+    for r in range(rounds):
+        u = np.zeros(nV + 1)
+        v = np.zeros(nV + 1)
+        s11 = np.zeros((M, nC + 1), order="F")
+        own_v, own_c = halo.nOwned["vertex"], halo.nOwned["cell"]
+        u[:own_v] = np.sin(0.001 * gv[:own_v] + r)
+        v[:own_v] = gv[:own_v] * (r + 1.0)
+        s11[:, :own_c] = (np.arange(M)[:, None] + 1.0) * (gc[None, :own_c] + 0.25 * r)
+        u[own_v:nV] = v[own_v:nV] = -1.0e30
+        s11[:, own_c:nC] = -1.0e30
+        b.ctx.put_many([("uVelocity", u), ("vVelocity", v), ("stress11", s11)])
+        comm.halo_exchange(dom, ["uVelocity", "vVelocity", "stress11"])
+        b.ctx.get_many([("uVelocity", u), ("vVelocity", v), ("stress11", s11)])
+        # entries in the receive lists must now hold their owners' values; entries no list names keep the marker
+        rv = comm.lists[0]["vertex"].recv_idx - 1
+        rc = comm.lists[0]["cell"].recv_idx - 1
+        bad += int((u[rv] != np.sin(0.001 * gv[rv] + r)).sum() + (v[rv] != gv[rv] * (r + 1.0)).sum())
+        bad += int((s11[:, rc] != (np.arange(M)[:, None] + 1.0) * (gc[None, rc] + 0.25 * r)).sum())
+    return bad
+
+
 def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, interval=None, cell_owner=None):
-    """One block per rank over RCCL: K steps of nsub subcycles; halos are `interval` layers deep and are
-    exchanged every `interval` subcycles (uVelocity, vVelocity, stress11/22/12)."""
+    """One block per rank: K steps of nsub subcycles; halos are `interval` layers deep and are exchanged every
+    `interval` subcycles (uVelocity, vVelocity, stress11/22/12).  Transport (SIH_TRANSPORT): "p2p", the library's
+    own (messages stored into the neighbours' IPC-mapped receive buffers, the whole loop with its exchanges
+    queued by sih_evp_subcycle_exchange), checked with known patterns before it is used; or "torch",
+    all_to_all_single of torch.distributed (RCCL), which is also the fall-back when the check fails."""
     import os
     import time
 
@@ -457,14 +488,13 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
 
     from . import velocity_solver as vs
     if interval is None:
-        # more ranks -> smaller blocks -> the exchange latency weighs more: deeper halos, fewer exchanges.
-        # Measured on one GPU (scripts/bench_block.py, QU60): a block of an 8-way partition needs 14.6 us per
-        # subcycle with 8 halo layers and 16.0 us with 16, pack + unpack cost 10 us per exchange; with a
-        # collective of 25 us or more per exchange the deeper halo wins at 8 ranks and 8 layers at 2 and 4.
-        default = 16 if int(os.environ.get("WORLD_SIZE", "1")) >= 8 else 8
-        interval = int(os.environ.get("SIH_HALO_INTERVAL", str(default)))
+        # Measured on one GPU (scripts/bench_block.py, QU60, block of an 8-way partition): 14.3 / 14.6 / 14.8 /
+        # 16.2 us per subcycle with 2 / 4 / 8 / 16 halo layers; an exchange costs the same two launches whatever
+        # the depth, so 8 layers win for any exchange cost between 5 and 20 us.
+        interval = int(os.environ.get("SIH_HALO_INTERVAL", "8"))
     use_graph = os.environ.get("SIH_MULTI_GRAPH", "1") != "0"
     backend = os.environ.get("SIH_DIST_BACKEND", "nccl")  # "gloo" only for rehearsals on a box with one GPU
+    transport = os.environ.get("SIH_TRANSPORT", "p2p")
     if not dist.is_initialized():
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -476,15 +506,34 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
         dist.all_reduce(t, op=op)
         return float(t.item())
     rank, world = dist.get_rank(), dist.get_world_size()
-    # the overlapped order costs two more launches per exchange (rim cells, send vertices: 11-14 us on a
-    # 25 k-cell block) and can hide at most the 13 us its interior pieces take: off unless asked for
     overlap = os.environ.get("SIH_OVERLAP", "0") != "0"
     cfg = {"config_elastic_subcycle_number": nsub, "config_num_halos": max(2, interval),
-           "config_halo_exchange_interval": interval, "config_overlap_halo_exchange": overlap}
+           "config_halo_exchange_interval": interval, "config_overlap_halo_exchange": overlap,
+           "config_subcycle_graph": use_graph}
     dom, halo, _ = make_partitioned_domain(mesh, name, world, configs=cfg, only_block=rank, cell_owner=cell_owner)
     vs.seaice_mesh_pool_create(dom, device=local_rank, renumber=renumber)
     ctx = dom.blocklist[0].ctx
-    dom.comm = DistComm(dom, halo, world, rank)  # also moves the block onto torch's (explicit) current stream
+    note = ""
+    if transport == "p2p":
+        ok = 1.0
+        try:
+            dom.comm = PeerComm(dom, halo, world, rank)
+        except Exception as e:  # noqa: BLE001 -- whatever fails, every rank must take the same branch
+            ok, note = 0.0, f"p2p set-up failed on rank {rank}: {e}"
+        if reduce_scalar(ok, dist.ReduceOp.MIN) < 1.0:
+            transport = "torch"
+        else:
+            bad = link_self_test(dom, halo, dom.comm)
+            try:
+                dom.comm.check(dom)
+            except Exception as e:  # noqa: BLE001
+                bad, note = bad + 1, str(e)
+            if reduce_scalar(float(bad), dist.ReduceOp.MAX) > 0.0:
+                transport, note = "torch", note or "p2p link check found wrong halo values"
+                dist.barrier()
+                ctx.comm_destroy()
+    if transport != "p2p":
+        dom.comm = DistComm(dom, halo, world, rank)  # also moves the block onto torch's (explicit) current stream
     vs.seaice_init_velocity_solver(dom)
     for b in dom.blocklist:
         vs._upload(dom, b)
@@ -493,11 +542,15 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
     t0 = time.perf_counter()
     vs.velocity_solver_pre_subcycle(dom)
     torch.cuda.synchronize()
+    ctx.sync()
     pre_ms = (time.perf_counter() - t0) * 1e3
     names = ["uVelocity", "vVelocity"] if interval == 1 else ["uVelocity", "vVelocity", "stress11", "stress22",
                                                                "stress12"]
 
     def step():
+        if transport == "p2p":
+            ctx.subcycle_exchange(nsub, last=False, interval=interval, overlap=overlap, use_graph=use_graph)
+            return
         if overlap:
             vs.subcycle_overlapped(dom, dom.comm, nsub, interval, names, use_graph=use_graph)
             return
@@ -510,33 +563,59 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
                 ctx.subcycle(m, last=False)
             done += m
             dom.comm.halo_exchange(dom, names)
+
+    def sync():
+        torch.cuda.synchronize()
+        ctx.sync()  # the block's own stream (the p2p transport does not run on torch's)
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    torch.cuda.synchronize()
+    sync()
     dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     wall = time.perf_counter() - t0
     wall = reduce_scalar(wall, dist.ReduceOp.MAX)
+    if transport == "p2p":
+        dom.comm.check(dom)  # raises if any message of the timed loop failed to arrive
     t0 = time.perf_counter()
     ctx.subcycle(1, last=True)
     dom.comm.halo_exchange(dom, names)
     vs.velocity_solver_post_subcycle(dom)
-    torch.cuda.synchronize()
+    sync()
     post_ms = (time.perf_counter() - t0) * 1e3
+    # the cost of one exchange: 50 of them queued back to back (each needs the neighbours' previous one, so the
+    # chain runs at the pace of launch + transfer + flag latency), host-timed over the whole chain
+    sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        dom.comm.halo_exchange(dom, names)
+    sync()
+    ex_us = reduce_scalar((time.perf_counter() - t0) / 50 * 1e6, dist.ReduceOp.MAX)
     _, cell_ms, vert_ms = ctx.subcycle_timed(8, use_graph=False, sample_every=1)
     u = np.zeros(dom.blocklist[0].dimensions["nVertices"] + 1)
     ctx.get("uVelocity", u)
     if reduce_scalar(1.0 if np.isfinite(u).all() else 0.0, dist.ReduceOp.MIN) < 1.0:
         raise SystemExit("non-finite velocities after the benchmark loop")
     n_block_cells = dom.blocklist[0].dimensions["nCells"]
+    if transport == "p2p":
+        dom.comm.check(dom)
+    dist.barrier()
     vs.seaice_mesh_pool_destroy(dom)
     dist.barrier()
+    real_backend = dist.get_backend()
     dist.destroy_process_group()
+    if transport == "p2p":
+        how = ("messages stored by the sender into the neighbours' IPC-mapped receive buffers (peer stores over xGMI), "
+               "sequence flags awaited on the device, iterations and exchanges replayed as HIP graphs")
+    else:
+        how = f"torch.distributed all_to_all_single over {real_backend}" + (" (RCCL)" if real_backend == "nccl" else "")
     return {"wall": wall, "pre_ms": pre_ms, "post_ms": post_ms, "cell_ms": cell_ms, "vert_ms": vert_ms,
-            "n_cells_total": int(mesh.nCells), "n_block_cells": int(n_block_cells), "interval": interval, "overlap": overlap, "graph": bool(use_graph)}
+            "n_cells_total": int(mesh.nCells), "n_block_cells": int(n_block_cells), "interval": interval,
+            "overlap": overlap, "graph": bool(use_graph), "transport": transport, "transport_text": how,
+            "transport_note": note, "exchange_us": ex_us, "rendezvous_backend": real_backend}
