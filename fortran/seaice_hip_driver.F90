@@ -4,8 +4,9 @@
 !> arrays with the Registry dimensions (src/Registry.xml:2251-2367, 2439-2524, 3691-3765); they are handed
 !> to the C ABI with c_loc, exactly as the shim hands the framework's pool arrays.
 !>
-!> usage: seaice_hip_driver <case file> <result file>
-!> The case file is a raw little-endian stream written by mpas_seaice_amd/fortran_case.py.
+!> usage: seaice_hip_driver <case file> <result file> [time]
+!> The case file is a raw little-endian stream written by mpas_seaice_amd/fortran_case.py.  With a third
+!> argument the driver also times a dynamics step as a host sees it, transfers included (time_host_step).
 program seaice_hip_driver
 
   use iso_c_binding
@@ -240,11 +241,124 @@ program seaice_hip_driver
   write(ou) upwindArea, upwindTemperature, upwindVolume, upwindSnow
   close(ou)
 
+  if (command_argument_count() >= 3) call time_host_step()
+
   ! ---- seaice_mesh_pool_destroy ---------------------------------------------------------------
   call check(sih_block_destroy(ctx), "sih_block_destroy")
   write(*,'(a,es23.15)') "seaice_hip_driver ok, max|uVelocity| = ", maxval(abs(uVelocity))
 
 contains
+
+  !> One dynamics step as the host model sees it: every input of seaice_run_velocity_solver goes to the device,
+  !> the solver runs (pre-cycle, the subcycles, post-cycle), every field the reference leaves in its pools comes
+  !> back -- the lists are those of the velocity-solver shim.  Timed three ways: one blocking call per field from
+  !> and to ordinary memory; one batched call each way (sih_fields_put / sih_fields_get) from and to page-locked
+  !> memory (sih_host_alloc); and the solver alone.
+  subroutine time_host_step()
+
+    integer, parameter :: nIn = 20, nOut = 44, nRep = 5
+    character(len=32), dimension(nIn), parameter :: inNames = [character(len=32) :: &
+         "iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory", "uOceanVelocity", "vOceanVelocity", &
+         "uAirVelocity", "vAirVelocity", "airDensity", "uVelocity", "vVelocity", "stressDivergenceU", &
+         "stressDivergenceV", "oceanStressU", "oceanStressV", "solveVelocityPrevious", "landIceMask", &
+         "landIceMaskVertex", "stress11", "stress22", "stress12"]
+    character(len=32), dimension(nOut), parameter :: outNames = [character(len=32) :: &
+         "uVelocity", "vVelocity", "uVelocityInitial", "vVelocityInitial", "icePressure", &
+         "stressDivergenceU", "stressDivergenceV", "airStressCellU", "airStressCellV", &
+         "airStressVertexU", "airStressVertexV", "uOceanVelocityVertex", "vOceanVelocityVertex", &
+         "oceanStressU", "oceanStressV", "oceanStressCoeff", "oceanStressCellU", "oceanStressCellV", &
+         "surfaceTiltForceU", "surfaceTiltForceV", "totalMassVertexfVertex", "divergence", "shear", &
+         "strain11", "strain22", "strain12", "stress11", "stress22", "stress12", "replacementPressure", &
+         "principalStress1", "principalStress2", &
+         "iceAreaVertex", "totalMassVertex", "iceAreaCellInitial", "totalMassCell", &
+         "iceAreaCell", "iceVolumeCell", "snowVolumeCell", "solveStress", "solveVelocity", &
+         "solveVelocityPrevious", "ridgeConvergence", "ridgeShear"]
+
+    character(len=33, kind=c_char), dimension(nIn + nOut), target :: names
+    type(c_ptr), dimension(nIn + nOut) :: namePtrs, pageable, pinned
+    integer(c_size_t), dimension(nIn + nOut) :: counts, offsets
+    integer(c_int) :: es
+    integer(c_size_t) :: total
+    integer(c_int8_t), dimension(:), allocatable, target :: arena
+    integer(c_int8_t), dimension(:), pointer :: pinnedArena
+    type(c_ptr) :: pinnedBase
+    integer(kind=8) :: t0, t1, rate
+    real(c_double) :: msPerField, msBatched, msCompute, mbIn, mbOut
+    integer :: i, rep
+
+    total = 0
+    mbIn = 0.0_c_double
+    mbOut = 0.0_c_double
+    do i = 1, nIn + nOut
+       if (i <= nIn) then
+          names(i) = trim(inNames(i)) // c_null_char
+       else
+          names(i) = trim(outNames(i - nIn)) // c_null_char
+       endif
+       namePtrs(i) = c_loc(names(i))
+       counts(i) = sih_field_count(ctx, names(i), es)
+       if (counts(i) == 0) then
+          write(*,*) "time_host_step: unknown field ", trim(names(i))
+          stop 1
+       endif
+       offsets(i) = total
+       total = total + ((counts(i) * es + 255_c_size_t) / 256_c_size_t) * 256_c_size_t
+       if (i <= nIn) then
+          mbIn = mbIn + real(counts(i) * es, c_double) / 1.0e6_c_double
+       else
+          mbOut = mbOut + real(counts(i) * es, c_double) / 1.0e6_c_double
+       endif
+    enddo
+    allocate(arena(total))
+    arena = 0_c_int8_t
+    call check(sih_host_alloc(pinnedBase, total), "sih_host_alloc")
+    call c_f_pointer(pinnedBase, pinnedArena, [total])
+    do i = 1, nIn + nOut
+       pageable(i) = c_loc(arena(offsets(i) + 1))
+       pinned(i) = c_loc(pinnedArena(offsets(i) + 1))
+    enddo
+    ! the inputs as they are on the device now, in both kinds of memory
+    call check(sih_fields_get(ctx, int(nIn, c_int), namePtrs, pageable, counts), "sih_fields_get")
+    call check(sih_fields_get(ctx, int(nIn, c_int), namePtrs, pinned, counts), "sih_fields_get")
+
+    call system_clock(count_rate=rate)
+    do rep = 0, nRep   ! rep 0 warms up
+       if (rep == 1) call system_clock(t0)
+       do i = 1, nIn
+          call check(sih_field_put(ctx, names(i), pageable(i), counts(i)), "sih_field_put")
+       enddo
+       call check(sih_evp_run(ctx), "sih_evp_run")
+       do i = nIn + 1, nIn + nOut
+          call check(sih_field_get(ctx, names(i), pageable(i), counts(i)), "sih_field_get")
+       enddo
+    enddo
+    call system_clock(t1)
+    msPerField = real(t1 - t0, c_double) / real(rate, c_double) * 1.0e3_c_double / nRep
+
+    do rep = 0, nRep
+       if (rep == 1) call system_clock(t0)
+       call check(sih_fields_put(ctx, int(nIn, c_int), namePtrs, pinned, counts), "sih_fields_put")
+       call check(sih_evp_run(ctx), "sih_evp_run")
+       call check(sih_fields_get(ctx, int(nOut, c_int), namePtrs(nIn+1:), pinned(nIn+1:), counts(nIn+1:)), "sih_fields_get")
+    enddo
+    call system_clock(t1)
+    msBatched = real(t1 - t0, c_double) / real(rate, c_double) * 1.0e3_c_double / nRep
+
+    do rep = 0, nRep
+       if (rep == 1) call system_clock(t0)
+       call check(sih_evp_run(ctx), "sih_evp_run")
+    enddo
+    call system_clock(t1)
+    msCompute = real(t1 - t0, c_double) / real(rate, c_double) * 1.0e3_c_double / nRep
+
+    write(*,'(a,i0,a,f8.1,a,f8.1,a)') "host step, ", nCells, " cells: ", mbIn, " MB up, ", mbOut, " MB down"
+    write(*,'(a,f10.3)') "host step ms, one blocking call per field, ordinary memory: ", msPerField
+    write(*,'(a,f10.3)') "host step ms, batched calls, page-locked memory: ", msBatched
+    write(*,'(a,f10.3)') "host step ms, solver alone: ", msCompute
+    call check(sih_host_free(pinnedBase), "sih_host_free")
+    deallocate(arena)
+
+  end subroutine time_host_step
 
   subroutine check(ierr, what)
     integer(c_int), intent(in) :: ierr

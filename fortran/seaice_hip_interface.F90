@@ -9,7 +9,7 @@ module seaice_hip_interface
   public
 
   integer(c_int), parameter :: SIH_OK = 0, SIH_ERR_ARG = 1, SIH_ERR_HIP = 2, SIH_ERR_STATE = 3, &
-                               SIH_ERR_UNSUPPORTED = 4, SIH_ERR_IR = 5
+                               SIH_ERR_UNSUPPORTED = 4, SIH_ERR_IR = 5, SIH_ERR_COMM = 6
 
   !> struct sih_mesh_desc
   type, bind(C) :: sih_mesh_desc
@@ -382,6 +382,112 @@ module seaice_hip_interface
        type(c_ptr), value :: phaseMs5
        integer(c_int) :: ierr
      end function sih_ir_run_timed
+
+     function sih_device_count() bind(C, name="sih_device_count") result(n)
+       import :: c_int
+       integer(c_int) :: n
+     end function sih_device_count
+
+     function sih_field_get_noalloc(ctx, name, host, count) bind(C, name="sih_field_get_noalloc") result(ierr)
+       import :: c_int, c_ptr, c_char, c_size_t
+       type(c_ptr), value :: ctx
+       character(kind=c_char), dimension(*), intent(in) :: name
+       type(c_ptr), value :: host
+       integer(c_size_t), value :: count
+       integer(c_int) :: ierr
+     end function sih_field_get_noalloc
+
+     ! the reference's two public operators on their own (velocity_solver_variational.F:575, :1064)
+     function sih_evp_strain_tensor(ctx) bind(C, name="sih_evp_strain_tensor") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int) :: ierr
+     end function sih_evp_strain_tensor
+
+     function sih_evp_stress_divergence(ctx) bind(C, name="sih_evp_stress_divergence") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int) :: ierr
+     end function sih_evp_stress_divergence
+
+     ! ---- halo exchange inside the library (the transport of mpas_dmpar_exch_group_full_halo_exch) ----
+     function sih_comm_handle_size() bind(C, name="sih_comm_handle_size") result(n)
+       import :: c_size_t
+       integer(c_size_t) :: n
+     end function sih_comm_handle_size
+
+     function sih_comm_create(ctx, rank, nRanks, maxCellPlanes, maxVertexPlanes) bind(C, name="sih_comm_create") &
+          result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: rank, nRanks, maxCellPlanes, maxVertexPlanes
+       integer(c_int) :: ierr
+     end function sih_comm_create
+
+     function sih_comm_get_handle(ctx, handle) bind(C, name="sih_comm_get_handle") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, handle
+       integer(c_int) :: ierr
+     end function sih_comm_get_handle
+
+     function sih_comm_connect(ctx, allHandles) bind(C, name="sih_comm_connect") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, allHandles
+       integer(c_int) :: ierr
+     end function sih_comm_connect
+
+     function sih_comm_destroy(ctx) bind(C, name="sih_comm_destroy") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int) :: ierr
+     end function sih_comm_destroy
+
+     function sih_halo_exchange(ctx, nFields, names) bind(C, name="sih_halo_exchange") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nFields
+       type(c_ptr), dimension(*), intent(in) :: names
+       integer(c_int) :: ierr
+     end function sih_halo_exchange
+
+     function sih_halo_exchange_start(ctx, nFields, names) bind(C, name="sih_halo_exchange_start") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nFields
+       type(c_ptr), dimension(*), intent(in) :: names
+       integer(c_int) :: ierr
+     end function sih_halo_exchange_start
+
+     function sih_halo_exchange_finish(ctx, nFields, names) bind(C, name="sih_halo_exchange_finish") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nFields
+       type(c_ptr), dimension(*), intent(in) :: names
+       integer(c_int) :: ierr
+     end function sih_halo_exchange_finish
+
+     function sih_comm_set_timeout(ctx, milliseconds) bind(C, name="sih_comm_set_timeout") result(ierr)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: milliseconds
+       integer(c_int) :: ierr
+     end function sih_comm_set_timeout
+
+     function sih_comm_status(ctx) bind(C, name="sih_comm_status") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int) :: ierr
+     end function sih_comm_status
+
+     !> n iterations of single_subcycle_velocity_solver with the halo update of uVelocity / vVelocity after every
+     !> `interval` of them (velocity_solver.F:2478-2592), all on the device
+     function sih_evp_subcycle_exchange(ctx, n, last, interval, overlap, useGraph) &
+          bind(C, name="sih_evp_subcycle_exchange") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n, last, interval, overlap, useGraph
+       integer(c_int) :: ierr
+     end function sih_evp_subcycle_exchange
 
      function sih_get_info(ctx, key, value) bind(C, name="sih_get_info") result(ierr)
        import :: c_int, c_ptr, c_char, c_double

@@ -1,7 +1,9 @@
 ! Declarations of the parts of the MPAS framework, and of the one sea-ice module that stays in the build, which
 ! fortran/shim/*.F use: types with the components the shims touch and procedures with empty bodies.  Their only
 ! purpose is `make check-shims` (amdflang -fsyntax-only), which type-checks the shim modules against these
-! interfaces; nothing here is linked, run, or a substitute for the framework.
+! interfaces, and `make check-abort-path`, which links the advection shim with them to walk its error path on the
+! CPU: for that the handful of procedures the path goes through answer with fixed values and the log and abort
+! routines print what they are asked to do.  Nothing here is a substitute for the framework.
 
 module mpass_derived_types
   implicit none
@@ -18,20 +20,42 @@ module mpass_derived_types
   type MPAS_Clock_type
      integer :: direction = 0
   end type MPAS_Clock_type
+  ! exchange lists of a field (mpas_derived_types of the framework): per halo layer a linked list over the
+  ! neighbouring processes; endPointID is the neighbour's rank, srcList / destList pair local entries with
+  ! positions in the message buffer
+  type mpas_exchange_list
+     integer :: endPointID, nList
+     integer, dimension(:), pointer :: srcList => null(), destList => null()
+     type(mpas_exchange_list), pointer :: next => null()
+  end type mpas_exchange_list
+  type mpas_exchange_list_pointer
+     type(mpas_exchange_list), pointer :: exchList => null()
+  end type mpas_exchange_list_pointer
+  type mpas_multihalo_exchange_list
+     type(mpas_exchange_list_pointer), dimension(:), pointer :: halos => null()
+  end type mpas_multihalo_exchange_list
+  type field1DReal
+     real(kind=RKIND), dimension(:), pointer :: array => null()
+     type(mpas_multihalo_exchange_list), pointer :: sendList => null(), recvList => null(), copyList => null()
+  end type field1DReal
   type field3DReal
      real(kind=RKIND), dimension(:,:,:), pointer :: array => null()
   end type field3DReal
+  type MPAS_streamManager_type
+     integer :: numStreams = 0
+  end type MPAS_streamManager_type
   type block_type
      type(MPAS_pool_type), pointer :: structs => null(), dimensions => null(), configs => null()
      type(block_type), pointer :: prev => null(), next => null()
   end type block_type
   type dm_info
-     integer :: nprocs = 1, my_proc_id = 0
+     integer :: nprocs = 1, my_proc_id = 0, comm = 0
   end type dm_info
   type domain_type
      type(block_type), pointer :: blocklist => null()
      type(MPAS_pool_type), pointer :: configs => null()
      type(dm_info), pointer :: dminfo => null()
+     type(MPAS_streamManager_type), pointer :: streamManager => null()
   end type domain_type
 end module mpass_derived_types
 
@@ -48,20 +72,28 @@ module mpass_pool_routines
      module procedure dim_0
   end interface MPAS_pool_get_dimension
   interface MPAS_pool_get_field
-     module procedure fld_r3
+     module procedure fld_r3, fld_r1
   end interface MPAS_pool_get_field
+  ! fixed answers for check-abort-path
+  logical, target, save :: yes = .true., no = .false.
+  real(kind=RKIND), target, save :: someReal = 900.0_RKIND
+  real(kind=RKIND), dimension(4), target, save :: someVector = 0.0_RKIND
+  character(len=StrKIND), target, save :: someString
+  type(MPAS_pool_type), target, save :: somePool
 contains
   subroutine get_r0(inPool, key, scalar, timeLevel)
     type(MPAS_pool_type), intent(in) :: inPool
     character(len=*), intent(in) :: key
     real(kind=RKIND), pointer :: scalar
     integer, intent(in), optional :: timeLevel
+    scalar => someReal   ! e.g. dynamicsTimeStep
   end subroutine get_r0
   subroutine get_r1(inPool, key, array, timeLevel)
     type(MPAS_pool_type), intent(in) :: inPool
     character(len=*), intent(in) :: key
     real(kind=RKIND), dimension(:), pointer :: array
     integer, intent(in), optional :: timeLevel
+    array => someVector
   end subroutine get_r1
   subroutine get_r2(inPool, key, array, timeLevel)
     type(MPAS_pool_type), intent(in) :: inPool
@@ -101,11 +133,18 @@ contains
     type(MPAS_pool_type), intent(in) :: inPool
     character(len=*), intent(in) :: key
     logical, pointer :: value
+    if (key == "config_use_advection" .or. key == "config_full_abort_write") then
+       value => yes
+    else
+       value => no
+    endif
   end subroutine cfg_l
   subroutine cfg_c(inPool, key, value)
     type(MPAS_pool_type), intent(in) :: inPool
     character(len=*), intent(in) :: key
     character(len=StrKIND), pointer :: value
+    someString = "incremental_remap"   ! config_advection_type
+    value => someString
   end subroutine cfg_c
   subroutine dim_0(inPool, key, dim)
     type(MPAS_pool_type), intent(in) :: inPool
@@ -118,15 +157,23 @@ contains
     type(field3DReal), pointer :: field
     integer, intent(in), optional :: timeLevel
   end subroutine fld_r3
+  subroutine fld_r1(inPool, key, field, timeLevel)
+    type(MPAS_pool_type), intent(in) :: inPool
+    character(len=*), intent(in) :: key
+    type(field1DReal), pointer :: field
+    integer, intent(in), optional :: timeLevel
+  end subroutine fld_r1
   subroutine MPAS_pool_get_subpool(inPool, key, subPool)
     type(MPAS_pool_type), intent(in) :: inPool
     character(len=*), intent(in) :: key
     type(MPAS_pool_type), pointer :: subPool
+    subPool => somePool
   end subroutine MPAS_pool_get_subpool
   subroutine MPAS_pool_get_field_info(inPool, key, info)
     type(MPAS_pool_type), intent(in) :: inPool
     character(len=*), intent(in) :: key
     type(MPAS_pool_field_info_type), intent(out) :: info
+    info % fieldType = 0; info % nDims = 1; info % nTimeLevels = 1; info % nHaloLayers = 0; info % isActive = .true.
   end subroutine MPAS_pool_get_field_info
   subroutine MPAS_pool_shift_time_levels(inPool)
     type(MPAS_pool_type), intent(inout) :: inPool
@@ -161,6 +208,11 @@ contains
     real(kind=RKIND), dimension(:), intent(in), optional :: realArgs
     logical, dimension(:), intent(in), optional :: logicArgs
     integer, intent(out), optional :: err
+    integer :: kind
+    kind = MPAS_LOG_OUT
+    if (present(messageType)) kind = messageType
+    write(*,'(a,i0,2a)') "mpas_log_write type ", kind, ": ", trim(message)
+    if (kind == MPAS_LOG_CRIT) stop 3   ! the framework aborts the run here
   end subroutine mpas_log_write
 end module mpass_log
 
@@ -192,6 +244,34 @@ contains
     integer, dimension(:), intent(in), optional :: haloLayersIn
   end subroutine exch_r3
 end module mpass_dmpar
+
+! the constants of the MPI library's own module that seaice_hip_transfer names; MPI_Allgather, MPI_Barrier,
+! MPI_Comm_split_type, MPI_Comm_rank and MPI_Comm_free are called through implicit interfaces, as with most
+! implementations of that module
+module mpi
+  implicit none
+  integer, parameter :: MPI_SUCCESS = 0, MPI_BYTE = 1, MPI_COMM_TYPE_SHARED = 2, MPI_INFO_NULL = 3
+end module mpi
+
+! src/shared/mpas_seaice_error.F:44, :80 of the reference: stays in the build, called by the advection shim
+module seaice_error
+  use mpass_derived_types
+  implicit none
+contains
+  subroutine seaice_critical_error_write_block(domain, block, abortFlag)
+    type(domain_type), intent(in) :: domain
+    type(block_type), intent(in) :: block
+    logical, intent(in) :: abortFlag
+    write(*,'(a,l1)') "seaice_critical_error_write_block abortFlag=", abortFlag
+  end subroutine seaice_critical_error_write_block
+  subroutine seaice_check_critical_error(domain, abortFlag)
+    use mpass_log, only: mpas_log_write
+    type(domain_type), intent(in) :: domain
+    logical, intent(in) :: abortFlag
+    write(*,'(a,l1)') "seaice_check_critical_error (vote of all ranks) abortFlag=", abortFlag
+    if (abortFlag) call mpas_log_write("Runtime error", messageType=MPAS_LOG_CRIT)   ! mpas_seaice_error.F:111
+  end subroutine seaice_check_critical_error
+end module seaice_error
 
 module mpass_rbf_interpolation
   use mpass_derived_types

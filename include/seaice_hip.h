@@ -130,6 +130,9 @@ typedef struct sih_evp_config {
 /* replaces seaice_mesh_pool_create (mesh_pool.F:76): uploads connectivity/geometry, builds the
  * internal numbering.  `device` is the HIP device ordinal. */
 int sih_block_create(const sih_mesh_desc *mesh, int device, sih_ctx **ctx);
+/* number of HIP devices this process sees (0 when there is none): a host with one rank per GPU takes
+ * device = node-local rank modulo this count */
+int sih_device_count(void);
 /* replaces seaice_mesh_pool_destroy (mesh_pool.F:188) */
 int sih_block_destroy(sih_ctx *ctx);
 const char *sih_last_error(void);

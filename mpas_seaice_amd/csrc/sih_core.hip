@@ -451,6 +451,16 @@ extern "C" int sih_block_destroy(sih_ctx *c)
     return SIH_OK;
 }
 
+extern "C" int sih_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
 extern "C" int sih_set_stream(sih_ctx *c, void *s)
 {
     if (!c) return SIH_ERR_ARG;

@@ -82,7 +82,7 @@ EXPORTS = [
     "sih_evp_strain_tensor", "sih_evp_stress_divergence",
     "sih_comm_handle_size", "sih_comm_create", "sih_comm_get_handle", "sih_comm_connect", "sih_comm_destroy",
     "sih_halo_exchange", "sih_halo_exchange_start", "sih_halo_exchange_finish", "sih_comm_set_timeout",
-    "sih_comm_status", "sih_evp_subcycle_exchange", "sih_field_get_noalloc",
+    "sih_comm_status", "sih_evp_subcycle_exchange", "sih_field_get_noalloc", "sih_device_count",
 ]
 
 
@@ -105,6 +105,7 @@ def load():
         pass
     lib = ctypes.CDLL(LIB_PATH)
     lib.sih_last_error.restype = ctypes.c_char_p
+    lib.sih_device_count.argtypes = []
     lib.sih_field_count.restype = ctypes.c_size_t
     lib.sih_field_count.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
     lib.sih_block_create.argtypes = [ctypes.POINTER(MeshDesc), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]

@@ -54,3 +54,29 @@ def test_fortran_shims_typecheck():
                        timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "error" not in r.stderr.lower(), r.stderr[-2000:]
+
+
+def test_advection_shim_keeps_the_reference_abort_convention():
+    """A forced run-time abort of the remap (the library call replaced by one that returns SIH_ERR_IR) takes the
+    advection shim through the reference's sequence (mpas_seaice_advection_incremental_remap.F:3182-3183,
+    mpas_seaice_error.F:44-115): the message as an error, seaice_critical_error_write_block for the failing block,
+    seaice_check_critical_error -- the vote every rank takes part in -- and only inside it the critical stop."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fc = "/opt/rocm/lib/llvm/bin/amdflang"
+    if not os.path.exists(fc) or shutil.which("make") is None or shutil.which("gcc") is None:
+        pytest.skip("amdflang, gcc or make not available")
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib/llvm/lib:/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run(["make", "-C", os.path.join(root, "fortran"), "check-abort-path"], capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln.strip() for ln in r.stdout.splitlines()]
+    want = ["mpas_log_write type 3: IR: Negative mass in IR",
+            "seaice_critical_error_write_block abortFlag=T",
+            "seaice_check_critical_error (vote of all ranks) abortFlag=T",
+            "mpas_log_write type 4: Runtime error"]
+    pos = [lines.index(w) for w in want]
+    assert pos == sorted(pos), lines
+    assert "seaice_run_advection returned" not in r.stdout  # the failing rank stops inside the vote routine

@@ -56,3 +56,31 @@ def test_fortran_driver_matches_oracle(oracle, tmp_path):
         err = np.abs(got[key] - r).max() / np.abs(r).max()
         assert err <= 1e-10, (key, err)
     assert np.abs(got["upwindVolume"]).max() > 0.0
+
+
+def test_fortran_host_step_with_transfers_at_qu60(tmp_path):
+    """A dynamics step at QU60 (120 subcycles) as a Fortran host sees it, every input uploaded and every pool field of
+    the reference downloaded: the batched calls from page-locked memory, which the shim modules use, against one
+    blocking call per field from ordinary memory."""
+    if not os.path.exists(EXE):
+        pytest.fail("fortran/seaice_hip_driver is not built (run __graft_entry__.build())")
+    mesh = get_mesh("QU60")
+    dom = cases.make_domain(mesh, "QU60")
+    case = str(tmp_path / "case.bin")
+    fortran_case.write_case(case, dom.blocklist[0], dom.configs)
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib/llvm/lib:/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    out = subprocess.run([EXE, case, str(tmp_path / "result.bin"), "time"], capture_output=True, text=True,
+                         timeout=280, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    ms = {}
+    for ln in out.stdout.splitlines():
+        if ln.startswith("host step ms, "):
+            k, v = ln[len("host step ms, "):].rsplit(":", 1)
+            ms[k.strip()] = float(v)
+    print(out.stdout)
+    per_field = ms["one blocking call per field, ordinary memory"]
+    batched = ms["batched calls, page-locked memory"]
+    alone = ms["solver alone"]
+    assert alone < batched < per_field
+    assert batched <= 14.0, ms  # 7 ms of solver + 69 MB up + 137 MB down over the host link
