@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libseaice_hip.so")
+LIB_PATH = os.environ.get("SIH_LIB_PATH") or os.path.join(_HERE, "libseaice_hip.so")  # SIH_LIB_PATH: another build
 _lib = None
 
 
