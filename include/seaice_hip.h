@@ -240,6 +240,15 @@ int sih_evp_subcycle(sih_ctx *ctx, int n, int last);
 /* the same n iterations (last = 0) replayed from a HIP graph captured on first use; asynchronous on the
  * context's stream.  For blocks so small that launch overhead dominates (many-GPU strong scaling). */
 int sih_evp_subcycle_graph(sih_ctx *ctx, int n);
+/* the same n iterations in ONE launch of a persistent kernel: every workgroup keeps a tile of 64 cells and the
+ * vertices it owns on the chip for all iterations (basis tables, stresses and vertex constants in registers) and
+ * waits only for the neighbouring tiles it reads from.  For blocks small enough to be resident at once (about
+ * 30 000 cells; sih_get_info "persistentKernel" = 1), where the two-kernel form is bound by its kernel boundaries
+ * and by re-reading tables that never change.  Same bits as sih_evp_subcycle.  With the environment variable
+ * SIH_PERSISTENT=1, sih_evp_subcycle_graph, sih_evp_run and sih_evp_subcycle_exchange use it by themselves where a
+ * block qualifies.  Returns SIH_ERR_UNSUPPORTED where it does not; a launch that cannot complete (its waits are
+ * bounded) is reported by sih_sync / sih_evp_run as SIH_ERR_STATE. */
+int sih_evp_subcycle_persistent(sih_ctx *ctx, int n);
 /* Pieces of one subcycle iteration (none the last of the dynamics step), for a host that overlaps the
  * halo exchange the reference does after every iteration (velocity_solver.F:2543-2584) with work that
  * needs no halo value.  sih_evp_overlap_setup derives four entity subsets from the lists given to
@@ -443,7 +452,7 @@ int sih_upwind_run(sih_ctx *ctx, double dt, int checks);
  * nCategories values each */
 int sih_upwind_get_sums(sih_ctx *ctx, const char *tracer, double *initSums, double *finalSums);
 
-/* introspection for tests and reports.  Keys: sparseGradient, splitCellKernel, dampingTimescale,
+/* introspection for tests and reports.  Keys: sparseGradient, splitCellKernel, persistentKernel, dampingTimescale,
  * elasticTimeStep, dynamicsTimeStep, numericalInertiaCoefficient, padC, padV, minDvEdge, and
  * irRecoverMeansWarnings (see sih_ir_run), irFluxWalk (1 when the flux kernel that walks the tracer tree is in use:
  * every tracer with children has one layer and there are at most 32 layer fields), irCflWarnings: number of vertices whose departure distance in the last sih_ir_run exceeded the

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libseaice_hip.so")
 SOURCES = ["sih_core.hip", "evp_init.hip", "evp_step.hip", "evp_weak.hip", "ir_advect.hip", "upwind_advect.hip",
-           "halo_exchange.hip"]
+           "halo_exchange.hip", "evp_persist.hip"]
 
 
 def hipcc():

@@ -772,7 +772,7 @@ extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
         return SIH_ERR_ARG;
     }
     sih_drop_graphs(c);  // whatever was captured holds launches of the previous kernel variants
-    return SIH_OK;
+    return sih_persist_setup(c);  // tile tables of the persistent subcycle kernel, if the block qualifies
 }
 
 extern "C" int sih_evp_static_changed(sih_ctx *c)
@@ -785,5 +785,6 @@ extern "C" int sih_evp_static_changed(sih_ctx *c)
     InitArgs a = makeInitArgs(c);
     int rc = packStatic(c, a);
     sih_drop_graphs(c);  // whatever was captured holds launches of the previous kernel variants
-    return rc;
+    if (rc) return rc;
+    return sih_persist_setup(c);
 }

@@ -1241,6 +1241,16 @@ extern "C" int sih_evp_apply_special_boundaries(sih_ctx *c)
     return SIH_OK;
 }
 
+// SIH_PERSISTENT=1: blocks that qualify run their subcycle loops in the persistent kernel (evp_persist.hip)
+static bool usePersistent(sih_ctx *c)
+{
+    static const bool on = [] {
+        const char *e = getenv("SIH_PERSISTENT");
+        return e && atoi(e) != 0;
+    }();
+    return on && sih_persist_usable(c);
+}
+
 extern "C" int sih_evp_subcycle(sih_ctx *c, int n, int last)
 {
     int rc = checkInit(c, "sih_evp_subcycle");
@@ -1334,7 +1344,7 @@ extern "C" int sih_evp_run(sih_ctx *c)
         return rc;
     if ((rc = sih_evp_post_subcycle(c, -1))) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
-    return SIH_OK;
+    return sih_persist_status(c);
 }
 
 static int ensureEvents(sih_ctx *c, size_t n)
@@ -1357,6 +1367,7 @@ extern "C" int sih_evp_subcycle_graph(sih_ctx *c, int n)
         return SIH_ERR_ARG;
     }
     beginSubcycles(c);
+    if (usePersistent(c)) return sih_persist_launch(c, n);  // small block: the whole loop as one resident launch
     if (!c->graphExec || c->graphN != n) {
         if (c->graphExec) {
             (void)hipGraphExecDestroy(c->graphExec);
@@ -1375,6 +1386,25 @@ extern "C" int sih_evp_subcycle_graph(sih_ctx *c, int n)
     }
     HIPCHK(hipGraphLaunch(c->graphExec, c->stream));
     return SIH_OK;
+}
+
+// n iterations (none the last of the dynamics step) in the persistent kernel; an error if the block does not
+// qualify for it (sih_get_info "persistentKernel")
+extern "C" int sih_evp_subcycle_persistent(sih_ctx *c, int n)
+{
+    int rc = checkInit(c, "sih_evp_subcycle_persistent");
+    if (rc) return rc;
+    if (n < 1) {
+        sih_set_error("sih_evp_subcycle_persistent: n must be >= 1");
+        return SIH_ERR_ARG;
+    }
+    if (!sih_persist_usable(c)) {
+        sih_set_error("sih_evp_subcycle_persistent: this block does not qualify (too many cells to stay resident, "
+                      "or an option that needs the two-kernel form)");
+        return SIH_ERR_UNSUPPORTED;
+    }
+    beginSubcycles(c);
+    return sih_persist_launch(c, n);
 }
 
 // ---------------------------------------------------------------------------- special boundaries
@@ -1599,9 +1629,13 @@ static int queueChunk(sih_ctx *c, int m, bool overlap, bool pendingIn, bool more
 {
     int rc;
     if (!overlap) {
-        for (int it = 0; it < m; it++) {
-            launchCellKernel(c, false);
-            launchVertexKernel(c, false);
+        if (usePersistent(c)) {
+            if ((rc = sih_persist_launch(c, m))) return rc;
+        } else {
+            for (int it = 0; it < m; it++) {
+                launchCellKernel(c, false);
+                launchVertexKernel(c, false);
+            }
         }
         if ((rc = sih_comm_push(c, nNames, names, c->stream))) return rc;
         if ((rc = sih_comm_pull(c, nNames, names, c->stream))) return rc;

@@ -420,6 +420,7 @@ extern "C" int sih_block_destroy(sih_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     if (c->graphExec) (void)hipGraphExecDestroy(c->graphExec);
     sih_comm_free(c);
+    sih_persist_destroy(c);
     sih_ir_destroy(c);
     sih_weak_destroy(c);
     sih_upwind_destroy(c);
@@ -481,7 +482,7 @@ extern "C" int sih_sync(sih_ctx *c)
     if (!c) return SIH_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return SIH_OK;
+    return sih_persist_status(c);  // a persistent launch that gave up is reported here
 }
 
 // Page-locked host memory for the arrays a host exchanges with the library every step.  Transfers from and
@@ -1048,6 +1049,11 @@ extern "C" int sih_get_info(sih_ctx *c, const char *key, double *value)
     else if (k == "irRecoverMeansWarnings") *value = sih_ir_recover_warnings(c);
     else if (k == "irFluxWalk") *value = sih_ir_flux_walk(c);
     else if (k == "splitCellKernel") *value = c->splitCells ? 1.0 : 0.0;
+    else if (k == "persistentKernel") *value = sih_persist_usable(c) ? 1.0 : 0.0;
+    else if (k == "persistentPerCU") *value = sih_persist_info(c, 0);
+    else if (k == "persistentReason") *value = sih_persist_info(c, 1);
+    else if (k == "persistentTiles") *value = sih_persist_info(c, 2);
+    else if (k == "persistentArrived") *value = sih_persist_info(c, 3);
     else {
         sih_set_error("sih_get_info: unknown key " + k);
         return SIH_ERR_ARG;

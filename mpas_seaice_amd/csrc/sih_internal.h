@@ -72,6 +72,7 @@ struct sih_ctx {
     struct sih_ir_state *ir = nullptr;                       // incremental-remap advection state
     struct sih_weak_state *weak = nullptr;                   // weak strain / stress-divergence scheme
     struct sih_upwind_state *upwind = nullptr;               // upwind advection state
+    struct sih_persist_state *persist = nullptr;             // persistent subcycle kernel (small blocks)
     struct sih_comm_state *comm = nullptr;                   // halo exchange with blocks of other processes / devices
     std::map<std::string, SihField> fields;
     std::vector<void *> allocs;
@@ -131,6 +132,12 @@ void sih_ir_destroy(sih_ctx *c);
 void sih_weak_destroy(sih_ctx *c);
 void sih_upwind_destroy(sih_ctx *c);
 void sih_comm_free(sih_ctx *c);
+void sih_persist_destroy(sih_ctx *c);
+int sih_persist_setup(sih_ctx *c);
+bool sih_persist_usable(sih_ctx *c);
+int sih_persist_launch(sih_ctx *c, int n);
+int sih_persist_status(sih_ctx *c);
+double sih_persist_info(sih_ctx *c, int what);
 int sih_comm_push(sih_ctx *c, int nFields, const char *const *names, hipStream_t stream);
 int sih_comm_pull(sih_ctx *c, int nFields, const char *const *names, hipStream_t stream);
 int sih_comm_prepare(sih_ctx *c, int nFields, const char *const *names);  // builds the group's tables (not capturable)

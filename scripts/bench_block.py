@@ -51,6 +51,12 @@ def timed(fn, n):
 out = {"cells_in_block": b.dimensions["nCells"], "owned": b.dimensions["nCellsSolve"], "interval": k}
 out["plain_us_per_subcycle"] = timed(lambda: ctx.subcycle(k), args.chunks) / k
 out["graph_us_per_subcycle"] = timed(lambda: ctx.subcycle_graph(k), args.chunks) / k
+out["persistent_kernel"] = ctx.info("persistentKernel")
+out["persistent_per_cu"], out["persistent_reason"] = ctx.info("persistentPerCU"), ctx.info("persistentReason")
+out["persistent_tiles"], out["persistent_arrived"] = ctx.info("persistentTiles"), ctx.info("persistentArrived")
+if out["persistent_kernel"]:
+    out["persistent_us_per_subcycle"] = timed(lambda: ctx.subcycle_persistent(k), args.chunks) / k
+    out["persistent_us_per_subcycle_120"] = timed(lambda: ctx.subcycle_persistent(120), 20) / 120
 body = [CR, VA] + [CA, VA] * (k - 2) + [CA, VS]
 tail = [VR, CI]
 
