@@ -8,30 +8,33 @@
 // the three integral matrices in LDS.  A tile solves the velocities of ALL vertices of its cells itself (those
 // it shares with neighbouring tiles are solved by each of them, from the same operands, to the same bits), so
 // the velocities never leave the chip: per iteration only the per-corner partial sums of the stress divergence
-// pass through memory, and a tile waits for exactly the tiles whose partial sums it reads (per-tile iteration
-// counters), never for the whole grid -- one hand-off per iteration.
+// pass through memory, and a vertex waits for exactly the sums it reads, never for the whole grid -- one hand-off
+// per iteration, with the arrival of the data as its own signal.
 //
 // The arithmetic is that of k_sub_cells_split / k_sub_vertices, statement for statement, so the results are
 // the same bits.  Iterations that store the end-of-step diagnostics (the last one of a dynamics step) stay with
 // the two-kernel form.
 //
 // Hand-off rules (per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed):
-//   - the partial sums are written with agent-scope atomic stores (write-through), every storing wave drains
-//     them (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, then one lane publishes the tile's iteration
-//     counter with the same kind of store;
-//   - a reader polls the counters of the tiles it depends on with agent-scope atomic loads (one lane per
-//     counter), the workgroup meets at a barrier, then reads the sums with agent-scope atomic loads (L1
-//     bypassed), optionally behind an agent-scope acquire fence (SIH_PERSIST_ACQUIRE=1);
-//   - the sums live in two buffers used in turn: a tile overwrites what it wrote two iterations ago, which every
-//     reader has finished with, because the tile has since seen that reader's counter move on;
+//   - the sums live in three buffers used in turn (iteration number modulo 3).  At the top of iteration t a corner
+//     stores a marker (a NaN bit pattern that arithmetic never produces) into its slot of buffer t+1, drains that
+//     store (s_waitcnt vmcnt(0)) and only then stores its sums of iteration t into buffer t; all of these are
+//     agent-scope atomic stores (write-through);
+//   - a vertex reads its three sums of iteration t with agent-scope atomic loads (L1 bypassed) again and again
+//     until none of them is the marker.  It cannot meet older data: it read the same three slots of buffer t-1
+//     one iteration ago, and their writers had the marker of buffer t acknowledged before they stored those;
+//   - a corner may overwrite buffer t+1 (the sums of iteration t-2): a reader of those is a tile that shares the
+//     vertex, whose sums of iteration t-1 this tile has read since, and that tile stored them only after all its
+//     vertices had finished iteration t-2;
 //   - every wait is bounded by the wall clock; a wait that runs out sets a status word, every workgroup leaves
-//     the loop, and the host reports it.  All workgroups must be resident together: the launch is sized by the
-//     occupancy the runtime reports, the kernel begins with a census (every workgroup checks in and waits for
-//     the others), and a probe launch at set-up settles whether this grid fits before it is ever used.
+//     the loop at the end of its iteration, and the host reports it.  All workgroups must be resident together:
+//     the launch is sized by the occupancy the runtime reports, the kernel begins with a census (every workgroup
+//     marks its slots of the first buffer, checks in -- 32 counters in separate cache lines, so that the check-ins
+//     do not queue behind one address -- and waits for the others), and a probe launch at set-up settles whether
+//     this grid fits before it is ever used.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
-#include <set>
 
 #include "sih_internal.h"
 
@@ -42,18 +45,18 @@
 #define SIN_TURN 0.0
 #define COS_TURN 1.0
 
-enum { PS_EPOCH = 0, PS_LAUNCHES = 1, PS_ARRIVE = 2, PS_FINISH = 3, PS_STATUS = 4, PS_TICKS = 5, PS_WORDS = 16 };
+// words of the state array; the census counters sit 128 bytes apart behind the first line
+enum { PS_EPOCH = 0, PS_LAUNCHES = 1, PS_STATUS = 2, PS_TICKS = 3, PS_CENSUS = 16, PS_CENSUS_N = 32, PS_CENSUS_STRIDE = 16,
+       PS_WORDS = PS_CENSUS + PS_CENSUS_N * PS_CENSUS_STRIDE };
+#define PS_MARKER 0xFFF8C0DEDEADBEEFULL  // "not written yet": a NaN with a payload no operation produces
 
 struct PersistArgs {
     int nTiles;
     const int *tileVertStart, *tileVerts;  // vertices of a tile's cells: tileVerts[tileVertStart[t] .. tileVertStart[t+1])
     const int *tileVertOwned;              // same indexing: 1 where this tile is the one that stores the vertex at the end
     const int *cornerSlot;                 // per (corner, cell) [g * padC + c]: position of its vertex in the tile's list
-    const int *depStart, *dep;             // tiles whose partial sums a tile's vertices read
-    unsigned int *cellDone;                // per tile: last iteration (absolute number) whose sums are published
-    double *partU2, *partV2;               // the second buffer of the partial sums (odd iterations)
+    unsigned long long *part;              // the partial sums: [buffer 0..2][U, V][corner * padC + cell]
     unsigned long long *state;             // PS_* words
-    int acquire;                           // agent-scope acquire fence after every wait
 };
 
 // what the kernel reads of SihDev, and nothing else: the fewer scalar registers the arguments take, the more
@@ -65,7 +68,7 @@ struct PersistDev {
     const double *tanLat, *varDenom, *gradU3, *gradV3, *SU, *SV, *SM, *icePressure;
     const double *totalMassVertex, *massF, *airVertU, *airVertV, *tiltForceU, *tiltForceV, *ocnStressU, *ocnStressV;
     const double *uOcnVert, *vOcnVert, *iceAreaVertex, *uInit, *vInit;
-    double *u, *v, *stress11, *stress22, *stress12, *partU, *partV;
+    double *u, *v, *stress11, *stress22, *stress12;
 };
 
 static PersistDev makePersistDev(const SihDev &d)
@@ -82,7 +85,6 @@ static PersistDev makePersistDev(const SihDev &d)
     q.tiltForceU = d.tiltForceU; q.tiltForceV = d.tiltForceV; q.ocnStressU = d.ocnStressU; q.ocnStressV = d.ocnStressV;
     q.uOcnVert = d.uOcnVert; q.vOcnVert = d.vOcnVert; q.iceAreaVertex = d.iceAreaVertex; q.uInit = d.uInit; q.vInit = d.vInit;
     q.u = d.u; q.v = d.v; q.stress11 = d.stress11; q.stress22 = d.stress22; q.stress12 = d.stress12;
-    q.partU = d.partU; q.partV = d.partV;
     return q;
 }
 
@@ -90,57 +92,22 @@ struct sih_persist_state {
     PersistArgs a{};
     int capacity = 0;  // workgroups the device holds at once
     int arrived = 0;
-    int perCU = 0, reason = 0;  // why not usable: 1 option, 2 too many tiles, 3 vertices per tile, 4 dependencies, 5 probe
+    int perCU = 0, reason = 0;  // why not usable: 1 option, 2 too many tiles, 3 vertices per tile, 5 probe
     bool usable = false;
     std::vector<void *> allocs;
 };
 
-__device__ inline double ldAgent(const double *p)
+__device__ inline unsigned long long ldAgent(const unsigned long long *p)
 {
-    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT));
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ inline void stAgent(double *p, double x)
+__device__ inline void stAgent(unsigned long long *p, unsigned long long x)
 {
-    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ inline unsigned long long bitsOf(double x) { return (unsigned long long)__double_as_longlong(x); }
+__device__ inline double valueOf(unsigned long long b) { return __longlong_as_double((long long)b); }
 __device__ inline double sign1p(double x) { return copysign(1.0, x); }
-
-// wave 0 polls cnt[dep[j]] (lane j) until every one has reached `target`; the verdict reaches the whole
-// workgroup through LDS.  Returns false when the time limit ran out or another workgroup has given up.
-__device__ inline bool waitTiles(const unsigned int *cnt, const int *dep, int nDep, unsigned int target,
-                                 unsigned long long *state, unsigned long long limit, int *okShared, int tid,
-                                 int acquire)
-{
-    if (tid < 64) {
-        bool good = true;
-        const long long t0 = wall_clock64();
-        for (int base = 0; base < nDep && good; base += 64) {
-            const int j = base + tid;
-            const unsigned int *w = cnt + (j < nDep ? dep[j] : dep[base]);
-            for (;;) {
-                // signed distance: the counters are absolute iteration numbers that may wrap
-                const int behind = (int)(target - __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                if (__all(behind <= 0)) break;
-                if ((unsigned long long)(wall_clock64() - t0) > limit ||
-                    __hip_atomic_load(&state[PS_STATUS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ULL) {
-                    good = false;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
-        if (!good && tid == 0)
-            __hip_atomic_fetch_max(&state[PS_STATUS], 2ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid == 0) *okShared = good ? 1 : 0;
-        if (acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    const bool ok = *okShared != 0;
-    __syncthreads();  // okShared may be rewritten by the next wait
-    return ok;
-}
 
 // At most 128 vector registers a lane (launch bound of four waves a SIMD), so that two workgroups of 6 waves are
 // resident on a CU wherever the hardware starts placing their waves; at 3 waves a SIMD the second workgroup was
@@ -163,7 +130,7 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
     double(*s12)[64] = (double(*)[64])(smem + 4 * M * 64);
     double *uT = smem + 5 * M * 64, *vT = uT + 64 * M;       // velocities of the tile's vertices
     double(*sInt)[64 * M] = (double(*)[64 * M])(vT + 64 * M);  // this thread's rows of basisIntegralsU / V / Metric
-    __shared__ int okShared;
+    __shared__ int okShared, sDead;
     const int lane = threadIdx.x, g = threadIdx.y, tid = g * 64 + lane;
     // consecutive tiles on one XCD (workgroups are dealt round-robin over the eight XCDs): neighbouring tiles then
     // mostly hand their sums over through one L2
@@ -173,29 +140,9 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
         const int b = blockIdx.x, q = nT / 8, r = nT % 8, x = b % 8;
         tile = x * q + (x < r ? x : r) + b / 8;
     }
-    const unsigned long long limit = __hip_atomic_load(&p.state[PS_TICKS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-    // ---- census: every workgroup of the launch is resident before anything is computed
-    const unsigned long long launches = __hip_atomic_load(&p.state[PS_LAUNCHES], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long epoch = __hip_atomic_load(&p.state[PS_EPOCH], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid == 0) {
-        int good = __hip_atomic_load(&p.state[PS_STATUS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ULL;
-        __hip_atomic_fetch_add(&p.state[PS_ARRIVE], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long want = (launches + 1ULL) * (unsigned long long)nT;
-        const long long t0 = wall_clock64();
-        while (good && __hip_atomic_load(&p.state[PS_ARRIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-            if ((unsigned long long)(wall_clock64() - t0) > limit ||
-                __hip_atomic_load(&p.state[PS_STATUS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ULL) {
-                __hip_atomic_fetch_max(&p.state[PS_STATUS], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                good = 0;
-            }
-            __builtin_amdgcn_s_sleep(8);
-        }
-        okShared = good;
-    }
-    __syncthreads();
-    bool alive = okShared != 0;
-    __syncthreads();
+    const unsigned long long limit = ldAgent(&p.state[PS_TICKS]);
+    const unsigned long long launches = ldAgent(&p.state[PS_LAUNCHES]);
+    const unsigned long long epoch = ldAgent(&p.state[PS_EPOCH]);  // iterations done by earlier launches
 
     // ---- what this thread keeps for all iterations: its cell corner ...
     const int P = d.padC, PV = d.padV;
@@ -284,17 +231,61 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
     }
     uT[tid] = uu;
     vT[tid] = vv;
+    if (tid == 0) sDead = 0;
+    const size_t plane = (size_t)M * P;  // one buffer holds 2 planes of this size: U, then V
+    // ---- census: every workgroup of the launch is resident, and has marked its slots of the first buffer, before
+    //      anything is computed
+    {
+        unsigned long long *b1 = p.part + ((epoch + 1ULL) % 3ULL) * 2ULL * plane;
+        if (corner) {
+            stAgent(&b1[k], PS_MARKER);
+            stAgent(&b1[plane + k], PS_MARKER);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
-    const int *dep = p.dep + p.depStart[tile];
-    const int nDep = p.depStart[tile + 1] - p.depStart[tile];
+    if (tid < 64) {
+        bool good = ldAgent(&p.state[PS_STATUS]) == 0ULL;
+        if (tid == 0)
+            __hip_atomic_fetch_add(&p.state[PS_CENSUS + (blockIdx.x % PS_CENSUS_N) * PS_CENSUS_STRIDE], 1ULL,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // lane j watches counter j: the workgroups with blockIdx % 32 == j check in there
+        const int j = tid % PS_CENSUS_N;
+        const unsigned long long want =
+            (launches + 1ULL) * (unsigned long long)(nT / PS_CENSUS_N + (j < nT % PS_CENSUS_N ? 1 : 0));
+        const long long t0 = wall_clock64();
+        while (good) {
+            const unsigned long long have = ldAgent(&p.state[PS_CENSUS + j * PS_CENSUS_STRIDE]);
+            if (__all(have >= want)) break;
+            if ((unsigned long long)(wall_clock64() - t0) > limit || ldAgent(&p.state[PS_STATUS]) != 0ULL) {
+                if (tid == 0)
+                    __hip_atomic_fetch_max(&p.state[PS_STATUS], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                good = false;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (tid == 0) okShared = good ? 1 : 0;
+    }
+    __syncthreads();
+    const bool alive = okShared != 0;
+    // every workgroup read the two words before it checked in, so one of them may move them on for the next launch
+    if (alive && tile == 0 && tid == 0) {
+        stAgent(&p.state[PS_EPOCH], epoch + (unsigned long long)nIter);
+        stAgent(&p.state[PS_LAUNCHES], launches + 1ULL);
+    }
     const double dtE = d.dtE, T = d.dampT, brlx = d.brlx, dtD = d.dtDyn;
     const int relation = d.relation;
-    const unsigned int e0 = (unsigned int)epoch;
+    int sl = (int)(epoch % 3ULL);  // buffer of the iteration before the one at hand
 
     for (int it = 1; it <= nIter && alive; it++) {
-        const unsigned int target = e0 + (unsigned int)it;
-        double *pU = (target & 1u) ? p.partU2 : d.partU, *pV = (target & 1u) ? p.partV2 : d.partV;
+        sl = sl == 2 ? 0 : sl + 1;
+        unsigned long long *pU = p.part + (size_t)sl * 2 * plane, *pV = pU + plane;
         // ================= cells: strain, stress, partial sums of the divergence (k_sub_cells_split)
+        if (corner) {
+            unsigned long long *nU = p.part + (size_t)(sl == 2 ? 0 : sl + 1) * 2 * plane;
+            stAgent(&nU[k], PS_MARKER);
+            stAgent(&nU[plane + k], PS_MARKER);
+        }
         const double ug = uT[slot], vg = vT[slot];
         su[g][lane] = corner ? ug : 0.0;
         sv[g][lane] = corner ? vg : 0.0;
@@ -358,27 +349,54 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
                     cv = cv - x22 * bv - x12 * bu + x11 * bm * tg;
                 }
             }
-            stAgent(&pU[k], cu);
-            stAgent(&pV[k], cv);
+            // the markers of the next buffer are in memory before these sums can be seen
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stAgent(&pU[k], bitsOf(cu));
+            stAgent(&pV[k], bitsOf(cv));
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(&p.cellDone[tile], target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
         // ================= vertices: divergence, ocean stress coefficient, velocity solve (k_sub_vertices), for
-        // every vertex of the tile's cells
-        alive = waitTiles(p.cellDone, dep, nDep, target, p.state, limit, &okShared, tid, p.acquire);
-        if (!alive) break;
+        // every vertex of the tile's cells, as soon as its three pairs of sums have arrived
+        unsigned long long bu0 = 0, bu1 = 0, bu2 = 0, bv0 = 0, bv1 = 0, bv2 = 0;
+        {
+            long long t0 = 0;
+            for (int spins = 1;; spins++) {
+                bool ready = true;
+                if (solV) {
+                    bu0 = ldAgent(&pU[q0]);
+                    bu1 = ldAgent(&pU[q1]);
+                    bu2 = ldAgent(&pU[q2]);
+                    bv0 = ldAgent(&pV[q0]);
+                    bv1 = ldAgent(&pV[q1]);
+                    bv2 = ldAgent(&pV[q2]);
+                    ready = bu0 != PS_MARKER && bu1 != PS_MARKER && bu2 != PS_MARKER && bv0 != PS_MARKER &&
+                            bv1 != PS_MARKER && bv2 != PS_MARKER;
+                }
+                if (__all(ready)) break;
+                if ((spins & 7) == 0) {
+                    const long long now = wall_clock64();
+                    if (t0 == 0) {
+                        t0 = now;
+                    } else if ((unsigned long long)(now - t0) > limit || ldAgent(&p.state[PS_STATUS]) != 0ULL) {
+                        // give up: this iteration runs to its end on whatever was read, then everyone leaves
+                        if (lane == 0) {
+                            __hip_atomic_fetch_max(&p.state[PS_STATUS], 2ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            sDead = 1;
+                        }
+                        break;
+                    }
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
         if (solV) {
             double dU = 0.0, dV = 0.0;
-            const double pu0 = ldAgent(&pU[q0]), pu1 = ldAgent(&pU[q1]), pu2 = ldAgent(&pU[q2]);
-            const double pv0 = ldAgent(&pV[q0]), pv1 = ldAgent(&pV[q1]), pv2 = ldAgent(&pV[q2]);
-            dU = dU + pu0;
-            dV = dV + pv0;
-            dU = dU + pu1;
-            dV = dV + pv1;
-            dU = dU + pu2;
-            dV = dV + pv2;
+            dU = dU + valueOf(bu0);
+            dV = dV + valueOf(bv0);
+            dU = dU + valueOf(bu1);
+            dV = dV + valueOf(bv1);
+            dU = dU + valueOf(bu2);
+            dV = dV + valueOf(bv2);
             dU = dU / den0;
             dV = dV / den0;
             double coeff = 0.0;
@@ -415,10 +433,11 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
             }
         }
         __syncthreads();
+        if (sDead) break;  // the same answer in every thread: written before the barrier, not again after it
     }
 
     // ---- stresses and velocities go back to memory for whatever runs next (the last iteration of the step, an
-    //      exchange); the last sums stay in their buffers, nothing reads them before the next cell kernel
+    //      exchange)
     if (alive) {
         if (corner) {
             d.stress11[k] = o11;
@@ -428,16 +447,6 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
         if (owned && solV && relation != 3) {
             d.u[v] = uu;
             d.v[v] = vv;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned long long old =
-            __hip_atomic_fetch_add(&p.state[PS_FINISH], 1ULL, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == (launches + 1ULL) * (unsigned long long)nT - 1ULL) {
-            // the last workgroup out moves the iteration base and the launch count on for the next launch
-            __hip_atomic_store(&p.state[PS_EPOCH], epoch + (unsigned long long)nIter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&p.state[PS_LAUNCHES], launches + 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -521,12 +530,10 @@ int sih_persist_setup(sih_ctx *c)
             if (v < nV) cellsOfVertex[v].push_back(i);
         }
     std::vector<int> vStart(nT + 1, 0), verts, ownedFlag, slot((size_t)M * c->padC, 0);
-    std::vector<int> dStart(nT + 1, 0), dList;
     {
         std::vector<int> where(nV, -1);  // position of a vertex in the current tile's list
         for (int t = 0; t < nT; t++) {
             const int first = (int)verts.size();
-            std::set<int> deps;
             for (int i = t * 64; i < std::min(nC, (t + 1) * 64); i++)
                 for (int sIdx = 0; sIdx < c->hNe[i]; sIdx++) {
                     const int v = c->hVoc[(size_t)sIdx * c->padC + i];
@@ -535,10 +542,7 @@ int sih_persist_setup(sih_ctx *c)
                         where[v] = (int)verts.size();
                         verts.push_back(v);
                         int low = nC;
-                        for (int cc : cellsOfVertex[v]) {
-                            low = std::min(low, cc);
-                            deps.insert(cc / 64);
-                        }
+                        for (int cc : cellsOfVertex[v]) low = std::min(low, cc);
                         ownedFlag.push_back(low / 64 == t ? 1 : 0);
                     }
                     slot[(size_t)sIdx * c->padC + i] = where[v] - first;
@@ -548,37 +552,22 @@ int sih_persist_setup(sih_ctx *c)
                 s->reason = 3;
                 return SIH_OK;
             }
-            if (deps.size() > 256) {
-                s->reason = 4;
-                return SIH_OK;
-            }
-            dList.insert(dList.end(), deps.begin(), deps.end());
-            dStart[t + 1] = (int)dList.size();
         }
     }
     if (verts.empty()) {
         verts.push_back(0);
         ownedFlag.push_back(0);
     }
-    if (dList.empty()) dList.push_back(0);
-    // the second buffer of the partial sums
-    if ((rc = sih_add_field(c, "_partU2", LOC_CELL, M, false))) return rc;
-    if ((rc = sih_add_field(c, "_partV2", LOC_CELL, M, false))) return rc;
+    // the three buffers of the partial sums, zero where no corner ever writes (the slot that stands for "no cell")
+    if ((rc = sih_add_field(c, "_partRing", LOC_CELL, 6 * M, false))) return rc;
     PersistArgs &a = s->a;
     a.nTiles = nT;
-    a.partU2 = (double *)sih_find_field(c, "_partU2")->d;
-    a.partV2 = (double *)sih_find_field(c, "_partV2")->d;
+    a.part = (unsigned long long *)sih_find_field(c, "_partRing")->d;
     if ((rc = upload(s, &a.tileVertStart, vStart))) return rc;
     if ((rc = upload(s, &a.tileVerts, verts))) return rc;
     if ((rc = upload(s, &a.tileVertOwned, ownedFlag))) return rc;
     if ((rc = upload(s, &a.cornerSlot, slot))) return rc;
-    if ((rc = upload(s, &a.depStart, dStart))) return rc;
-    if ((rc = upload(s, &a.dep, dList))) return rc;
     void *q = nullptr;
-    HIPCHK(hipMalloc(&q, sizeof(unsigned int) * (size_t)nT));
-    s->allocs.push_back(q);
-    HIPCHK(hipMemset(q, 0, sizeof(unsigned int) * (size_t)nT));
-    a.cellDone = (unsigned int *)q;
     HIPCHK(hipMalloc(&q, sizeof(unsigned long long) * PS_WORDS));
     s->allocs.push_back(q);
     HIPCHK(hipMemset(q, 0, sizeof(unsigned long long) * PS_WORDS));
@@ -586,7 +575,6 @@ int sih_persist_setup(sih_ctx *c)
     unsigned long long ticks = 2ULL * 100000000ULL;  // 2 s of the 100 MHz wall clock
     if (const char *e = getenv("SIH_PERSIST_TIMEOUT_MS")) ticks = (unsigned long long)(atof(e) * 100000.0);
     HIPCHK(hipMemcpy(a.state + PS_TICKS, &ticks, sizeof ticks, hipMemcpyHostToDevice));
-    a.acquire = getenv("SIH_PERSIST_ACQUIRE") ? atoi(getenv("SIH_PERSIST_ACQUIRE")) : 0;
     // probe: a launch of zero iterations runs the census only.  If its workgroups are not all resident together it
     // says so within the time limit and the two-kernel form stays in use.
     s->usable = true;
@@ -598,9 +586,9 @@ int sih_persist_setup(sih_ctx *c)
     if (st != 0) {
         s->usable = false;
         s->reason = 5;
-        unsigned long long arr = 0;
-        HIPCHK(hipMemcpy(&arr, a.state + PS_ARRIVE, sizeof arr, hipMemcpyDeviceToHost));
-        s->arrived = (int)arr;
+        std::vector<unsigned long long> w(PS_WORDS);
+        HIPCHK(hipMemcpy(w.data(), a.state, sizeof(unsigned long long) * PS_WORDS, hipMemcpyDeviceToHost));
+        for (int j = 0; j < PS_CENSUS_N; j++) s->arrived += (int)w[PS_CENSUS + j * PS_CENSUS_STRIDE];
     }
     return SIH_OK;
 }
