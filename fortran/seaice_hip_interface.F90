@@ -270,6 +270,15 @@ module seaice_hip_interface
        integer(c_int) :: ierr
      end function sih_evp_subcycle_graph
 
+     ! n iterations in one launch of the persistent kernel (small blocks; SIH_ERR_UNSUPPORTED where a block does
+     ! not qualify: query sih_get_info "persistentKernel")
+     function sih_evp_subcycle_persistent(ctx, n) bind(C, name="sih_evp_subcycle_persistent") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n
+       integer(c_int) :: ierr
+     end function sih_evp_subcycle_persistent
+
      function sih_ir_init(ctx, desc) bind(C, name="sih_ir_init") result(ierr)
        import :: sih_ir_desc, c_int, c_ptr
        type(c_ptr), value :: ctx

@@ -240,14 +240,19 @@ int sih_evp_subcycle(sih_ctx *ctx, int n, int last);
 /* the same n iterations (last = 0) replayed from a HIP graph captured on first use; asynchronous on the
  * context's stream.  For blocks so small that launch overhead dominates (many-GPU strong scaling). */
 int sih_evp_subcycle_graph(sih_ctx *ctx, int n);
-/* the same n iterations in ONE launch of a persistent kernel: every workgroup keeps a tile of 64 cells and the
- * vertices it owns on the chip for all iterations (basis tables, stresses and vertex constants in registers) and
- * waits only for the neighbouring tiles it reads from.  For blocks small enough to be resident at once (about
- * 30 000 cells; sih_get_info "persistentKernel" = 1), where the two-kernel form is bound by its kernel boundaries
- * and by re-reading tables that never change.  Same bits as sih_evp_subcycle.  With the environment variable
- * SIH_PERSISTENT=1, sih_evp_subcycle_graph, sih_evp_run and sih_evp_subcycle_exchange use it by themselves where a
- * block qualifies.  Returns SIH_ERR_UNSUPPORTED where it does not; a launch that cannot complete (its waits are
- * bounded) is reported by sih_sync / sih_evp_run as SIH_ERR_STATE. */
+/* the same n iterations in ONE launch of a persistent kernel: every workgroup keeps a tile of 64 cells and all the
+ * vertices of those cells on the chip for all iterations (basis gradients, stresses and vertex constants in
+ * registers, integral rows and velocities in LDS); only the per-corner sums of the stress divergence pass through
+ * memory, and a vertex waits only for the sums it reads.  For blocks small enough to be resident at once (two
+ * workgroups a CU: 32 768 cells on 256 CUs; sih_get_info "persistentKernel" = 1), where the two-kernel form is
+ * bound by its kernel boundaries and by re-reading tables that never change.  Same bits as sih_evp_subcycle.
+ * sih_evp_subcycle_graph, sih_evp_run and sih_evp_subcycle_exchange use it by themselves for loops of two or more
+ * iterations where a block qualifies and its context is the only one of the process on the device (the launches
+ * of other blocks would take the places of its workgroups); the environment variable SIH_PERSISTENT=0 switches that off;
+ * sih_evp_subcycle_exchange then exchanges between the chunks without overlap.  Returns SIH_ERR_UNSUPPORTED where
+ * the block does not qualify; a launch that cannot complete (its waits are bounded: SIH_PERSIST_TIMEOUT_MS,
+ * default 2000) is reported by sih_sync / sih_evp_run as SIH_ERR_STATE.  The GPU must not be shared with other
+ * work that could keep some of the workgroups from being resident. */
 int sih_evp_subcycle_persistent(sih_ctx *ctx, int n);
 /* Pieces of one subcycle iteration (none the last of the dynamics step), for a host that overlaps the
  * halo exchange the reference does after every iteration (velocity_solver.F:2543-2584) with work that

@@ -94,6 +94,7 @@ struct sih_persist_state {
     int arrived = 0;
     int perCU = 0, reason = 0;  // why not usable: 1 option, 2 too many tiles, 3 vertices per tile, 5 probe
     bool usable = false;
+    bool unchecked = false;  // a launch since the status word was last read
     std::vector<void *> allocs;
 };
 
@@ -599,7 +600,8 @@ double sih_persist_info(sih_ctx *c, int what)
     return what == 0 ? c->persist->perCU : what == 1 ? c->persist->reason : what == 2 ? c->persist->a.nTiles : c->persist->arrived;
 }
 
-bool sih_persist_usable(sih_ctx *c) { return c->persist && c->persist->usable; }
+// the kernel reads the compact gradients: a put of a basis array switches it off until sih_evp_static_changed()
+bool sih_persist_usable(sih_ctx *c) { return c->persist && c->persist->usable && c->sparseGrad; }
 
 template <int M>
 static void launchPersist(sih_ctx *c, int n)
@@ -620,14 +622,16 @@ int sih_persist_launch(sih_ctx *c, int n)
         default: launchPersist<8>(c, n); break;
     }
     HIPCHK(hipGetLastError());
+    c->persist->unchecked = true;
     return SIH_OK;
 }
 
 // waits for the stream; SIH_ERR_STATE if a launch gave up (workgroups not resident together, or a wait ran out)
 int sih_persist_status(sih_ctx *c)
 {
-    if (!sih_persist_usable(c)) return SIH_OK;
+    if (!sih_persist_usable(c) || !c->persist->unchecked) return SIH_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
+    c->persist->unchecked = false;
     unsigned long long st = 0;
     HIPCHK(hipMemcpy(&st, c->persist->a.state + PS_STATUS, sizeof st, hipMemcpyDeviceToHost));
     if (st) {

@@ -1241,14 +1241,18 @@ extern "C" int sih_evp_apply_special_boundaries(sih_ctx *c)
     return SIH_OK;
 }
 
-// SIH_PERSISTENT=1: blocks that qualify run their subcycle loops in the persistent kernel (evp_persist.hip)
-static bool usePersistent(sih_ctx *c)
+// Blocks that qualify run loops of two or more iterations in the persistent kernel (evp_persist.hip): a launch of
+// it costs about as much as one iteration of the two-kernel form before the first iteration starts.
+// Only while this context is the only one of the process on its device: the kernel needs all its workgroups resident
+// together, and the launches of other blocks (each on its own stream) would take their places.
+// SIH_PERSISTENT=0 keeps the two-kernel form everywhere.
+static bool usePersistent(sih_ctx *c, int iterations)
 {
     static const bool on = [] {
         const char *e = getenv("SIH_PERSISTENT");
-        return e && atoi(e) != 0;
+        return !(e && atoi(e) == 0);
     }();
-    return on && sih_persist_usable(c);
+    return on && iterations >= 2 && sih_persist_usable(c) && sih_live_contexts(c->device) == 1;
 }
 
 extern "C" int sih_evp_subcycle(sih_ctx *c, int n, int last)
@@ -1367,7 +1371,7 @@ extern "C" int sih_evp_subcycle_graph(sih_ctx *c, int n)
         return SIH_ERR_ARG;
     }
     beginSubcycles(c);
-    if (usePersistent(c)) return sih_persist_launch(c, n);  // small block: the whole loop as one resident launch
+    if (usePersistent(c, n)) return sih_persist_launch(c, n);  // small block: the whole loop as one resident launch
     if (!c->graphExec || c->graphN != n) {
         if (c->graphExec) {
             (void)hipGraphExecDestroy(c->graphExec);
@@ -1629,7 +1633,7 @@ static int queueChunk(sih_ctx *c, int m, bool overlap, bool pendingIn, bool more
 {
     int rc;
     if (!overlap) {
-        if (usePersistent(c)) {
+        if (usePersistent(c, m)) {
             if ((rc = sih_persist_launch(c, m))) return rc;
         } else {
             for (int it = 0; it < m; it++) {
@@ -1703,6 +1707,9 @@ extern "C" int sih_evp_subcycle_exchange(sih_ctx *c, int n, int last, int interv
         return SIH_ERR_UNSUPPORTED;
     }
     HIPCHK(hipSetDevice(c->device));
+    // a block small enough for the persistent kernel gains more from it than from hiding the exchange behind the
+    // pieces of the two-kernel form (8-way block of QU60: 8.4 us an iteration against 17.8)
+    if (overlap && usePersistent(c, std::min(interval, last ? n - 1 : n))) overlap = 0;
     static const char *uv[2] = {"uVelocity", "vVelocity"};
     static const char *uvs[5] = {"uVelocity", "vVelocity", "stress11", "stress22", "stress12"};
     const char *const *names = interval == 1 ? uv : uvs;
@@ -1715,7 +1722,8 @@ extern "C" int sih_evp_subcycle_exchange(sih_ctx *c, int n, int last, int interv
         const int m = std::min(interval, nMain - done);
         const bool more = done + m < nMain;
         if (useGraph) {
-            std::vector<int> key = {-1000, m, overlap ? 1 : 0, pending ? 1 : 0, more ? 1 : 0, c->sparseGrad ? 1 : 0};
+            std::vector<int> key = {-1000, m, overlap ? 1 : 0, pending ? 1 : 0, more ? 1 : 0, c->sparseGrad ? 1 : 0,
+                                    usePersistent(c, m) ? 1 : 0};
             auto it = c->partGraphs.find(key);
             if (it == c->partGraphs.end()) {
                 hipGraph_t graph;

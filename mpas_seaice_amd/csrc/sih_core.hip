@@ -1,5 +1,6 @@
 // Context, device field registry, layout conversion and halo pack/unpack of libseaice_hip.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -162,6 +163,11 @@ static uint64_t mortonKey(double x, double y, double z)
 extern "C" int sih_block_destroy(sih_ctx *c);
 static int resolveScratch(int device);
 
+// contexts alive per device in this process: a kernel that needs the whole device to itself (evp_persist.hip) is
+// only chosen while its context is the only one
+static std::atomic<int> g_liveCtx[SIH_MAX_DEVICES];
+int sih_live_contexts(int device) { return device >= 0 && device < SIH_MAX_DEVICES ? g_liveCtx[device].load() : 2; }
+
 extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **out)
 {
     if (!m || !out) {
@@ -194,6 +200,10 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
         }
     } guard{c};
     c->device = device;
+    if (device >= 0 && device < SIH_MAX_DEVICES) {
+        g_liveCtx[device]++;
+        c->counted = true;
+    }
     HIPCHK(hipStreamCreate(&c->ownStream));
     c->stream = c->ownStream;
     c->nCells = m->nCells;
@@ -448,6 +458,7 @@ extern "C" int sih_block_destroy(sih_ctx *c)
                 if (kv.second.d_base[a][b]) (void)hipFree(kv.second.d_base[a][b]);
     }
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
+    if (c->counted) g_liveCtx[c->device]--;
     delete c;
     return SIH_OK;
 }

@@ -80,6 +80,7 @@ struct sih_ctx {
     size_t arenaSize = 0, arenaUsed = 0;
     sih_evp_config cfg{};
     bool inited = false, sparseGrad = false;
+    bool counted = false;  // in the per-device count of live contexts
     bool splitCells = false;  // cell kernel with one thread per (cell, corner) instead of one per cell
     double minDvEdge = 0.0;
     SihDev dev{};
@@ -124,6 +125,8 @@ struct sih_ctx {
 };
 
 void sih_set_error(const std::string &s);
+#define SIH_MAX_DEVICES 64
+int sih_live_contexts(int device);  // contexts of this process on a device (2 for a device number out of range)
 void sih_drop_graphs(sih_ctx *c);  // captured graphs no longer match what a launch would queue
 SihField *sih_find_field(sih_ctx *c, const char *name);
 int sih_add_field(sih_ctx *c, const char *name, SihLoc loc, int lead, bool isInt);
