@@ -263,6 +263,30 @@ module seaice_hip_interface
        integer(c_int) :: ierr
      end function sih_halo_unpack
 
+     ! hand-off to the column package's ridging: host(S, nCategories, nCells) records of the listed fields for
+     ! the host cells firstCell .. firstCell+nCells-1 (0-based), gathered / scattered on the device
+     function sih_column_get(ctx, nFields, names, nCategories, firstCell, nCells, host, count) &
+          bind(C, name="sih_column_get") result(ierr)
+       import :: c_int, c_ptr, c_size_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nFields, nCategories, firstCell, nCells
+       type(c_ptr), dimension(*), intent(in) :: names
+       type(c_ptr), value :: host
+       integer(c_size_t), value :: count
+       integer(c_int) :: ierr
+     end function sih_column_get
+
+     function sih_column_put(ctx, nFields, names, nCategories, firstCell, nCells, host, count) &
+          bind(C, name="sih_column_put") result(ierr)
+       import :: c_int, c_ptr, c_size_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nFields, nCategories, firstCell, nCells
+       type(c_ptr), dimension(*), intent(in) :: names
+       type(c_ptr), value :: host
+       integer(c_size_t), value :: count
+       integer(c_int) :: ierr
+     end function sih_column_put
+
      function sih_evp_subcycle_graph(ctx, n) bind(C, name="sih_evp_subcycle_graph") result(ierr)
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx

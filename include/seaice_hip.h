@@ -211,6 +211,26 @@ int sih_field_get(sih_ctx *ctx, const char *name, void *host, size_t count);
 int sih_fields_put(sih_ctx *ctx, int nFields, const char *const *names, const void *const *hosts,
                    const size_t *counts);
 int sih_fields_get(sih_ctx *ctx, int nFields, const char *const *names, void *const *hosts, const size_t *counts);
+/* Hand-off to the column package between advection and ridging (seaice_column_dynamics_time_integration,
+ * mpas_seaice_time_integration.F:158 -> column_ridging, mpas_seaice_column.F:3391-3560), which works cell by cell
+ * on the owned cells and takes, per cell, ridgeConvergence / ridgeShear (written by the velocity solver's
+ * final_divergence_shear, mpas_seaice_velocity_solver_variational.F:1300-1319), the category arrays
+ * iceAreaCategory(1,:,iCell) ... and trcrn(nTracers, nCategories) assembled from the tracer fields by
+ * set_cice_physics_tracer_array_category (mpas_seaice_column.F:6534-6575).  Instead of downloading every tracer
+ * field whole (halo cells included) and assembling on the host, sih_column_get gathers on the device, for host
+ * cells [firstCell, firstCell + nCells) (0-based; the owned cells are 0 .. nCellsSolve-1), one record per cell:
+ *     host[((cell - firstCell) * nCategories + category) * S + slot]
+ * where the listed fields' layers follow each other in list order (S = sum of their layer counts; a field of
+ * leading size lead has lead / nCategories layers).  In Fortran that is host(S, nCategories, nCells): host(:,:,i)
+ * is colpkg_step_ridge's trcrn for cell i when the names are given in the reference's tracer order, and with
+ * nCategories = 1 and the names ridgeConvergence, ridgeShear it is host(2, 1, nCells).  sih_column_put is the way
+ * back (get_cice_physics_tracer_array_category, :6723-6760): the device fields of those cells take the values of
+ * the records, so the next velocity solve and advection see what the ridging left, and nothing else is touched.
+ * count = nCells * nCategories * S, checked. */
+int sih_column_get(sih_ctx *ctx, int nFields, const char *const *names, int nCategories, int firstCell, int nCells,
+                   double *host, size_t count);
+int sih_column_put(sih_ctx *ctx, int nFields, const char *const *names, int nCategories, int firstCell, int nCells,
+                   const double *host, size_t count);
 /* sih_field_get for callers that cannot allocate: code under HIP graph capture elsewhere in the process, tight
  * serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  The layout conversion is
  * staged in a 16 MiB array that is part of the library's code object on every GPU, so the call makes no

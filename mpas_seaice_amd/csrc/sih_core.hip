@@ -590,6 +590,102 @@ static int putgetMany(sih_ctx *c, int nf, const char *const *names, void *const 
     return SIH_OK;
 }
 
+// ---- hand-off to the column package (ridging) ----------------------------------------------------------------
+// One record per owned cell in the layout colpkg_step_ridge takes its arguments in (column.F:3465-3530): for cell
+// h, category cat, the listed fields' layers one after the other -- trcrn(nt, ncat) of that cell is then one
+// contiguous piece of the host buffer.  Only cells [firstCell, firstCell + nCells) in host numbering travel.
+__global__ void k_column_get(double *__restrict__ dst, const double *__restrict__ src, const int *__restrict__ perm,
+                             int nAll, int L, int nCat, int pad, int S, int slot0, int cell0, int n)
+{
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)nAll * L * nCat) return;
+    const int l = (int)(t / nAll), i = (int)(t % nAll);
+    const int h = (perm ? perm[i] : i) - cell0;
+    if (h < 0 || h >= n) return;
+    const int cat = l / L, layer = l - cat * L;
+    dst[((size_t)h * nCat + cat) * S + slot0 + layer] = src[(size_t)l * pad + i];
+}
+
+__global__ void k_column_put(double *__restrict__ dst, const double *__restrict__ src, const int *__restrict__ perm,
+                             int nAll, int L, int nCat, int pad, int S, int slot0, int cell0, int n)
+{
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)nAll * L * nCat) return;
+    const int l = (int)(t / nAll), i = (int)(t % nAll);
+    const int h = (perm ? perm[i] : i) - cell0;
+    if (h < 0 || h >= n) return;
+    const int cat = l / L, layer = l - cat * L;
+    dst[(size_t)l * pad + i] = src[((size_t)h * nCat + cat) * S + slot0 + layer];
+}
+
+static int columnMove(sih_ctx *c, int nf, const char *const *names, int nCat, int firstCell, int nCells, double *host,
+                      size_t count, bool put)
+{
+    const char *who = put ? "sih_column_put" : "sih_column_get";
+    if (!c || nf < 1 || !names || !host || nCat < 1 || firstCell < 0 || nCells < 0 || firstCell + nCells > c->nCells) {
+        sih_set_error(std::string(who) + ": bad argument");
+        return SIH_ERR_ARG;
+    }
+    std::vector<SihField *> fs(nf);
+    std::vector<int> slot0(nf, 0);
+    int S = 0;
+    for (int k = 0; k < nf; k++) {
+        SihField *f = names[k] ? sih_find_field(c, names[k]) : nullptr;
+        if (!f) {
+            sih_set_error(std::string(who) + ": unknown field: " + (names[k] ? names[k] : "(null)"));
+            return SIH_ERR_ARG;
+        }
+        if (f->loc != LOC_CELL || f->isInt || f->lead % nCat != 0) {
+            sih_set_error(std::string(who) + ": field " + names[k] +
+                          " must be a real cell field whose leading size is a multiple of nCategories");
+            return SIH_ERR_ARG;
+        }
+        fs[k] = f;
+        slot0[k] = S;
+        S += f->lead / nCat;
+    }
+    if (count != (size_t)nCells * nCat * S) {
+        sih_set_error(std::string(who) + ": element count mismatch");
+        return SIH_ERR_ARG;
+    }
+    if (nCells == 0) return SIH_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t bytes = count * sizeof(double);
+    int rc = ensureStage(c, bytes);
+    if (rc) return rc;
+    double *stage = (double *)c->d_stage;
+    const int *perm = c->renumber ? c->d_cellPerm : nullptr;
+    if (put) HIPCHK(hipMemcpyAsync(stage, host, bytes, hipMemcpyHostToDevice, c->stream));
+    for (int k = 0; k < nf; k++) {
+        SihField *f = fs[k];
+        const int L = f->lead / nCat;
+        const long total = (long)c->nCells * f->lead;
+        dim3 grid((unsigned)((total + 255) / 256)), block(256);
+        if (put)
+            hipLaunchKernelGGL(k_column_put, grid, block, 0, c->stream, (double *)f->d, (const double *)stage, perm, c->nCells,
+                               L, nCat, c->padC, S, slot0[k], firstCell, nCells);
+        else
+            hipLaunchKernelGGL(k_column_get, grid, block, 0, c->stream, stage, (const double *)f->d, perm, c->nCells, L, nCat,
+                               c->padC, S, slot0[k], firstCell, nCells);
+        HIPCHK(hipGetLastError());
+    }
+    if (!put) HIPCHK(hipMemcpyAsync(host, stage, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SIH_OK;
+}
+
+extern "C" int sih_column_get(sih_ctx *c, int nFields, const char *const *names, int nCategories, int firstCell,
+                              int nCells, double *host, size_t count)
+{
+    return columnMove(c, nFields, names, nCategories, firstCell, nCells, host, count, false);
+}
+
+extern "C" int sih_column_put(sih_ctx *c, int nFields, const char *const *names, int nCategories, int firstCell,
+                              int nCells, const double *host, size_t count)
+{
+    return columnMove(c, nFields, names, nCategories, firstCell, nCells, (double *)host, count, true);
+}
+
 static int putget(sih_ctx *c, const char *name, void *host, size_t count, bool put)
 {
     return putgetMany(c, 1, &name, &host, &count, put);

@@ -82,7 +82,7 @@ EXPORTS = [
     "sih_evp_strain_tensor", "sih_evp_stress_divergence",
     "sih_comm_handle_size", "sih_comm_create", "sih_comm_get_handle", "sih_comm_connect", "sih_comm_destroy",
     "sih_halo_exchange", "sih_halo_exchange_start", "sih_halo_exchange_finish", "sih_comm_set_timeout",
-    "sih_comm_status", "sih_evp_subcycle_exchange", "sih_field_get_noalloc", "sih_device_count", "sih_evp_subcycle_persistent",
+    "sih_comm_status", "sih_evp_subcycle_exchange", "sih_field_get_noalloc", "sih_device_count", "sih_evp_subcycle_persistent", "sih_column_get", "sih_column_put",
 ]
 
 
@@ -106,6 +106,9 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     lib.sih_last_error.restype = ctypes.c_char_p
     lib.sih_device_count.argtypes = []
+    for fn in (lib.sih_column_get, lib.sih_column_put):
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                       ctypes.c_void_p, ctypes.c_size_t]
     lib.sih_field_count.restype = ctypes.c_size_t
     lib.sih_field_count.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
     lib.sih_block_create.argtypes = [ctypes.POINTER(MeshDesc), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
@@ -460,6 +463,20 @@ class BlockContext:
         nl = np.ascontiguousarray(nLayers, dtype=np.int32)
         check(self._lib.sih_ir_set_tracers(self.handle, len(names), self._names(names), self._names(parents),
                                            _ptr(nl)), "sih_ir_set_tracers")
+
+    def _column(self, fn, names, n_categories, first_cell, n_cells, arr):
+        assert arr.dtype == np.float64 and (arr.flags["F_CONTIGUOUS"] or arr.flags["C_CONTIGUOUS"])
+        arr_t = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])
+        check(fn(self.handle, len(names), arr_t, int(n_categories), int(first_cell), int(n_cells), _ptr(arr),
+                 ctypes.c_size_t(arr.size)), fn.__name__)
+
+    def column_get(self, names, n_categories, first_cell, n_cells, arr):
+        """records of the listed fields for host cells [first_cell, first_cell + n_cells): arr(S, nCategories, nCells)
+        in Fortran order"""
+        self._column(self._lib.sih_column_get, names, n_categories, first_cell, n_cells, arr)
+
+    def column_put(self, names, n_categories, first_cell, n_cells, arr):
+        self._column(self._lib.sih_column_put, names, n_categories, first_cell, n_cells, arr)
 
     def ir_run(self, dt, check_conservation=False, check_monotonicity=False, check_recover_means=False):
         checks = ((1 if check_conservation else 0) | (2 if check_monotonicity else 0)
