@@ -149,6 +149,10 @@ class CommBase:
         k = (key, is_int)
         t = self._bufs.get(k)
         if t is None or t.numel() < max(n, 1):
+            if t is not None:
+                # pack / unpack kernels of the library's streams may still read or write the buffer that is about to
+                # be released: torch's allocator knows nothing of those streams
+                torch.cuda.synchronize()
             t = torch.empty(max(n, 1), dtype=torch.int32 if is_int else torch.float64, device=device)
             self._bufs[k] = t
         return t
