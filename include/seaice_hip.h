@@ -477,7 +477,11 @@ int sih_upwind_run(sih_ctx *ctx, double dt, int checks);
  * nCategories values each */
 int sih_upwind_get_sums(sih_ctx *ctx, const char *tracer, double *initSums, double *finalSums);
 
-/* introspection for tests and reports.  Keys: sparseGradient, splitCellKernel, persistentKernel, dampingTimescale,
+/* introspection for tests and reports.  Keys: sparseGradient, splitCellKernel, persistentKernel (and persistentPerCU,
+ * persistentTiles, persistentReason, persistentArrived, persistentLaunches, persistentExchangeLaunches: workgroups of
+ * the persistent subcycle kernel a CU holds, its tiles, why the block does not qualify (1 option, 2 too many tiles,
+ * 3 too many vertices in a tile, 5 not resident together in the trial launch), workgroups that arrived in a failed
+ * trial, launches so far and those with the halo exchange inside), dampingTimescale,
  * elasticTimeStep, dynamicsTimeStep, numericalInertiaCoefficient, padC, padV, minDvEdge, and
  * irRecoverMeansWarnings (see sih_ir_run), irFluxWalk (1 when the flux kernel that walks the tracer tree is in use:
  * every tracer with children has one layer and there are at most 32 layer fields), irCflWarnings: number of vertices whose departure distance in the last sih_ir_run exceeded the

@@ -46,7 +46,7 @@
 #define COS_TURN 1.0
 
 // words of the state array; the census counters sit 128 bytes apart behind the first line
-enum { PS_EPOCH = 0, PS_LAUNCHES = 1, PS_STATUS = 2, PS_TICKS = 3, PS_CENSUS = 16, PS_CENSUS_N = 32, PS_CENSUS_STRIDE = 16,
+enum { PS_EPOCH = 0, PS_LAUNCHES = 1, PS_STATUS = 2, PS_TICKS = 3, PS_XSEQ = 4, PS_CENSUS = 16, PS_CENSUS_N = 32, PS_CENSUS_STRIDE = 16,
        PS_WORDS = PS_CENSUS + PS_CENSUS_N * PS_CENSUS_STRIDE };
 #define PS_MARKER 0xFFF8C0DEDEADBEEFULL  // "not written yet": a NaN with a payload no operation produces
 
@@ -57,6 +57,25 @@ struct PersistArgs {
     const int *cornerSlot;                 // per (corner, cell) [g * padC + c]: position of its vertex in the tile's list
     unsigned long long *part;              // the partial sums: [buffer 0..2][U, V][corner * padC + cell]
     unsigned long long *state;             // PS_* words
+};
+
+// Tables of the in-kernel halo exchange (a copy lives in device memory; the kernel takes a pointer, so that the
+// launch without exchange pays nothing for it).  Velocities and stresses travel as in the exchange between launches
+// (uVelocity, vVelocity, stress11/22/12 of every list entry), but each value is two 8-byte words
+// {low 32 bits | tag << 32}, {high 32 bits | tag << 32} with tag = number of the exchange: a word is there when its
+// tag is, no flag and no fence.  The slots exist twice (parity of the tag).  A tile sends what its own cells and
+// the vertices it stores hold, straight from LDS into the neighbour's memory, and goes on; a thread whose corner or
+// vertex is in a receive list polls its own slots.  Tiles away from the block's edge never wait for a neighbour.
+struct PersistXchg {
+    const int *sendStart;                          // per tile: its entries [sendStart[t], sendStart[t+1])
+    const int *sendSrc, *sendItem, *sendPeer, *sendSlot;  // kind << 28 | index in LDS; cell or vertex; rank; slot there
+    char *const *peerBase;                         // per rank: its tagged region, half 0, in this address space
+    const unsigned long long *peerHalf;            // per rank: bytes of one half
+    const int *recvCBase, *recvCStride;            // per (corner, cell) [g * padC + c]: first slot (-1: none), stride between the three stresses
+    const int *recvVBase, *recvVStride;            // per entry of tileVerts
+    const char *myBase;                            // this block's tagged region, half 0
+    unsigned long long myHalf;
+    const double *stress11, *stress22, *stress12;  // for the corners the kernel does not update
 };
 
 // what the kernel reads of SihDev, and nothing else: the fewer scalar registers the arguments take, the more
@@ -96,6 +115,13 @@ struct sih_persist_state {
     bool usable = false;
     bool unchecked = false;  // a launch since the status word was last read
     std::vector<void *> allocs;
+    // the tiles' vertex lists on the host, for the tables of the in-kernel exchange
+    std::vector<int> hVStart, hVerts, hOwned;
+    int launches = 0, xLaunches = 0;  // launches so far, and those of them with the exchange inside
+    int xGeneration = -1;  // generation of the transport the exchange tables were built for (-1: none)
+    bool xUsable = false;
+    PersistXchg *d_x = nullptr;
+    std::vector<void *> xAllocs;
 };
 
 __device__ inline unsigned long long ldAgent(const unsigned long long *p)
@@ -105,6 +131,14 @@ __device__ inline unsigned long long ldAgent(const unsigned long long *p)
 __device__ inline void stAgent(unsigned long long *p, unsigned long long x)
 {
     __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline unsigned long long ldSystem(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ inline void stSystem(unsigned long long *p, unsigned long long x)
+{
+    __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ inline unsigned long long bitsOf(double x) { return (unsigned long long)__double_as_longlong(x); }
 __device__ inline double valueOf(unsigned long long b) { return __longlong_as_double((long long)b); }
@@ -120,8 +154,9 @@ __device__ inline double sign1p(double x) { return copysign(1.0, x); }
 template <int M>
 constexpr int persistLdsDoubles() { return 5 * M * 64 + 2 * 64 * M + 3 * M * 64 * M; }
 
-template <int M>
-__global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, PersistArgs p, int nIter)
+template <int M, bool XCHG>
+__global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, PersistArgs p, int nIter,
+                                                             const PersistXchg *__restrict__ xp, int xInterval)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double(*su)[64] = (double(*)[64])(smem);
@@ -144,6 +179,7 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
     const unsigned long long limit = ldAgent(&p.state[PS_TICKS]);
     const unsigned long long launches = ldAgent(&p.state[PS_LAUNCHES]);
     const unsigned long long epoch = ldAgent(&p.state[PS_EPOCH]);  // iterations done by earlier launches
+    const unsigned long long xseq0 = XCHG ? ldAgent(&p.state[PS_XSEQ]) : 0ULL;  // exchanges done by earlier launches
 
     // ---- what this thread keeps for all iterations: its cell corner ...
     const int P = d.padC, PV = d.padV;
@@ -273,7 +309,9 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
     if (alive && tile == 0 && tid == 0) {
         stAgent(&p.state[PS_EPOCH], epoch + (unsigned long long)nIter);
         stAgent(&p.state[PS_LAUNCHES], launches + 1ULL);
+        if (XCHG) stAgent(&p.state[PS_XSEQ], xseq0 + (unsigned long long)((nIter + xInterval - 1) / xInterval));
     }
+    unsigned int xDone = 0;  // exchanges of this launch so far
     const double dtE = d.dtE, T = d.dampT, brlx = d.brlx, dtD = d.dtDyn;
     const int relation = d.relation;
     int sl = (int)(epoch % 3ULL);  // buffer of the iteration before the one at hand
@@ -435,17 +473,105 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
         }
         __syncthreads();
         if (sDead) break;  // the same answer in every thread: written before the barrier, not again after it
+        if (XCHG && (it % xInterval == 0 || it == nIter)) {
+            // ================= halo update of velocities and stresses with the neighbouring blocks
+            const PersistXchg X = *xp;
+            xDone++;
+            const unsigned long long tag = ((xseq0 + xDone) & 0xffffffffULL) << 32;
+            const unsigned long long par = (xseq0 + xDone) & 1ULL;
+            for (int i = X.sendStart[tile] + tid, iEnd = X.sendStart[tile + 1]; i < iEnd; i += 64 * M) {
+                const int src = X.sendSrc[i], item = X.sendItem[i], peer = X.sendPeer[i];
+                const int kind = src >> 28, idx = src & 0x0fffffff;
+                double val;
+                if (kind < 3) {
+                    // idx = corner * 64 + cell within the tile.  A corner the kernel does not update (no ice, or
+                    // past the cell's last edge) sends what memory holds, as the exchange between launches does.
+                    const int gg = idx >> 6, ll = idx & 63;
+                    const bool upd = d.solveStress[item] == 1 && gg < d.nEdgesOnCell[item];
+                    if (upd)
+                        val = kind == 0 ? s11[gg][ll] : kind == 1 ? s22[gg][ll] : s12[gg][ll];
+                    else
+                        val = (kind == 0 ? X.stress11 : kind == 1 ? X.stress22 : X.stress12)[(size_t)gg * P + item];
+                } else {
+                    val = kind == 3 ? uT[idx] : vT[idx];
+                }
+                const unsigned long long b = bitsOf(val);
+                unsigned long long *dst = (unsigned long long *)(X.peerBase[peer] + par * X.peerHalf[peer]) + 2 * (size_t)X.sendSlot[i];
+                stSystem(dst, (b & 0xffffffffULL) | tag);
+                stSystem(dst + 1, (b >> 32) | tag);
+            }
+            const int rb = inRange ? X.recvCBase[k] : -1, rs = rb >= 0 ? X.recvCStride[k] : 0;
+            const int vb = hasV ? X.recvVBase[v0 + tid] : -1, vstr = vb >= 0 ? X.recvVStride[v0 + tid] : 0;
+            const unsigned long long *mine = (const unsigned long long *)(X.myBase + par * X.myHalf);
+            unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, y0 = 0, y1 = 0, y2 = 0, y3 = 0;
+            {
+                long long t0 = 0;
+                for (int spins = 1;; spins++) {
+                    bool ready = true;
+                    if (rb >= 0) {
+                        const unsigned long long *q = mine + 2 * (size_t)rb;
+                        w0 = ldSystem(q);
+                        w1 = ldSystem(q + 1);
+                        w2 = ldSystem(q + 2 * (size_t)rs);
+                        w3 = ldSystem(q + 2 * (size_t)rs + 1);
+                        w4 = ldSystem(q + 4 * (size_t)rs);
+                        w5 = ldSystem(q + 4 * (size_t)rs + 1);
+                        ready = ((w0 ^ tag) >> 32) == 0 && ((w1 ^ tag) >> 32) == 0 && ((w2 ^ tag) >> 32) == 0 &&
+                                ((w3 ^ tag) >> 32) == 0 && ((w4 ^ tag) >> 32) == 0 && ((w5 ^ tag) >> 32) == 0;
+                    }
+                    if (vb >= 0) {
+                        const unsigned long long *q = mine + 2 * (size_t)vb;
+                        y0 = ldSystem(q);
+                        y1 = ldSystem(q + 1);
+                        y2 = ldSystem(q + 2 * (size_t)vstr);
+                        y3 = ldSystem(q + 2 * (size_t)vstr + 1);
+                        ready = ready && ((y0 ^ tag) >> 32) == 0 && ((y1 ^ tag) >> 32) == 0 && ((y2 ^ tag) >> 32) == 0 &&
+                                ((y3 ^ tag) >> 32) == 0;
+                    }
+                    if (__all(ready)) break;
+                    if ((spins & 7) == 0) {
+                        const long long now = wall_clock64();
+                        if (t0 == 0) {
+                            t0 = now;
+                        } else if ((unsigned long long)(now - t0) > limit || ldAgent(&p.state[PS_STATUS]) != 0ULL) {
+                            if (lane == 0) {
+                                __hip_atomic_fetch_max(&p.state[PS_STATUS], 3ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                sDead = 1;
+                            }
+                            break;
+                        }
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            if (rb >= 0) {
+                o11 = valueOf((w0 & 0xffffffffULL) | (w1 << 32));
+                o22 = valueOf((w2 & 0xffffffffULL) | (w3 << 32));
+                o12 = valueOf((w4 & 0xffffffffULL) | (w5 << 32));
+            }
+            if (vb >= 0) {
+                uu = valueOf((y0 & 0xffffffffULL) | (y1 << 32));
+                vv = valueOf((y2 & 0xffffffffULL) | (y3 << 32));
+                uT[tid] = uu;
+                vT[tid] = vv;
+            }
+            __syncthreads();
+            if (sDead) break;
+        }
     }
 
     // ---- stresses and velocities go back to memory for whatever runs next (the last iteration of the step, an
     //      exchange)
     if (alive) {
-        if (corner) {
+        // with the exchange inside, what was received goes to memory too, updated by this kernel or not
+        const bool gotC = XCHG && xDone > 0 && inRange && xp->recvCBase[k] >= 0;
+        const bool gotV = XCHG && xDone > 0 && hasV && xp->recvVBase[v0 + tid] >= 0;
+        if (corner || gotC) {
             d.stress11[k] = o11;
             d.stress22[k] = o22;
             d.stress12[k] = o12;
         }
-        if (owned && solV && relation != 3) {
+        if (owned && ((solV && relation != 3) || gotV)) {
             d.u[v] = uu;
             d.v[v] = vv;
         }
@@ -458,6 +584,7 @@ void sih_persist_destroy(sih_ctx *c)
     sih_persist_state *s = c->persist;
     if (!s) return;
     for (void *q : s->allocs) (void)hipFree(q);
+    for (void *q : s->xAllocs) (void)hipFree(q);
     delete s;
     c->persist = nullptr;
 }
@@ -466,7 +593,7 @@ template <int M>
 static int occupancyFor(int *perCU)
 {
     int n = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_sub_persistent<M>, 64 * M, persistLdsDoubles<M>() * sizeof(double));
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (k_sub_persistent<M, true>), 64 * M, persistLdsDoubles<M>() * sizeof(double));
     if (e != hipSuccess) return sih_hip_fail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor", __FILE__, __LINE__);
     *perCU = n;
     return SIH_OK;
@@ -561,6 +688,9 @@ int sih_persist_setup(sih_ctx *c)
     }
     // the three buffers of the partial sums, zero where no corner ever writes (the slot that stands for "no cell")
     if ((rc = sih_add_field(c, "_partRing", LOC_CELL, 6 * M, false))) return rc;
+    s->hVStart = vStart;
+    s->hVerts = verts;
+    s->hOwned = ownedFlag;
     PersistArgs &a = s->a;
     a.nTiles = nT;
     a.part = (unsigned long long *)sih_find_field(c, "_partRing")->d;
@@ -597,33 +727,206 @@ int sih_persist_setup(sih_ctx *c)
 double sih_persist_info(sih_ctx *c, int what)
 {
     if (!c->persist) return 0.0;
-    return what == 0 ? c->persist->perCU : what == 1 ? c->persist->reason : what == 2 ? c->persist->a.nTiles : c->persist->arrived;
+    const sih_persist_state *s = c->persist;
+    return what == 0 ? s->perCU : what == 1 ? s->reason : what == 2 ? s->a.nTiles : what == 3 ? s->arrived : what == 4 ? s->launches : s->xLaunches;
 }
 
 // the kernel reads the compact gradients: a put of a basis array switches it off until sih_evp_static_changed()
 bool sih_persist_usable(sih_ctx *c) { return c->persist && c->persist->usable && c->sparseGrad; }
 
 template <int M>
-static void launchPersist(sih_ctx *c, int n)
+static void launchPersist(sih_ctx *c, int n, int interval)
 {
     const PersistArgs &a = c->persist->a;
-    hipLaunchKernelGGL((k_sub_persistent<M>), dim3((unsigned)a.nTiles), dim3(64, M), persistLdsDoubles<M>() * sizeof(double), c->stream, makePersistDev(c->dev), a, n);
+    const size_t lds = persistLdsDoubles<M>() * sizeof(double);
+    if (interval > 0)
+        hipLaunchKernelGGL((k_sub_persistent<M, true>), dim3((unsigned)a.nTiles), dim3(64, M), lds, c->stream,
+                           makePersistDev(c->dev), a, n, (const PersistXchg *)c->persist->d_x, interval);
+    else
+        hipLaunchKernelGGL((k_sub_persistent<M, false>), dim3((unsigned)a.nTiles), dim3(64, M), lds, c->stream,
+                           makePersistDev(c->dev), a, n, (const PersistXchg *)nullptr, 1);
 }
 
-// n iterations (none the last of the dynamics step) as one launch; asynchronous
-int sih_persist_launch(sih_ctx *c, int n)
+static int launchAny(sih_ctx *c, int n, int interval)
 {
     switch (c->M) {
-        case 3: launchPersist<3>(c, n); break;
-        case 4: launchPersist<4>(c, n); break;
-        case 5: launchPersist<5>(c, n); break;
-        case 6: launchPersist<6>(c, n); break;
-        case 7: launchPersist<7>(c, n); break;
-        default: launchPersist<8>(c, n); break;
+        case 3: launchPersist<3>(c, n, interval); break;
+        case 4: launchPersist<4>(c, n, interval); break;
+        case 5: launchPersist<5>(c, n, interval); break;
+        case 6: launchPersist<6>(c, n, interval); break;
+        case 7: launchPersist<7>(c, n, interval); break;
+        default: launchPersist<8>(c, n, interval); break;
     }
     HIPCHK(hipGetLastError());
     c->persist->unchecked = true;
+    c->persist->launches++;
+    if (interval > 0) c->persist->xLaunches++;
     return SIH_OK;
+}
+
+// n iterations (none the last of the dynamics step) as one launch; asynchronous
+int sih_persist_launch(sih_ctx *c, int n) { return launchAny(c, n, 0); }
+
+template <typename T>
+static int uploadX(sih_persist_state *s, const T **dst, const std::vector<T> &v)
+{
+    void *q = nullptr;
+    HIPCHK(hipMalloc(&q, sizeof(T) * std::max<size_t>(v.size(), 1)));
+    s->xAllocs.push_back(q);
+    if (!v.empty()) HIPCHK(hipMemcpy(q, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+    *dst = (const T *)q;
+    return SIH_OK;
+}
+
+// Tables of the in-kernel exchange from the lists given to sih_halo_set_lists and the connected transport.  Built
+// on first use and again when the transport has changed.
+static int exchangeSetup(sih_ctx *c)
+{
+    sih_persist_state *s = c->persist;
+    sih_comm_tagged t;
+    const bool have = sih_comm_tagged_info(c, &t);
+    if (s->xGeneration == t.generation && t.generation != 0) return SIH_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (void *q : s->xAllocs) (void)hipFree(q);
+    s->xAllocs.clear();
+    s->d_x = nullptr;
+    s->xUsable = false;
+    s->xGeneration = t.generation;
+    if (!have || c->dev.relation == 3) return SIH_OK;
+    const int M = c->M, nT = s->a.nTiles, nC = c->nCells, nV = c->nVertices, P = c->padC, nR = t.nRanks;
+    // where a vertex sits: the tile that stores it at the end, and its place in that tile's list
+    std::vector<int> ownerTile(nV, -1), ownerPos(nV, -1);
+    for (int tl = 0; tl < nT; tl++)
+        for (int j = s->hVStart[tl]; j < s->hVStart[tl + 1]; j++)
+            if (s->hOwned[j]) {
+                ownerTile[s->hVerts[j]] = tl;
+                ownerPos[s->hVerts[j]] = j - s->hVStart[tl];
+            }
+    // ---- what every tile sends
+    struct Entry {
+        int src, item, peer, slot;
+    };
+    std::vector<std::vector<Entry>> perTile(nT);
+    {
+        size_t at = 0;
+        for (int p = 0; p < nR; p++) {
+            const int cnt = c->hSendCounts[0][p], cntV = c->hSendCounts[1][p];
+            for (int r = 0; r < cnt; r++, at++) {
+                const int cell = c->hSend[0][at];
+                if (cell < 0 || cell >= nC) return SIH_OK;
+                for (int f = 0; f < 3; f++)
+                    for (int g = 0; g < M; g++)
+                        perTile[cell / 64].push_back(Entry{(f << 28) | (g * 64 + cell % 64), cell, p,
+                                                           (int)t.peerSlotOff[p] + (f * M + g) * cnt + r});
+            }
+            (void)cntV;
+        }
+        at = 0;
+        for (int p = 0; p < nR; p++) {
+            const int cnt = c->hSendCounts[0][p], cntV = c->hSendCounts[1][p];
+            for (int r = 0; r < cntV; r++, at++) {
+                const int v = c->hSend[1][at];
+                if (v < 0 || v >= nV || ownerTile[v] < 0) return SIH_OK;  // a vertex no tile holds: no in-kernel exchange
+                for (int f = 0; f < 2; f++)
+                    perTile[ownerTile[v]].push_back(Entry{((3 + f) << 28) | ownerPos[v], v, p,
+                                                          (int)t.peerSlotOff[p] + 3 * M * cnt + f * cntV + r});
+            }
+        }
+    }
+    std::vector<int> sStart(nT + 1, 0), sSrc, sItem, sPeer, sSlot;
+    for (int tl = 0; tl < nT; tl++) {
+        for (const Entry &e : perTile[tl]) {
+            sSrc.push_back(e.src);
+            sItem.push_back(e.item);
+            sPeer.push_back(e.peer);
+            sSlot.push_back(e.slot);
+        }
+        sStart[tl + 1] = (int)sSrc.size();
+    }
+    // ---- what every corner and every listed vertex receives
+    std::vector<int> rcBase((size_t)M * P, -1), rcStride((size_t)M * P, 0);
+    std::vector<int> rvBaseOfVertex(nV, -1), rvStrideOfVertex(nV, 0);
+    {
+        size_t at = 0;
+        for (int p = 0; p < nR; p++) {
+            const int cnt = c->hRecvCounts[0][p];
+            for (int r = 0; r < cnt; r++, at++) {
+                const int cell = c->hRecv[0][at];
+                if (cell < 0 || cell >= nC) return SIH_OK;
+                for (int g = 0; g < M; g++) {
+                    rcBase[(size_t)g * P + cell] = (int)t.mySlotOff[p] + g * cnt + r;
+                    rcStride[(size_t)g * P + cell] = M * cnt;
+                }
+            }
+        }
+        at = 0;
+        for (int p = 0; p < nR; p++) {
+            const int cnt = c->hRecvCounts[0][p], cntV = c->hRecvCounts[1][p];
+            for (int r = 0; r < cntV; r++, at++) {
+                const int v = c->hRecv[1][at];
+                if (v < 0 || v >= nV || ownerTile[v] < 0) return SIH_OK;
+                rvBaseOfVertex[v] = (int)t.mySlotOff[p] + 3 * M * cnt + r;
+                rvStrideOfVertex[v] = cntV;
+            }
+        }
+    }
+    std::vector<int> rvBase(s->hVerts.size(), -1), rvStride(s->hVerts.size(), 0);
+    for (size_t j = 0; j < s->hVerts.size(); j++) {
+        rvBase[j] = rvBaseOfVertex[s->hVerts[j]];
+        rvStride[j] = rvStrideOfVertex[s->hVerts[j]];
+    }
+    std::vector<char *> pb(nR, nullptr);
+    std::vector<unsigned long long> ph(nR, 0);
+    for (int p = 0; p < nR; p++) {
+        pb[p] = t.peerBase[p];
+        ph[p] = t.peerHalfBytes[p];
+    }
+    PersistXchg x{};
+    int rc;
+    if ((rc = uploadX(s, &x.sendStart, sStart))) return rc;
+    if ((rc = uploadX(s, &x.sendSrc, sSrc))) return rc;
+    if ((rc = uploadX(s, &x.sendItem, sItem))) return rc;
+    if ((rc = uploadX(s, &x.sendPeer, sPeer))) return rc;
+    if ((rc = uploadX(s, &x.sendSlot, sSlot))) return rc;
+    if ((rc = uploadX<char *>(s, (char *const **)&x.peerBase, pb))) return rc;
+    if ((rc = uploadX(s, &x.peerHalf, ph))) return rc;
+    if ((rc = uploadX(s, &x.recvCBase, rcBase))) return rc;
+    if ((rc = uploadX(s, &x.recvCStride, rcStride))) return rc;
+    if ((rc = uploadX(s, &x.recvVBase, rvBase))) return rc;
+    if ((rc = uploadX(s, &x.recvVStride, rvStride))) return rc;
+    x.myBase = t.myBase;
+    x.myHalf = t.myHalfBytes;
+    x.stress11 = c->dev.stress11;
+    x.stress22 = c->dev.stress22;
+    x.stress12 = c->dev.stress12;
+    void *q = nullptr;
+    HIPCHK(hipMalloc(&q, sizeof x));
+    s->xAllocs.push_back(q);
+    HIPCHK(hipMemcpy(q, &x, sizeof x, hipMemcpyHostToDevice));
+    s->d_x = (PersistXchg *)q;
+    s->xUsable = true;
+    return SIH_OK;
+}
+
+// SIH_PERSIST_EXCHANGE=0 keeps the exchange between the launches
+bool sih_persist_exchange_usable(sih_ctx *c)
+{
+    static const bool on = [] {
+        const char *e = getenv("SIH_PERSIST_EXCHANGE");
+        return !(e && atoi(e) == 0);
+    }();
+    if (!on || !sih_persist_usable(c) || !sih_comm_ready(c)) return false;
+    if (exchangeSetup(c) != SIH_OK) return false;
+    return c->persist->xUsable;
+}
+
+int sih_persist_launch_exchange(sih_ctx *c, int n, int interval)
+{
+    if (!sih_persist_exchange_usable(c) || n < 1 || interval < 1) {
+        sih_set_error("persistent subcycle kernel: the exchange inside the kernel is not available for this block");
+        return SIH_ERR_UNSUPPORTED;
+    }
+    return launchAny(c, n, interval);
 }
 
 // waits for the stream; SIH_ERR_STATE if a launch gave up (workgroups not resident together, or a wait ran out)
@@ -635,8 +938,9 @@ int sih_persist_status(sih_ctx *c)
     unsigned long long st = 0;
     HIPCHK(hipMemcpy(&st, c->persist->a.state + PS_STATUS, sizeof st, hipMemcpyDeviceToHost));
     if (st) {
-        sih_set_error(st == 1 ? "persistent subcycle kernel: its workgroups were not resident together"
-                              : "persistent subcycle kernel: a wait for a neighbouring tile ran out of time");
+        sih_set_error(st == 1   ? "persistent subcycle kernel: its workgroups were not resident together"
+                      : st == 2 ? "persistent subcycle kernel: a wait for a neighbouring tile ran out of time"
+                                : "persistent subcycle kernel: a neighbouring block's halo values did not arrive in time");
         c->persist->usable = false;
         return SIH_ERR_STATE;
     }

@@ -1718,6 +1718,11 @@ extern "C" int sih_evp_subcycle_exchange(sih_ctx *c, int n, int last, int interv
     const int nMain = last ? n - 1 : n;
     int done = 0;
     bool pending = false;
+    // a small block whose transport allows it: all the iterations and the exchanges between them as one launch
+    if (interval > 1 && nMain >= 2 && usePersistent(c, nMain) && sih_persist_exchange_usable(c)) {
+        if ((rc = sih_persist_launch_exchange(c, nMain, interval))) return rc;
+        done = nMain;
+    }
     while (done < nMain) {
         const int m = std::min(interval, nMain - done);
         const bool more = done + m < nMain;

@@ -44,6 +44,10 @@ struct sih_comm_blob {
     hipIpcMemHandle_t mem;
     unsigned long long slotOff[SIH_COMM_MAXR];  // byte offset inside one half of the slot for messages from rank p
     unsigned long long slotCap[SIH_COMM_MAXR];  // its capacity in bytes
+    // the tagged region (velocities and stresses exchanged from inside the persistent subcycle kernel): two halves
+    // of 16-byte slots behind the plain halves; first slot and slot count of the segment for messages from rank p
+    unsigned long long taggedOff, taggedHalfBytes;
+    unsigned long long tSlotOff[SIH_COMM_MAXR], tSlotCnt[SIH_COMM_MAXR];
 };
 
 struct CommTable {  // one field group
@@ -74,6 +78,11 @@ struct sih_comm_state {
     int nSendPeers = 0, nRecvPeers = 0;
     unsigned long long *d_state = nullptr;
     bool connected = false;
+    int generation = 0;  // changes whenever the lists or the peers' addresses may have changed
+    size_t taggedOff = 0, taggedHalfBytes = 0;
+    std::vector<size_t> tSlotOff, tSlotCnt;              // receive side, per peer
+    std::vector<char *> peerTagged;                      // peer p's tagged region (half 0) in this address space
+    std::vector<size_t> peerTHalf, peerTSlotOff;         // its half size; first slot of my segment there
     std::map<std::string, CommTable> tables;
     hipStream_t commStream = nullptr;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
@@ -290,7 +299,20 @@ extern "C" int sih_comm_create(sih_ctx *c, int rank, int nRanks, int maxCellPlan
     }
     s->halfBytes = std::max<size_t>(off, 256);
     s->dataOff = ((size_t)nRanks * SIH_FLAG_STRIDE + 4095) & ~(size_t)4095;
-    s->allocBytes = s->dataOff + 2 * s->halfBytes;
+    // tagged slots: per received cell the three stresses at every corner, per received vertex the two velocities
+    s->tSlotOff.assign(nRanks, 0);
+    s->tSlotCnt.assign(nRanks, 0);
+    size_t tSlots = 0;
+    for (int p = 0; p < nRanks; p++) {
+        s->tSlotOff[p] = tSlots;
+        s->tSlotCnt[p] = (size_t)3 * c->M * c->hRecvCounts[0][p] + (size_t)2 * c->hRecvCounts[1][p];
+        tSlots += s->tSlotCnt[p];
+    }
+    s->taggedHalfBytes = (std::max<size_t>(tSlots * 16, 256) + 255) & ~(size_t)255;
+    s->taggedOff = s->dataOff + 2 * s->halfBytes;
+    s->allocBytes = s->taggedOff + 2 * s->taggedHalfBytes;
+    static int generations = 0;
+    s->generation = ++generations;
     // uncached device memory where the runtime has it (remote stores and local polls then never meet a stale
     // cache line); fine-grained or ordinary memory otherwise -- every access is a system-scope atomic anyway
     void *p = nullptr;
@@ -367,9 +389,13 @@ extern "C" int sih_comm_get_handle(sih_ctx *c, void *blob)
     b.dataOff = s->dataOff;
     b.halfBytes = s->halfBytes;
     HIPCHK(hipIpcGetMemHandle(&b.mem, s->base));
+    b.taggedOff = s->taggedOff;
+    b.taggedHalfBytes = s->taggedHalfBytes;
     for (int p = 0; p < s->nRanks; p++) {
         b.slotOff[p] = s->slotOff[p];
         b.slotCap[p] = s->slotCap[p];
+        b.tSlotOff[p] = s->tSlotOff[p];
+        b.tSlotCnt[p] = s->tSlotCnt[p];
     }
     memcpy(blob, &b, sizeof b);
     return SIH_OK;
@@ -388,6 +414,9 @@ extern "C" int sih_comm_connect(sih_ctx *c, const void *allHandles)
     s->peerBase.assign(n, nullptr);
     s->peerIpc.assign(n, 0);
     s->peerSlotCap.assign(n, 0);
+    s->peerTagged.assign(n, nullptr);
+    s->peerTHalf.assign(n, 0);
+    s->peerTSlotOff.assign(n, 0);
     std::vector<char *> dstBase(n, nullptr);
     std::vector<unsigned long long> dstHalf(n, 0);
     std::vector<unsigned long long *> dstFlag(n, nullptr);
@@ -415,6 +444,12 @@ extern "C" int sih_comm_connect(sih_ctx *c, const void *allHandles)
         }
         s->peerBase[p] = base;
         s->peerSlotCap[p] = b.slotCap[s->rank];
+        // the tagged segment the peer keeps for this rank must be what this rank will send
+        if (b.tSlotCnt[s->rank] == (unsigned long long)3 * c->M * c->hSendCounts[0][p] + (unsigned long long)2 * c->hSendCounts[1][p]) {
+            s->peerTagged[p] = base + b.taggedOff;
+            s->peerTHalf[p] = b.taggedHalfBytes;
+            s->peerTSlotOff[p] = b.tSlotOff[s->rank];
+        }
         dstBase[p] = base + b.dataOff + b.slotOff[s->rank];
         dstHalf[p] = b.halfBytes;
         dstFlag[p] = (unsigned long long *)(base + (size_t)s->rank * SIH_FLAG_STRIDE);
@@ -428,7 +463,28 @@ extern "C" int sih_comm_connect(sih_ctx *c, const void *allHandles)
     HIPCHK(hipMemcpy(s->d_dstHalf, dstHalf.data(), sizeof(unsigned long long) * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->d_dstFlag, dstFlag.data(), sizeof(unsigned long long *) * n, hipMemcpyHostToDevice));
     s->connected = true;
+    static int connects = 1000000;
+    s->generation = ++connects;
     return SIH_OK;
+}
+
+// what the persistent subcycle kernel needs of the transport for its in-kernel exchange; false when a peer's
+// segment does not match this rank's send lists (then the launches exchange between the chunks as before)
+bool sih_comm_tagged_info(sih_ctx *c, sih_comm_tagged *out)
+{
+    sih_comm_state *s = c->comm;
+    if (!s || !s->connected) return false;
+    out->generation = s->generation;
+    out->nRanks = s->nRanks;
+    out->myBase = s->base + s->taggedOff;
+    out->myHalfBytes = s->taggedHalfBytes;
+    out->mySlotOff = s->tSlotOff;
+    out->peerBase = s->peerTagged;
+    out->peerHalfBytes = s->peerTHalf;
+    out->peerSlotOff = s->peerTSlotOff;
+    for (int p = 0; p < s->nRanks; p++)
+        if (s->sendTot[p] > 0 && !s->peerTagged[p]) return false;
+    return true;
 }
 
 extern "C" int sih_comm_set_timeout(sih_ctx *c, double milliseconds)

@@ -1161,6 +1161,8 @@ extern "C" int sih_get_info(sih_ctx *c, const char *key, double *value)
     else if (k == "persistentReason") *value = sih_persist_info(c, 1);
     else if (k == "persistentTiles") *value = sih_persist_info(c, 2);
     else if (k == "persistentArrived") *value = sih_persist_info(c, 3);
+    else if (k == "persistentLaunches") *value = sih_persist_info(c, 4);
+    else if (k == "persistentExchangeLaunches") *value = sih_persist_info(c, 5);
     else {
         sih_set_error("sih_get_info: unknown key " + k);
         return SIH_ERR_ARG;

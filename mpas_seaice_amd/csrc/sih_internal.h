@@ -145,6 +145,21 @@ int sih_comm_push(sih_ctx *c, int nFields, const char *const *names, hipStream_t
 int sih_comm_pull(sih_ctx *c, int nFields, const char *const *names, hipStream_t stream);
 int sih_comm_prepare(sih_ctx *c, int nFields, const char *const *names);  // builds the group's tables (not capturable)
 bool sih_comm_ready(sih_ctx *c);
+// the tagged region of the transport: 16-byte slots {low word | tag << 32, high word | tag << 32} that carry their
+// own arrival signal, written and polled from inside the persistent subcycle kernel
+struct sih_comm_tagged {
+    int generation = 0, nRanks = 0;
+    char *myBase = nullptr;  // half 0 of this block's region
+    size_t myHalfBytes = 0;
+    std::vector<size_t> mySlotOff;                 // first slot of the segment for messages from rank p
+    std::vector<char *> peerBase;                  // rank p's region (half 0) in this address space
+    std::vector<size_t> peerHalfBytes, peerSlotOff;  // its half size; first slot of this rank's segment there
+};
+bool sih_comm_tagged_info(sih_ctx *c, sih_comm_tagged *out);
+// n iterations in the persistent kernel with the halo update of velocities and stresses inside it, after every
+// interval-th iteration and after the last; SIH_ERR_UNSUPPORTED when the block or the transport does not allow it
+int sih_persist_launch_exchange(sih_ctx *c, int n, int interval);
+bool sih_persist_exchange_usable(sih_ctx *c);
 hipStream_t sih_comm_stream(sih_ctx *c);
 void sih_comm_events(sih_ctx *c, hipEvent_t *fork, hipEvent_t *join);
 int sih_setup_edges(sih_ctx *c, const sih_ir_desc *m, const char *who);

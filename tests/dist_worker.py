@@ -81,6 +81,9 @@ def main():
             dom.blocklist[0].structs["tracers"]["surfaceTemperature"][..., :dom.blocklist[0].dimensions["nCells"]] += 273.15
             advection_upwind.seaice_init_advection_upwind(dom)
             advection_upwind.seaice_run_advection_upwind(dom)
+        ctx = dom.blocklist[0].ctx
+        print(f"rank {rank} persistent kernel {int(ctx.info('persistentKernel'))} launches "
+              f"{int(ctx.info('persistentLaunches'))} with exchange {int(ctx.info('persistentExchangeLaunches'))}", flush=True)
         if peer:
             dom.comm.check(dom)
             dist.barrier()  # no rank unmaps its buffer while a neighbour may still write to it

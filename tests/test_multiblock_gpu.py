@@ -61,6 +61,29 @@ def test_two_ranks_sharing_the_gpu_over_gloo(extra):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.count(": ok") == 2, out.stdout
+    if "deep" in extra and "p2p" in extra:
+        # small blocks, each alone in its process: the subcycle loop is one launch with the exchanges inside it
+        assert out.stdout.count("launches 2 with exchange 1") == 2, out.stdout
+
+
+@pytest.mark.parametrize("mesh,ranks,extra", [("QU240", 2, ["p2p", "deep"]), ("QU480", 4, ["p2p", "deep"]),
+                                              ("var16", 3, ["p2p", "graph", "deep"])])
+def test_exchange_inside_the_persistent_kernel(mesh, ranks, extra):
+    """More tiles a block and more ranks than the two-rank cases above: every rank's block runs its subcycle loop
+    as one launch that sends and receives the halo values itself (three halo layers, an exchange every three
+    iterations and after the eleventh), checked on every rank against the single-block oracle."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "dist_worker.py"), "gpu", mesh] + extra
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.count(": ok") == ranks, out.stdout
+    assert out.stdout.count("launches 2 with exchange 1") == ranks, out.stdout
 
 
 @pytest.mark.parametrize("nblocks,interval,graph", [(2, 1, False), (4, 1, True), (3, 3, False), (4, 4, True)])
