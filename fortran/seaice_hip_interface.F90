@@ -303,6 +303,15 @@ module seaice_hip_interface
        integer(c_int) :: ierr
      end function sih_evp_subcycle_persistent
 
+     ! 0 two-kernel form, 1 persistent kernel, 2 persistent kernel with the halo exchange inside (default where a
+     ! block qualifies), -1 back to the environment; the same on every block of a run
+     function sih_evp_set_persistent(ctx, mode) bind(C, name="sih_evp_set_persistent") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: mode
+       integer(c_int) :: ierr
+     end function sih_evp_set_persistent
+
      function sih_ir_init(ctx, desc) bind(C, name="sih_ir_init") result(ierr)
        import :: sih_ir_desc, c_int, c_ptr
        type(c_ptr), value :: ctx

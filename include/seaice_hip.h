@@ -274,6 +274,16 @@ int sih_evp_subcycle_graph(sih_ctx *ctx, int n);
  * default 2000) is reported by sih_sync / sih_evp_run as SIH_ERR_STATE.  The GPU must not be shared with other
  * work that could keep some of the workgroups from being resident. */
 int sih_evp_subcycle_persistent(sih_ctx *ctx, int n);
+/* which form sih_evp_subcycle_graph, sih_evp_run and sih_evp_subcycle_exchange choose for this block where it
+ * qualifies: 0 the two-kernel form; 1 (the default) the persistent kernel with the halo exchanges between its
+ * launches; 2 the persistent kernel with the exchanges of sih_evp_subcycle_exchange inside it: one launch for all
+ * iterations but the last, in which the tiles at the block's edge store their velocities and stresses straight into
+ * the neighbours' memory and poll for theirs, and the tiles inside never wait for a neighbour.  Mode 2 speaks
+ * another protocol than the exchange between launches, so all blocks that exchange with each other must run it or
+ * none: the host asks every block (sih_get_info "persistentExchangeReady" = 1 when the block qualifies and its
+ * transport is connected), takes the minimum over the ranks and sets mode 2 on all of them or on none.  -1 goes
+ * back to the environment (SIH_PERSISTENT=0 is mode 0, SIH_PERSIST_EXCHANGE=1 is mode 2). */
+int sih_evp_set_persistent(sih_ctx *ctx, int mode);
 /* Pieces of one subcycle iteration (none the last of the dynamics step), for a host that overlaps the
  * halo exchange the reference does after every iteration (velocity_solver.F:2543-2584) with work that
  * needs no halo value.  sih_evp_overlap_setup derives four entity subsets from the lists given to
@@ -478,7 +488,8 @@ int sih_upwind_run(sih_ctx *ctx, double dt, int checks);
 int sih_upwind_get_sums(sih_ctx *ctx, const char *tracer, double *initSums, double *finalSums);
 
 /* introspection for tests and reports.  Keys: sparseGradient, splitCellKernel, persistentKernel (and persistentPerCU,
- * persistentTiles, persistentReason, persistentArrived, persistentLaunches, persistentExchangeLaunches: workgroups of
+ * persistentTiles, persistentReason, persistentArrived, persistentLaunches, persistentExchangeLaunches,
+ * persistentExchangeReady (see sih_evp_set_persistent): workgroups of
  * the persistent subcycle kernel a CU holds, its tiles, why the block does not qualify (1 option, 2 too many tiles,
  * 3 too many vertices in a tile, 5 not resident together in the trial launch), workgroups that arrived in a failed
  * trial, launches so far and those with the halo exchange inside), dampingTimescale,

@@ -908,14 +908,9 @@ static int exchangeSetup(sih_ctx *c)
     return SIH_OK;
 }
 
-// SIH_PERSIST_EXCHANGE=0 keeps the exchange between the launches
 bool sih_persist_exchange_usable(sih_ctx *c)
 {
-    static const bool on = [] {
-        const char *e = getenv("SIH_PERSIST_EXCHANGE");
-        return !(e && atoi(e) == 0);
-    }();
-    if (!on || !sih_persist_usable(c) || !sih_comm_ready(c)) return false;
+    if (!sih_persist_usable(c) || !sih_comm_ready(c)) return false;
     if (exchangeSetup(c) != SIH_OK) return false;
     return c->persist->xUsable;
 }

@@ -1245,14 +1245,34 @@ extern "C" int sih_evp_apply_special_boundaries(sih_ctx *c)
 // it costs about as much as one iteration of the two-kernel form before the first iteration starts.
 // Only while this context is the only one of the process on its device: the kernel needs all its workgroups resident
 // together, and the launches of other blocks (each on its own stream) would take their places.
-// SIH_PERSISTENT=0 keeps the two-kernel form everywhere.
+// sih_evp_set_persistent chooses per context; without it the environment does: SIH_PERSISTENT=0 keeps the two-kernel
+// form everywhere.  The halo exchange inside the kernel (mode 2) is never chosen by default: the blocks that
+// exchange with each other must all run it or none, which only their host can know (SIH_PERSIST_EXCHANGE=1 asks
+// for it from the environment, for runs whose blocks are known to qualify alike).
+static int persistentMode(sih_ctx *c)
+{
+    static const int fromEnv = [] {
+        const char *e = getenv("SIH_PERSISTENT");
+        if (e && atoi(e) == 0) return 0;
+        const char *x = getenv("SIH_PERSIST_EXCHANGE");
+        return (x && atoi(x) != 0) ? 2 : 1;
+    }();
+    return c->persistMode >= 0 ? c->persistMode : fromEnv;
+}
+
 static bool usePersistent(sih_ctx *c, int iterations)
 {
-    static const bool on = [] {
-        const char *e = getenv("SIH_PERSISTENT");
-        return !(e && atoi(e) == 0);
-    }();
-    return on && iterations >= 2 && sih_persist_usable(c) && sih_live_contexts(c->device) == 1;
+    return persistentMode(c) >= 1 && iterations >= 2 && sih_persist_usable(c) && sih_live_contexts(c->device) == 1;
+}
+
+extern "C" int sih_evp_set_persistent(sih_ctx *c, int mode)
+{
+    if (!c || mode < -1 || mode > 2) {
+        sih_set_error("sih_evp_set_persistent: mode must be -1 (environment), 0, 1 or 2");
+        return SIH_ERR_ARG;
+    }
+    c->persistMode = mode;
+    return SIH_OK;
 }
 
 extern "C" int sih_evp_subcycle(sih_ctx *c, int n, int last)
@@ -1719,7 +1739,7 @@ extern "C" int sih_evp_subcycle_exchange(sih_ctx *c, int n, int last, int interv
     int done = 0;
     bool pending = false;
     // a small block whose transport allows it: all the iterations and the exchanges between them as one launch
-    if (interval > 1 && nMain >= 2 && usePersistent(c, nMain) && sih_persist_exchange_usable(c)) {
+    if (interval > 1 && nMain >= 2 && persistentMode(c) == 2 && usePersistent(c, nMain) && sih_persist_exchange_usable(c)) {
         if ((rc = sih_persist_launch_exchange(c, nMain, interval))) return rc;
         done = nMain;
     }

@@ -81,6 +81,7 @@ struct sih_ctx {
     sih_evp_config cfg{};
     bool inited = false, sparseGrad = false;
     bool counted = false;  // in the per-device count of live contexts
+    int persistMode = -1;  // sih_evp_set_persistent: -1 environment, 0 two-kernel form, 1 persistent kernel, 2 with the exchange inside
     bool splitCells = false;  // cell kernel with one thread per (cell, corner) instead of one per cell
     double minDvEdge = 0.0;
     SihDev dev{};

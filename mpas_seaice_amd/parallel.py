@@ -10,6 +10,8 @@ buffers; host blocks (``HostFields``) index numpy pool arrays, which is what the
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import cases
@@ -416,6 +418,19 @@ class PeerComm(DistComm):
     def check(self, domain):
         """raises if a neighbour's message ever failed to arrive (waits for the block's stream)"""
         domain.blocklist[0].ctx.comm_status()
+
+    def agree_on_exchange_inside(self, domain, allow=True):
+        """The persistent subcycle kernel can carry the halo exchange itself, but only if every block of the run
+        does so: the ranks vote once (after sih_evp_init, a minimum over all of them) and set the mode on all
+        blocks or on none.  Returns what was agreed."""
+        ctx = domain.blocklist[0].ctx
+        ready = 1 if (allow and os.environ.get("SIH_PERSIST_EXCHANGE", "1") != "0"
+                      and os.environ.get("SIH_PERSISTENT", "1") != "0"
+                      and ctx.info("persistentExchangeReady") == 1.0) else 0
+        agreed = (self.allreduce_min(float(ready)) if self.nblocks > 1 else float(ready)) >= 1.0
+        ctx.set_persistent(2 if agreed else -1)
+        self.exchange_inside = agreed
+        return agreed
 
 
 # ----------------------------------------------------------------------------------------------

@@ -74,7 +74,29 @@ def main():
         from mpas_seaice_amd import advection as adv
         vs.seaice_init_velocity_solver(dom)
         adv.seaice_init_advection(dom)
+        if "silent" in sys.argv[3:]:
+            # rank 1 never runs its dynamics: rank 0's kernel must give up within its time limit, end normally and
+            # leave an error for the host (the time limit comes from SIH_PERSIST_TIMEOUT_MS)
+            from mpas_seaice_amd import lib as sihlib
+            if rank == 0:
+                dom.comm.agree_on_exchange_inside(dom)
+                try:
+                    vs.seaice_run_velocity_solver(dom)
+                    dom.blocklist[0].ctx.sync()
+                    print("rank 0: no error", flush=True)
+                except sihlib.SeaiceHipError as e:
+                    print(f"rank 0 reported: {e}", flush=True)
+            else:
+                dom.comm.agree_on_exchange_inside(dom)
+            dist.barrier()
+            vs.seaice_mesh_pool_destroy(dom)
+            dist.destroy_process_group()
+            return
         vs.seaice_run_velocity_solver(dom)
+        if os.environ.get("SIH_TEST_DUMP"):
+            sv, vv = dom.blocklist[0].structs["velocity_solver"], dom.blocklist[0].structs["velocity_variational"]
+            np.savez(os.path.join(os.environ["SIH_TEST_DUMP"], f"rank{rank}.npz"), u=sv["uVelocity"], v=sv["vVelocity"],
+                     s11=vv["stress11"], s22=vv["stress22"], s12=vv["stress12"], div=sv["divergence"])
         adv.seaice_run_advection(dom)
         if upwind:
             from mpas_seaice_amd import advection_upwind

@@ -86,6 +86,43 @@ def test_exchange_inside_the_persistent_kernel(mesh, ranks, extra):
     assert out.stdout.count("launches 2 with exchange 1") == ranks, out.stdout
 
 
+def _run_ranks(mesh, ranks, extra, env_extra, timeout=400):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "dist_worker.py"), "gpu", mesh] + extra
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_exchange_inside_the_kernel_changes_no_bit(tmp_path):
+    """the same three-rank run with the exchanges between the launches and inside the one launch: every array of
+    every block, halo entries included, must be the same bits"""
+    res = []
+    for inside in ("0", "1"):
+        d = tmp_path / inside
+        d.mkdir()
+        out = _run_ranks("QU240", 3, ["p2p", "deep"], {"SIH_PERSIST_EXCHANGE": inside, "SIH_TEST_DUMP": str(d)})
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+        assert out.stdout.count(f"with exchange {inside}") == 3, out.stdout
+        res.append([np.load(d / f"rank{r}.npz") for r in range(3)])
+    for a, b in zip(*res):
+        assert np.abs(a["u"]).max() > 0
+        for k in a.files:
+            assert np.array_equal(a[k], b[k]), k
+
+
+def test_a_silent_neighbour_ends_the_kernel_with_the_exchange_inside():
+    """Rank 1 agrees to exchange inside the kernel and then never launches: rank 0's launch must not hang.  Its
+    waits are bounded (here 300 ms), every workgroup leaves, and the host gets an error that says why."""
+    out = _run_ranks("geo8", 2, ["p2p", "deep", "silent"], {"SIH_PERSIST_TIMEOUT_MS": "300"}, timeout=120)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "rank 0 reported:" in out.stdout and "did not arrive in time" in out.stdout, out.stdout
+
+
 @pytest.mark.parametrize("nblocks,interval,graph", [(2, 1, False), (4, 1, True), (3, 3, False), (4, 4, True)])
 def test_overlapped_exchange_is_bit_identical(nblocks, interval, graph):
     """The exchange hidden behind interior work (send vertices first, interior cells of the next iteration
