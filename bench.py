@@ -311,7 +311,25 @@ def main():
     }
     if world > 1:
         out["exchange"] = {"transport": res["transport"], "rendezvous_backend": res["rendezvous_backend"],
-                           "us_per_exchange_in_a_chain_of_50": res["exchange_us"], "block_cells_with_halo": block_cells}
+                           "us_per_exchange_in_a_chain_of_50": res["exchange_us"], "block_cells_with_halo": block_cells,
+                           "inside_the_subcycle_kernel": res["exchange_inside_kernel"],
+                           "inside_note": res["exchange_inside_note"] or None}
+        if res["persistent_kernel"]:
+            # the block is small enough to stay on the chip: one launch runs all iterations of a step, the two-kernel
+            # timings above are not what ran.  Its tables never leave registers and LDS, so the figure below (the
+            # bytes the two-kernel form would have to move per iteration over the time an iteration took) is an
+            # equivalent rate, not HBM traffic.
+            it_ms = ms_per_step / nsub
+            eq = (b_cell + b_vert) * block_cells / (it_ms * 1e-3) / 1e9
+            out["roofline"].update({
+                "kernel": "k_sub_persistent (all iterations of a step in one launch: tiles of 64 cells resident on the "
+                          "chip, per-corner sums handed from tile to tile, halo values"
+                          + (" exchanged inside the launch)" if res["exchange_inside_kernel"] else " exchanged between launches)"),
+                "bound": "hbm", "achieved": eq, "frac": eq / HBM_PEAK_GBS, "kernel_ms": it_ms, "vertex_kernel_ms": None,
+                "algorithmic_bytes_per_launch": (b_cell + b_vert) * block_cells, "layout_bytes_per_launch": None,
+                "frac_layout": None, "traffic": None, "frac_counter": None,
+                "traffic_source": "equivalent rate of a chip-resident kernel: bytes of the two-kernel form per iteration "
+                                  "over the time an iteration took (step time / iterations, exchanges included)"})
     if world == 1 and not args.no_hbm_only and mesh_label == "QU60":
         out["roofline"]["hbm_only"] = hbm_only_pass(local_rank)
     if world == 1 and advection is not None:
