@@ -63,15 +63,24 @@ struct PersistArgs {
 // launch without exchange pays nothing for it).  Velocities and stresses travel as in the exchange between launches
 // (uVelocity, vVelocity, stress11/22/12 of every list entry), but each value is two 8-byte words
 // {low 32 bits | tag << 32}, {high 32 bits | tag << 32} with tag = number of the exchange: a word is there when its
-// tag is, no flag and no fence.  The slots exist twice (parity of the tag).  A tile sends what its own cells and
-// the vertices it stores hold, straight from LDS into the neighbour's memory, and goes on; a thread whose corner or
-// vertex is in a receive list polls its own slots.  Tiles away from the block's edge never wait for a neighbour.
+// tag is, no flag and no fence.  The slots exist twice (parity of the tag).  A thread sends what its own corner
+// (or the vertex it stores at the end) holds, straight from its registers into the neighbour's memory, and goes
+// on; a thread whose corner or vertex is in a receive list polls its own slots.  Tiles away from the block's edge
+// never wait for a neighbour.
 struct PersistXchg {
-    const int *sendStart;                          // per tile: its entries [sendStart[t], sendStart[t+1])
-    const int *sendSrc, *sendItem, *sendPeer, *sendSlot;  // kind << 28 | index in LDS; cell or vertex; rank; slot there
-    char *const *peerBase;                         // per rank: its tagged region, half 0, in this address space
-    const unsigned long long *peerHalf;            // per rank: bytes of one half
-    const int *recvCBase, *recvCStride;            // per (corner, cell) [g * padC + c]: first slot (-1: none), stride between the three stresses
+    const int *tileActive;                         // per tile: it sends or receives something
+    // what a cell sends: destinations [cellDestStart[c], cellDestStart[c+1]), each the address of the cell's first
+    // slot (stress11, corner 0) in half 0 of a neighbour's region, that region's half size, and the neighbour's
+    // count of received cells (slots between two corners; maxEdges times that between two stresses)
+    const int *cellDestStart;
+    const unsigned long long *cellDestAddr, *cellDestHalf;
+    const int *cellDestCnt;
+    // what the entries of tileVerts send (only the copy that is stored at the end has destinations): uVelocity's
+    // slot, the half size, the neighbour's count of received vertices (slots between uVelocity and vVelocity)
+    const int *vertDestStart;
+    const unsigned long long *vertDestAddr, *vertDestHalf;
+    const int *vertDestCnt;
+    const int *recvCBase, *recvCStride;            // per (corner, cell) [g * padC + c]: first slot (-1: none), slots between two stresses
     const int *recvVBase, *recvVStride;            // per entry of tileVerts
     const char *myBase;                            // this block's tagged region, half 0
     unsigned long long myHalf;
@@ -133,6 +142,10 @@ __device__ inline void stAgent(unsigned long long *p, unsigned long long x)
     __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ inline unsigned long long ldSystem(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ inline unsigned int ldSystem32(const unsigned int *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -475,58 +488,62 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
         if (sDead) break;  // the same answer in every thread: written before the barrier, not again after it
         if (XCHG && (it % xInterval == 0 || it == nIter)) {
             // ================= halo update of velocities and stresses with the neighbouring blocks
-            const PersistXchg X = *xp;
             xDone++;
+            if (xp->tileActive[tile] == 0) continue;  // nothing of this tile travels (the same answer in every thread)
+            const PersistXchg X = *xp;
             const unsigned long long tag = ((xseq0 + xDone) & 0xffffffffULL) << 32;
             const unsigned long long par = (xseq0 + xDone) & 1ULL;
-            for (int i = X.sendStart[tile] + tid, iEnd = X.sendStart[tile + 1]; i < iEnd; i += 64 * M) {
-                const int src = X.sendSrc[i], item = X.sendItem[i], peer = X.sendPeer[i];
-                const int kind = src >> 28, idx = src & 0x0fffffff;
-                double val;
-                if (kind < 3) {
-                    // idx = corner * 64 + cell within the tile.  A corner the kernel does not update (no ice, or
-                    // past the cell's last edge) sends what memory holds, as the exchange between launches does.
-                    const int gg = idx >> 6, ll = idx & 63;
-                    const bool upd = d.solveStress[item] == 1 && gg < d.nEdgesOnCell[item];
-                    if (upd)
-                        val = kind == 0 ? s11[gg][ll] : kind == 1 ? s22[gg][ll] : s12[gg][ll];
-                    else
-                        val = (kind == 0 ? X.stress11 : kind == 1 ? X.stress22 : X.stress12)[(size_t)gg * P + item];
-                } else {
-                    val = kind == 3 ? uT[idx] : vT[idx];
+            if (inRange) {
+                for (int e = X.cellDestStart[c], eEnd = X.cellDestStart[c + 1]; e < eEnd; e++) {
+                    // A corner the kernel does not update (no ice, or past the cell's last edge) sends what memory
+                    // holds, as the exchange between launches does.
+                    const unsigned long long b11 = bitsOf(corner ? o11 : X.stress11[k]);
+                    const unsigned long long b22 = bitsOf(corner ? o22 : X.stress22[k]);
+                    const unsigned long long b12 = bitsOf(corner ? o12 : X.stress12[k]);
+                    const size_t cnt = (size_t)X.cellDestCnt[e];
+                    unsigned long long *dst = (unsigned long long *)(X.cellDestAddr[e] + par * X.cellDestHalf[e]) + 2 * (size_t)g * cnt;
+                    const size_t fs = 2 * (size_t)M * cnt;
+                    stSystem(dst, (b11 & 0xffffffffULL) | tag);
+                    stSystem(dst + 1, (b11 >> 32) | tag);
+                    stSystem(dst + fs, (b22 & 0xffffffffULL) | tag);
+                    stSystem(dst + fs + 1, (b22 >> 32) | tag);
+                    stSystem(dst + 2 * fs, (b12 & 0xffffffffULL) | tag);
+                    stSystem(dst + 2 * fs + 1, (b12 >> 32) | tag);
                 }
-                const unsigned long long b = bitsOf(val);
-                unsigned long long *dst = (unsigned long long *)(X.peerBase[peer] + par * X.peerHalf[peer]) + 2 * (size_t)X.sendSlot[i];
-                stSystem(dst, (b & 0xffffffffULL) | tag);
-                stSystem(dst + 1, (b >> 32) | tag);
+            }
+            if (hasV) {
+                for (int e = X.vertDestStart[v0 + tid], eEnd = X.vertDestStart[v0 + tid + 1]; e < eEnd; e++) {
+                    const unsigned long long bu = bitsOf(uu), bv = bitsOf(vv);
+                    unsigned long long *dst = (unsigned long long *)(X.vertDestAddr[e] + par * X.vertDestHalf[e]);
+                    const size_t fs = 2 * (size_t)X.vertDestCnt[e];
+                    stSystem(dst, (bu & 0xffffffffULL) | tag);
+                    stSystem(dst + 1, (bu >> 32) | tag);
+                    stSystem(dst + fs, (bv & 0xffffffffULL) | tag);
+                    stSystem(dst + fs + 1, (bv >> 32) | tag);
+                }
             }
             const int rb = inRange ? X.recvCBase[k] : -1, rs = rb >= 0 ? X.recvCStride[k] : 0;
             const int vb = hasV ? X.recvVBase[v0 + tid] : -1, vstr = vb >= 0 ? X.recvVStride[v0 + tid] : 0;
             const unsigned long long *mine = (const unsigned long long *)(X.myBase + par * X.myHalf);
-            unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, y0 = 0, y1 = 0, y2 = 0, y3 = 0;
+            // The upper half of every word is the tag: poll those (ten dwords a thread at most), fetch the words
+            // once all of them are there.
+            const unsigned int tag32 = (unsigned int)(tag >> 32);
+            const unsigned int *tc = (const unsigned int *)(mine + 2 * (size_t)(rb >= 0 ? rb : 0)) + 1;
+            const unsigned int *tv = (const unsigned int *)(mine + 2 * (size_t)(vb >= 0 ? vb : 0)) + 1;
             {
                 long long t0 = 0;
                 for (int spins = 1;; spins++) {
                     bool ready = true;
                     if (rb >= 0) {
-                        const unsigned long long *q = mine + 2 * (size_t)rb;
-                        w0 = ldSystem(q);
-                        w1 = ldSystem(q + 1);
-                        w2 = ldSystem(q + 2 * (size_t)rs);
-                        w3 = ldSystem(q + 2 * (size_t)rs + 1);
-                        w4 = ldSystem(q + 4 * (size_t)rs);
-                        w5 = ldSystem(q + 4 * (size_t)rs + 1);
-                        ready = ((w0 ^ tag) >> 32) == 0 && ((w1 ^ tag) >> 32) == 0 && ((w2 ^ tag) >> 32) == 0 &&
-                                ((w3 ^ tag) >> 32) == 0 && ((w4 ^ tag) >> 32) == 0 && ((w5 ^ tag) >> 32) == 0;
+                        const unsigned int a0 = ldSystem32(tc), a1 = ldSystem32(tc + 2);
+                        const unsigned int a2 = ldSystem32(tc + 4 * (size_t)rs), a3 = ldSystem32(tc + 4 * (size_t)rs + 2);
+                        const unsigned int a4 = ldSystem32(tc + 8 * (size_t)rs), a5 = ldSystem32(tc + 8 * (size_t)rs + 2);
+                        ready = a0 == tag32 && a1 == tag32 && a2 == tag32 && a3 == tag32 && a4 == tag32 && a5 == tag32;
                     }
                     if (vb >= 0) {
-                        const unsigned long long *q = mine + 2 * (size_t)vb;
-                        y0 = ldSystem(q);
-                        y1 = ldSystem(q + 1);
-                        y2 = ldSystem(q + 2 * (size_t)vstr);
-                        y3 = ldSystem(q + 2 * (size_t)vstr + 1);
-                        ready = ready && ((y0 ^ tag) >> 32) == 0 && ((y1 ^ tag) >> 32) == 0 && ((y2 ^ tag) >> 32) == 0 &&
-                                ((y3 ^ tag) >> 32) == 0;
+                        const unsigned int a0 = ldSystem32(tv), a1 = ldSystem32(tv + 2);
+                        const unsigned int a2 = ldSystem32(tv + 4 * (size_t)vstr), a3 = ldSystem32(tv + 4 * (size_t)vstr + 2);
+                        ready = ready && a0 == tag32 && a1 == tag32 && a2 == tag32 && a3 == tag32;
                     }
                     if (__all(ready)) break;
                     if ((spins & 7) == 0) {
@@ -545,13 +562,17 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
                 }
             }
             if (rb >= 0) {
-                o11 = valueOf((w0 & 0xffffffffULL) | (w1 << 32));
-                o22 = valueOf((w2 & 0xffffffffULL) | (w3 << 32));
-                o12 = valueOf((w4 & 0xffffffffULL) | (w5 << 32));
+                const unsigned long long *q = mine + 2 * (size_t)rb;
+                const size_t fs = 2 * (size_t)rs;
+                o11 = valueOf((ldSystem(q) & 0xffffffffULL) | (ldSystem(q + 1) << 32));
+                o22 = valueOf((ldSystem(q + fs) & 0xffffffffULL) | (ldSystem(q + fs + 1) << 32));
+                o12 = valueOf((ldSystem(q + 2 * fs) & 0xffffffffULL) | (ldSystem(q + 2 * fs + 1) << 32));
             }
             if (vb >= 0) {
-                uu = valueOf((y0 & 0xffffffffULL) | (y1 << 32));
-                vv = valueOf((y2 & 0xffffffffULL) | (y3 << 32));
+                const unsigned long long *q = mine + 2 * (size_t)vb;
+                const size_t fs = 2 * (size_t)vstr;
+                uu = valueOf((ldSystem(q) & 0xffffffffULL) | (ldSystem(q + 1) << 32));
+                vv = valueOf((ldSystem(q + fs) & 0xffffffffULL) | (ldSystem(q + fs + 1) << 32));
                 uT[tid] = uu;
                 vT[tid] = vv;
             }
@@ -802,24 +823,24 @@ static int exchangeSetup(sih_ctx *c)
                 ownerTile[s->hVerts[j]] = tl;
                 ownerPos[s->hVerts[j]] = j - s->hVStart[tl];
             }
-    // ---- what every tile sends
-    struct Entry {
-        int src, item, peer, slot;
-    };
-    std::vector<std::vector<Entry>> perTile(nT);
+    // ---- what every cell and every stored vertex sends
+    std::vector<int> tileActive(nT, 0);
+    std::vector<std::vector<int>> cellDest(nC), vertDest(s->hVerts.size());  // indices into the flat entry arrays
+    std::vector<unsigned long long> cAddr, cHalf, vAddr, vHalf;
+    std::vector<int> cCnt, vCnt;
     {
         size_t at = 0;
         for (int p = 0; p < nR; p++) {
-            const int cnt = c->hSendCounts[0][p], cntV = c->hSendCounts[1][p];
+            const int cnt = c->hSendCounts[0][p];
             for (int r = 0; r < cnt; r++, at++) {
                 const int cell = c->hSend[0][at];
                 if (cell < 0 || cell >= nC) return SIH_OK;
-                for (int f = 0; f < 3; f++)
-                    for (int g = 0; g < M; g++)
-                        perTile[cell / 64].push_back(Entry{(f << 28) | (g * 64 + cell % 64), cell, p,
-                                                           (int)t.peerSlotOff[p] + (f * M + g) * cnt + r});
+                cellDest[cell].push_back((int)cAddr.size());
+                cAddr.push_back((unsigned long long)(uintptr_t)t.peerBase[p] + 16ULL * (t.peerSlotOff[p] + (size_t)r));
+                cHalf.push_back(t.peerHalfBytes[p]);
+                cCnt.push_back(cnt);
+                tileActive[cell / 64] = 1;
             }
-            (void)cntV;
         }
         at = 0;
         for (int p = 0; p < nR; p++) {
@@ -827,21 +848,34 @@ static int exchangeSetup(sih_ctx *c)
             for (int r = 0; r < cntV; r++, at++) {
                 const int v = c->hSend[1][at];
                 if (v < 0 || v >= nV || ownerTile[v] < 0) return SIH_OK;  // a vertex no tile holds: no in-kernel exchange
-                for (int f = 0; f < 2; f++)
-                    perTile[ownerTile[v]].push_back(Entry{((3 + f) << 28) | ownerPos[v], v, p,
-                                                          (int)t.peerSlotOff[p] + 3 * M * cnt + f * cntV + r});
+                vertDest[s->hVStart[ownerTile[v]] + ownerPos[v]].push_back((int)vAddr.size());
+                vAddr.push_back((unsigned long long)(uintptr_t)t.peerBase[p] +
+                                16ULL * (t.peerSlotOff[p] + (size_t)3 * M * cnt + (size_t)r));
+                vHalf.push_back(t.peerHalfBytes[p]);
+                vCnt.push_back(cntV);
+                tileActive[ownerTile[v]] = 1;
             }
         }
     }
-    std::vector<int> sStart(nT + 1, 0), sSrc, sItem, sPeer, sSlot;
-    for (int tl = 0; tl < nT; tl++) {
-        for (const Entry &e : perTile[tl]) {
-            sSrc.push_back(e.src);
-            sItem.push_back(e.item);
-            sPeer.push_back(e.peer);
-            sSlot.push_back(e.slot);
+    // entries in the order of their senders
+    std::vector<int> cStart(nC + 1, 0), vStartD(s->hVerts.size() + 1, 0);
+    std::vector<unsigned long long> cAddrS, cHalfS, vAddrS, vHalfS;
+    std::vector<int> cCntS, vCntS;
+    for (int i = 0; i < nC; i++) {
+        for (int e : cellDest[i]) {
+            cAddrS.push_back(cAddr[e]);
+            cHalfS.push_back(cHalf[e]);
+            cCntS.push_back(cCnt[e]);
         }
-        sStart[tl + 1] = (int)sSrc.size();
+        cStart[i + 1] = (int)cAddrS.size();
+    }
+    for (size_t j = 0; j < s->hVerts.size(); j++) {
+        for (int e : vertDest[j]) {
+            vAddrS.push_back(vAddr[e]);
+            vHalfS.push_back(vHalf[e]);
+            vCntS.push_back(vCnt[e]);
+        }
+        vStartD[j + 1] = (int)vAddrS.size();
     }
     // ---- what every corner and every listed vertex receives
     std::vector<int> rcBase((size_t)M * P, -1), rcStride((size_t)M * P, 0);
@@ -857,6 +891,7 @@ static int exchangeSetup(sih_ctx *c)
                     rcBase[(size_t)g * P + cell] = (int)t.mySlotOff[p] + g * cnt + r;
                     rcStride[(size_t)g * P + cell] = M * cnt;
                 }
+                tileActive[cell / 64] = 1;
             }
         }
         at = 0;
@@ -871,25 +906,23 @@ static int exchangeSetup(sih_ctx *c)
         }
     }
     std::vector<int> rvBase(s->hVerts.size(), -1), rvStride(s->hVerts.size(), 0);
-    for (size_t j = 0; j < s->hVerts.size(); j++) {
-        rvBase[j] = rvBaseOfVertex[s->hVerts[j]];
-        rvStride[j] = rvStrideOfVertex[s->hVerts[j]];
-    }
-    std::vector<char *> pb(nR, nullptr);
-    std::vector<unsigned long long> ph(nR, 0);
-    for (int p = 0; p < nR; p++) {
-        pb[p] = t.peerBase[p];
-        ph[p] = t.peerHalfBytes[p];
-    }
+    for (int tl = 0; tl < nT; tl++)
+        for (int j = s->hVStart[tl]; j < s->hVStart[tl + 1]; j++) {
+            rvBase[j] = rvBaseOfVertex[s->hVerts[j]];
+            rvStride[j] = rvStrideOfVertex[s->hVerts[j]];
+            if (rvBase[j] >= 0) tileActive[tl] = 1;
+        }
     PersistXchg x{};
     int rc;
-    if ((rc = uploadX(s, &x.sendStart, sStart))) return rc;
-    if ((rc = uploadX(s, &x.sendSrc, sSrc))) return rc;
-    if ((rc = uploadX(s, &x.sendItem, sItem))) return rc;
-    if ((rc = uploadX(s, &x.sendPeer, sPeer))) return rc;
-    if ((rc = uploadX(s, &x.sendSlot, sSlot))) return rc;
-    if ((rc = uploadX<char *>(s, (char *const **)&x.peerBase, pb))) return rc;
-    if ((rc = uploadX(s, &x.peerHalf, ph))) return rc;
+    if ((rc = uploadX(s, &x.tileActive, tileActive))) return rc;
+    if ((rc = uploadX(s, &x.cellDestStart, cStart))) return rc;
+    if ((rc = uploadX(s, &x.cellDestAddr, cAddrS))) return rc;
+    if ((rc = uploadX(s, &x.cellDestHalf, cHalfS))) return rc;
+    if ((rc = uploadX(s, &x.cellDestCnt, cCntS))) return rc;
+    if ((rc = uploadX(s, &x.vertDestStart, vStartD))) return rc;
+    if ((rc = uploadX(s, &x.vertDestAddr, vAddrS))) return rc;
+    if ((rc = uploadX(s, &x.vertDestHalf, vHalfS))) return rc;
+    if ((rc = uploadX(s, &x.vertDestCnt, vCntS))) return rc;
     if ((rc = uploadX(s, &x.recvCBase, rcBase))) return rc;
     if ((rc = uploadX(s, &x.recvCStride, rcStride))) return rc;
     if ((rc = uploadX(s, &x.recvVBase, rvBase))) return rc;
