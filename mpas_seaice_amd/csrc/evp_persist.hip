@@ -63,24 +63,26 @@ struct PersistArgs {
 // launch without exchange pays nothing for it).  Velocities and stresses travel as in the exchange between launches
 // (uVelocity, vVelocity, stress11/22/12 of every list entry), but each value is two 8-byte words
 // {low 32 bits | tag << 32}, {high 32 bits | tag << 32} with tag = number of the exchange: a word is there when its
-// tag is, no flag and no fence.  The slots exist twice (parity of the tag).  A thread sends what its own corner
+// tag is, no flag and no fence.  The words exist twice (parity of the tag).  They are laid out in planes ordered by
+// the sender's own numbering, so that a sending wave, whose lanes hold consecutive cells, writes consecutive words
+// (whole lines on the link, not one 8-byte packet a value).  A thread sends what its own corner
 // (or the vertex it stores at the end) holds, straight from its registers into the neighbour's memory, and goes
 // on; a thread whose corner or vertex is in a receive list polls its own slots.  Tiles away from the block's edge
 // never wait for a neighbour.
 struct PersistXchg {
     const int *tileActive;                         // per tile: it sends or receives something
     // what a cell sends: destinations [cellDestStart[c], cellDestStart[c+1]), each the address of the cell's first
-    // slot (stress11, corner 0) in half 0 of a neighbour's region, that region's half size, and the neighbour's
-    // count of received cells (slots between two corners; maxEdges times that between two stresses)
+    // word (stress11, corner 0, low word) in half 0 of a neighbour's region, that region's half size, and the
+    // neighbour's count of received cells: the words are planes of that many, [stress][corner][low / high]
     const int *cellDestStart;
     const unsigned long long *cellDestAddr, *cellDestHalf;
     const int *cellDestCnt;
-    // what the entries of tileVerts send (only the copy that is stored at the end has destinations): uVelocity's
-    // slot, the half size, the neighbour's count of received vertices (slots between uVelocity and vVelocity)
+    // what the entries of tileVerts send (only the copy that is stored at the end has destinations): the low word
+    // of uVelocity, the half size, the neighbour's count of received vertices (planes [u, v][low / high])
     const int *vertDestStart;
     const unsigned long long *vertDestAddr, *vertDestHalf;
     const int *vertDestCnt;
-    const int *recvCBase, *recvCStride;            // per (corner, cell) [g * padC + c]: first slot (-1: none), slots between two stresses
+    const int *recvCBase, *recvCStride;            // per (corner, cell) [g * padC + c]: first word (-1: none), words in a plane
     const int *recvVBase, *recvVStride;            // per entry of tileVerts
     const char *myBase;                            // this block's tagged region, half 0
     unsigned long long myHalf;
@@ -504,22 +506,22 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
                     unsigned long long *dst = (unsigned long long *)(X.cellDestAddr[e] + par * X.cellDestHalf[e]) + 2 * (size_t)g * cnt;
                     const size_t fs = 2 * (size_t)M * cnt;
                     stSystem(dst, (b11 & 0xffffffffULL) | tag);
-                    stSystem(dst + 1, (b11 >> 32) | tag);
+                    stSystem(dst + cnt, (b11 >> 32) | tag);
                     stSystem(dst + fs, (b22 & 0xffffffffULL) | tag);
-                    stSystem(dst + fs + 1, (b22 >> 32) | tag);
+                    stSystem(dst + fs + cnt, (b22 >> 32) | tag);
                     stSystem(dst + 2 * fs, (b12 & 0xffffffffULL) | tag);
-                    stSystem(dst + 2 * fs + 1, (b12 >> 32) | tag);
+                    stSystem(dst + 2 * fs + cnt, (b12 >> 32) | tag);
                 }
             }
             if (hasV) {
                 for (int e = X.vertDestStart[v0 + tid], eEnd = X.vertDestStart[v0 + tid + 1]; e < eEnd; e++) {
                     const unsigned long long bu = bitsOf(uu), bv = bitsOf(vv);
                     unsigned long long *dst = (unsigned long long *)(X.vertDestAddr[e] + par * X.vertDestHalf[e]);
-                    const size_t fs = 2 * (size_t)X.vertDestCnt[e];
+                    const size_t cnt = (size_t)X.vertDestCnt[e];
                     stSystem(dst, (bu & 0xffffffffULL) | tag);
-                    stSystem(dst + 1, (bu >> 32) | tag);
-                    stSystem(dst + fs, (bv & 0xffffffffULL) | tag);
-                    stSystem(dst + fs + 1, (bv >> 32) | tag);
+                    stSystem(dst + cnt, (bu >> 32) | tag);
+                    stSystem(dst + 2 * cnt, (bv & 0xffffffffULL) | tag);
+                    stSystem(dst + 3 * cnt, (bv >> 32) | tag);
                 }
             }
             const int rb = inRange ? X.recvCBase[k] : -1, rs = rb >= 0 ? X.recvCStride[k] : 0;
@@ -528,21 +530,22 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
             // The upper half of every word is the tag: poll those (ten dwords a thread at most), fetch the words
             // once all of them are there.
             const unsigned int tag32 = (unsigned int)(tag >> 32);
-            const unsigned int *tc = (const unsigned int *)(mine + 2 * (size_t)(rb >= 0 ? rb : 0)) + 1;
-            const unsigned int *tv = (const unsigned int *)(mine + 2 * (size_t)(vb >= 0 ? vb : 0)) + 1;
+            const unsigned int *tc = (const unsigned int *)(mine + (size_t)(rb >= 0 ? rb : 0)) + 1;
+            const unsigned int *tv = (const unsigned int *)(mine + (size_t)(vb >= 0 ? vb : 0)) + 1;
+            const size_t cw = 2 * (size_t)rs, cf = 4 * (size_t)M * rs, vw = 2 * (size_t)vstr;  // in dwords
             {
                 long long t0 = 0;
                 for (int spins = 1;; spins++) {
                     bool ready = true;
                     if (rb >= 0) {
-                        const unsigned int a0 = ldSystem32(tc), a1 = ldSystem32(tc + 2);
-                        const unsigned int a2 = ldSystem32(tc + 4 * (size_t)rs), a3 = ldSystem32(tc + 4 * (size_t)rs + 2);
-                        const unsigned int a4 = ldSystem32(tc + 8 * (size_t)rs), a5 = ldSystem32(tc + 8 * (size_t)rs + 2);
+                        const unsigned int a0 = ldSystem32(tc), a1 = ldSystem32(tc + cw);
+                        const unsigned int a2 = ldSystem32(tc + cf), a3 = ldSystem32(tc + cf + cw);
+                        const unsigned int a4 = ldSystem32(tc + 2 * cf), a5 = ldSystem32(tc + 2 * cf + cw);
                         ready = a0 == tag32 && a1 == tag32 && a2 == tag32 && a3 == tag32 && a4 == tag32 && a5 == tag32;
                     }
                     if (vb >= 0) {
-                        const unsigned int a0 = ldSystem32(tv), a1 = ldSystem32(tv + 2);
-                        const unsigned int a2 = ldSystem32(tv + 4 * (size_t)vstr), a3 = ldSystem32(tv + 4 * (size_t)vstr + 2);
+                        const unsigned int a0 = ldSystem32(tv), a1 = ldSystem32(tv + vw);
+                        const unsigned int a2 = ldSystem32(tv + 2 * vw), a3 = ldSystem32(tv + 3 * vw);
                         ready = ready && a0 == tag32 && a1 == tag32 && a2 == tag32 && a3 == tag32;
                     }
                     if (__all(ready)) break;
@@ -562,17 +565,16 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
                 }
             }
             if (rb >= 0) {
-                const unsigned long long *q = mine + 2 * (size_t)rb;
-                const size_t fs = 2 * (size_t)rs;
-                o11 = valueOf((ldSystem(q) & 0xffffffffULL) | (ldSystem(q + 1) << 32));
-                o22 = valueOf((ldSystem(q + fs) & 0xffffffffULL) | (ldSystem(q + fs + 1) << 32));
-                o12 = valueOf((ldSystem(q + 2 * fs) & 0xffffffffULL) | (ldSystem(q + 2 * fs + 1) << 32));
+                const unsigned long long *q = mine + (size_t)rb;
+                const size_t fs = 2 * (size_t)M * rs;
+                o11 = valueOf((ldSystem(q) & 0xffffffffULL) | (ldSystem(q + rs) << 32));
+                o22 = valueOf((ldSystem(q + fs) & 0xffffffffULL) | (ldSystem(q + fs + rs) << 32));
+                o12 = valueOf((ldSystem(q + 2 * fs) & 0xffffffffULL) | (ldSystem(q + 2 * fs + rs) << 32));
             }
             if (vb >= 0) {
-                const unsigned long long *q = mine + 2 * (size_t)vb;
-                const size_t fs = 2 * (size_t)vstr;
-                uu = valueOf((ldSystem(q) & 0xffffffffULL) | (ldSystem(q + 1) << 32));
-                vv = valueOf((ldSystem(q + fs) & 0xffffffffULL) | (ldSystem(q + fs + 1) << 32));
+                const unsigned long long *q = mine + (size_t)vb;
+                uu = valueOf((ldSystem(q) & 0xffffffffULL) | (ldSystem(q + vstr) << 32));
+                vv = valueOf((ldSystem(q + 2 * (size_t)vstr) & 0xffffffffULL) | (ldSystem(q + 3 * (size_t)vstr) << 32));
                 uT[tid] = uu;
                 vT[tid] = vv;
             }
@@ -836,7 +838,7 @@ static int exchangeSetup(sih_ctx *c)
                 const int cell = c->hSend[0][at];
                 if (cell < 0 || cell >= nC) return SIH_OK;
                 cellDest[cell].push_back((int)cAddr.size());
-                cAddr.push_back((unsigned long long)(uintptr_t)t.peerBase[p] + 16ULL * (t.peerSlotOff[p] + (size_t)r));
+                cAddr.push_back((unsigned long long)(uintptr_t)t.peerBase[p] + 8ULL * (t.peerWordOff[p] + (size_t)t.sendPos[0][at]));
                 cHalf.push_back(t.peerHalfBytes[p]);
                 cCnt.push_back(cnt);
                 tileActive[cell / 64] = 1;
@@ -850,7 +852,7 @@ static int exchangeSetup(sih_ctx *c)
                 if (v < 0 || v >= nV || ownerTile[v] < 0) return SIH_OK;  // a vertex no tile holds: no in-kernel exchange
                 vertDest[s->hVStart[ownerTile[v]] + ownerPos[v]].push_back((int)vAddr.size());
                 vAddr.push_back((unsigned long long)(uintptr_t)t.peerBase[p] +
-                                16ULL * (t.peerSlotOff[p] + (size_t)3 * M * cnt + (size_t)r));
+                                8ULL * (t.peerWordOff[p] + (size_t)6 * M * cnt + (size_t)t.sendPos[1][at]));
                 vHalf.push_back(t.peerHalfBytes[p]);
                 vCnt.push_back(cntV);
                 tileActive[ownerTile[v]] = 1;
@@ -888,8 +890,8 @@ static int exchangeSetup(sih_ctx *c)
                 const int cell = c->hRecv[0][at];
                 if (cell < 0 || cell >= nC) return SIH_OK;
                 for (int g = 0; g < M; g++) {
-                    rcBase[(size_t)g * P + cell] = (int)t.mySlotOff[p] + g * cnt + r;
-                    rcStride[(size_t)g * P + cell] = M * cnt;
+                    rcBase[(size_t)g * P + cell] = (int)(t.myWordOff[p] + (size_t)2 * g * cnt + (size_t)t.recvPos[0][at]);
+                    rcStride[(size_t)g * P + cell] = cnt;
                 }
                 tileActive[cell / 64] = 1;
             }
@@ -900,7 +902,7 @@ static int exchangeSetup(sih_ctx *c)
             for (int r = 0; r < cntV; r++, at++) {
                 const int v = c->hRecv[1][at];
                 if (v < 0 || v >= nV || ownerTile[v] < 0) return SIH_OK;
-                rvBaseOfVertex[v] = (int)t.mySlotOff[p] + 3 * M * cnt + r;
+                rvBaseOfVertex[v] = (int)(t.myWordOff[p] + (size_t)6 * M * cnt + (size_t)t.recvPos[1][at]);
                 rvStrideOfVertex[v] = cntV;
             }
         }

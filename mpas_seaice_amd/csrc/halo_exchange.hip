@@ -45,9 +45,13 @@ struct sih_comm_blob {
     unsigned long long slotOff[SIH_COMM_MAXR];  // byte offset inside one half of the slot for messages from rank p
     unsigned long long slotCap[SIH_COMM_MAXR];  // its capacity in bytes
     // the tagged region (velocities and stresses exchanged from inside the persistent subcycle kernel): two halves
-    // of 16-byte slots behind the plain halves; first slot and slot count of the segment for messages from rank p
-    unsigned long long taggedOff, taggedHalfBytes;
-    unsigned long long tSlotOff[SIH_COMM_MAXR], tSlotCnt[SIH_COMM_MAXR];
+    // of 8-byte words behind the plain halves, then the set-up words (one per received cell and vertex, written
+    // once by the sender: its own index of that entity, from which both sides derive the order of the words).
+    // Per rank p: cells and vertices received from it, first word of its segment in a half, first set-up word.
+    unsigned long long taggedOff, taggedHalfBytes, setupOff;
+    unsigned int maxEdges, pad1;
+    unsigned int rCntC[SIH_COMM_MAXR], rCntV[SIH_COMM_MAXR];
+    unsigned long long tWordOff[SIH_COMM_MAXR], sWordOff[SIH_COMM_MAXR];
 };
 
 struct CommTable {  // one field group
@@ -79,10 +83,12 @@ struct sih_comm_state {
     unsigned long long *d_state = nullptr;
     bool connected = false;
     int generation = 0;  // changes whenever the lists or the peers' addresses may have changed
-    size_t taggedOff = 0, taggedHalfBytes = 0;
-    std::vector<size_t> tSlotOff, tSlotCnt;              // receive side, per peer
+    size_t taggedOff = 0, taggedHalfBytes = 0, setupOff = 0, setupWords = 0;
+    std::vector<size_t> tWordOff, sWordOff;              // receive side, per peer: first word of its segment / set-up words
     std::vector<char *> peerTagged;                      // peer p's tagged region (half 0) in this address space
-    std::vector<size_t> peerTHalf, peerTSlotOff;         // its half size; first slot of my segment there
+    std::vector<size_t> peerTHalf, peerTWordOff;         // its half size; first word of my segment there
+    std::vector<int> sendPos[2], recvPos[2];             // per list entry: its place in the sender's own order (recv: once known)
+    bool recvPosKnown = false;
     std::map<std::string, CommTable> tables;
     hipStream_t commStream = nullptr;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
@@ -299,18 +305,22 @@ extern "C" int sih_comm_create(sih_ctx *c, int rank, int nRanks, int maxCellPlan
     }
     s->halfBytes = std::max<size_t>(off, 256);
     s->dataOff = ((size_t)nRanks * SIH_FLAG_STRIDE + 4095) & ~(size_t)4095;
-    // tagged slots: per received cell the three stresses at every corner, per received vertex the two velocities
-    s->tSlotOff.assign(nRanks, 0);
-    s->tSlotCnt.assign(nRanks, 0);
-    size_t tSlots = 0;
+    // tagged words: per received cell the three stresses at every corner, per received vertex the two velocities,
+    // two words a value
+    s->tWordOff.assign(nRanks, 0);
+    s->sWordOff.assign(nRanks, 0);
+    size_t tWords = 0, sWords = 0;
     for (int p = 0; p < nRanks; p++) {
-        s->tSlotOff[p] = tSlots;
-        s->tSlotCnt[p] = (size_t)3 * c->M * c->hRecvCounts[0][p] + (size_t)2 * c->hRecvCounts[1][p];
-        tSlots += s->tSlotCnt[p];
+        s->tWordOff[p] = tWords;
+        s->sWordOff[p] = sWords;
+        tWords += (size_t)6 * c->M * c->hRecvCounts[0][p] + (size_t)4 * c->hRecvCounts[1][p];
+        sWords += (size_t)c->hRecvCounts[0][p] + (size_t)c->hRecvCounts[1][p];
     }
-    s->taggedHalfBytes = (std::max<size_t>(tSlots * 16, 256) + 255) & ~(size_t)255;
+    s->taggedHalfBytes = (std::max<size_t>(tWords * 8, 256) + 255) & ~(size_t)255;
     s->taggedOff = s->dataOff + 2 * s->halfBytes;
-    s->allocBytes = s->taggedOff + 2 * s->taggedHalfBytes;
+    s->setupOff = s->taggedOff + 2 * s->taggedHalfBytes;
+    s->setupWords = sWords;
+    s->allocBytes = s->setupOff + ((std::max<size_t>(sWords * 8, 256) + 255) & ~(size_t)255);
     static int generations = 0;
     s->generation = ++generations;
     // uncached device memory where the runtime has it (remote stores and local polls then never meet a stale
@@ -391,14 +401,25 @@ extern "C" int sih_comm_get_handle(sih_ctx *c, void *blob)
     HIPCHK(hipIpcGetMemHandle(&b.mem, s->base));
     b.taggedOff = s->taggedOff;
     b.taggedHalfBytes = s->taggedHalfBytes;
+    b.setupOff = s->setupOff;
+    b.maxEdges = (unsigned int)c->M;
     for (int p = 0; p < s->nRanks; p++) {
         b.slotOff[p] = s->slotOff[p];
         b.slotCap[p] = s->slotCap[p];
-        b.tSlotOff[p] = s->tSlotOff[p];
-        b.tSlotCnt[p] = s->tSlotCnt[p];
+        b.rCntC[p] = (unsigned int)c->hRecvCounts[0][p];
+        b.rCntV[p] = (unsigned int)c->hRecvCounts[1][p];
+        b.tWordOff[p] = s->tWordOff[p];
+        b.sWordOff[p] = s->sWordOff[p];
     }
     memcpy(blob, &b, sizeof b);
     return SIH_OK;
+}
+
+// one-time stores of the set-up words into the neighbours' memory
+__global__ void k_setup_store(const unsigned long long *dst, const unsigned long long *val, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) __hip_atomic_store((unsigned long long *)(uintptr_t)dst[i], val[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 extern "C" int sih_comm_connect(sih_ctx *c, const void *allHandles)
@@ -416,7 +437,23 @@ extern "C" int sih_comm_connect(sih_ctx *c, const void *allHandles)
     s->peerSlotCap.assign(n, 0);
     s->peerTagged.assign(n, nullptr);
     s->peerTHalf.assign(n, 0);
-    s->peerTSlotOff.assign(n, 0);
+    s->peerTWordOff.assign(n, 0);
+    s->recvPosKnown = false;
+    // the order in which this block's kernel meets the entities it sends: by its own (internal) index
+    std::vector<unsigned long long> setupDst;
+    std::vector<unsigned long long> setupVal;
+    for (int loc = 0; loc < 2; loc++) {
+        s->sendPos[loc].assign(c->hSend[loc].size(), 0);
+        size_t at = 0;
+        for (int p = 0; p < n; p++) {
+            const int cnt = c->hSendCounts[loc][p];
+            std::vector<std::pair<int, int>> byIndex(cnt);
+            for (int r = 0; r < cnt; r++) byIndex[r] = {c->hSend[loc][at + r], r};
+            std::sort(byIndex.begin(), byIndex.end());
+            for (int k = 0; k < cnt; k++) s->sendPos[loc][at + byIndex[k].second] = k;
+            at += cnt;
+        }
+    }
     std::vector<char *> dstBase(n, nullptr);
     std::vector<unsigned long long> dstHalf(n, 0);
     std::vector<unsigned long long *> dstFlag(n, nullptr);
@@ -445,10 +482,26 @@ extern "C" int sih_comm_connect(sih_ctx *c, const void *allHandles)
         s->peerBase[p] = base;
         s->peerSlotCap[p] = b.slotCap[s->rank];
         // the tagged segment the peer keeps for this rank must be what this rank will send
-        if (b.tSlotCnt[s->rank] == (unsigned long long)3 * c->M * c->hSendCounts[0][p] + (unsigned long long)2 * c->hSendCounts[1][p]) {
+        if (b.maxEdges == (unsigned int)c->M && b.rCntC[s->rank] == (unsigned int)c->hSendCounts[0][p] &&
+            b.rCntV[s->rank] == (unsigned int)c->hSendCounts[1][p]) {
             s->peerTagged[p] = base + b.taggedOff;
             s->peerTHalf[p] = b.taggedHalfBytes;
-            s->peerTSlotOff[p] = b.tSlotOff[s->rank];
+            s->peerTWordOff[p] = b.tWordOff[s->rank];
+            // set-up words for this peer: the internal index of every entity this rank sends to it, in list order
+            size_t atC = 0, atV = 0;
+            for (int q = 0; q < p; q++) {
+                atC += c->hSendCounts[0][q];
+                atV += c->hSendCounts[1][q];
+            }
+            unsigned long long *w = (unsigned long long *)(base + b.setupOff) + b.sWordOff[s->rank];
+            for (int r = 0; r < c->hSendCounts[0][p]; r++) {
+                setupDst.push_back((unsigned long long)(uintptr_t)(w + r));
+                setupVal.push_back((unsigned long long)(unsigned int)c->hSend[0][atC + r] | (1ULL << 32));
+            }
+            for (int r = 0; r < c->hSendCounts[1][p]; r++) {
+                setupDst.push_back((unsigned long long)(uintptr_t)(w + c->hSendCounts[0][p] + r));
+                setupVal.push_back((unsigned long long)(unsigned int)c->hSend[1][atV + r] | (1ULL << 32));
+            }
         }
         dstBase[p] = base + b.dataOff + b.slotOff[s->rank];
         dstHalf[p] = b.halfBytes;
@@ -462,6 +515,20 @@ extern "C" int sih_comm_connect(sih_ctx *c, const void *allHandles)
     HIPCHK(hipMemcpy(s->d_dstBase, dstBase.data(), sizeof(char *) * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->d_dstHalf, dstHalf.data(), sizeof(unsigned long long) * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->d_dstFlag, dstFlag.data(), sizeof(unsigned long long *) * n, hipMemcpyHostToDevice));
+    if (!setupDst.empty()) {
+        unsigned long long *dDst = nullptr, *dVal = nullptr;
+        const size_t nb = sizeof(unsigned long long) * setupDst.size();
+        HIPCHK(hipMalloc((void **)&dDst, nb));
+        HIPCHK(hipMalloc((void **)&dVal, nb));
+        HIPCHK(hipMemcpy(dDst, setupDst.data(), nb, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dVal, setupVal.data(), nb, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_setup_store, dim3((unsigned)((setupDst.size() + 255) / 256)), dim3(256), 0, c->stream, dDst, dVal,
+                           (int)setupDst.size());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));  // the words are in the neighbours' memory when this call returns
+        HIPCHK(hipFree(dDst));
+        HIPCHK(hipFree(dVal));
+    }
     s->connected = true;
     static int connects = 1000000;
     s->generation = ++connects;
@@ -476,14 +543,45 @@ bool sih_comm_tagged_info(sih_ctx *c, sih_comm_tagged *out)
     if (!s || !s->connected) return false;
     out->generation = s->generation;
     out->nRanks = s->nRanks;
-    out->myBase = s->base + s->taggedOff;
-    out->myHalfBytes = s->taggedHalfBytes;
-    out->mySlotOff = s->tSlotOff;
-    out->peerBase = s->peerTagged;
-    out->peerHalfBytes = s->peerTHalf;
-    out->peerSlotOff = s->peerTSlotOff;
     for (int p = 0; p < s->nRanks; p++)
         if (s->sendTot[p] > 0 && !s->peerTagged[p]) return false;
+    if (!s->recvPosKnown) {
+        // the neighbours' set-up words: all there once every neighbour has connected
+        std::vector<unsigned long long> w(std::max<size_t>(s->setupWords, 1));
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return false;
+        if (s->setupWords &&
+            hipMemcpy(w.data(), s->base + s->setupOff, sizeof(unsigned long long) * s->setupWords, hipMemcpyDeviceToHost) != hipSuccess)
+            return false;
+        for (size_t i = 0; i < s->setupWords; i++)
+            if ((w[i] >> 32) != 1ULL) {
+                out->generation = 0;  // not yet: ask again later
+                return false;
+            }
+        for (int loc = 0; loc < 2; loc++) {
+            s->recvPos[loc].assign(c->hRecv[loc].size(), 0);
+            size_t at = 0;
+            for (int p = 0; p < s->nRanks; p++) {
+                const int cnt = c->hRecvCounts[loc][p];
+                const size_t first = s->sWordOff[p] + (loc == 1 ? (size_t)c->hRecvCounts[0][p] : 0);
+                std::vector<std::pair<unsigned int, int>> byIndex(cnt);
+                for (int r = 0; r < cnt; r++) byIndex[r] = {(unsigned int)(w[first + r] & 0xffffffffULL), r};
+                std::sort(byIndex.begin(), byIndex.end());
+                for (int k = 0; k < cnt; k++) s->recvPos[loc][at + byIndex[k].second] = k;
+                at += cnt;
+            }
+        }
+        s->recvPosKnown = true;
+    }
+    out->myBase = s->base + s->taggedOff;
+    out->myHalfBytes = s->taggedHalfBytes;
+    out->myWordOff = s->tWordOff;
+    out->peerBase = s->peerTagged;
+    out->peerHalfBytes = s->peerTHalf;
+    out->peerWordOff = s->peerTWordOff;
+    for (int loc = 0; loc < 2; loc++) {
+        out->sendPos[loc] = s->sendPos[loc];
+        out->recvPos[loc] = s->recvPos[loc];
+    }
     return true;
 }
 

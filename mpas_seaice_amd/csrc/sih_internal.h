@@ -146,15 +146,19 @@ int sih_comm_push(sih_ctx *c, int nFields, const char *const *names, hipStream_t
 int sih_comm_pull(sih_ctx *c, int nFields, const char *const *names, hipStream_t stream);
 int sih_comm_prepare(sih_ctx *c, int nFields, const char *const *names);  // builds the group's tables (not capturable)
 bool sih_comm_ready(sih_ctx *c);
-// the tagged region of the transport: 16-byte slots {low word | tag << 32, high word | tag << 32} that carry their
-// own arrival signal, written and polled from inside the persistent subcycle kernel
+// The tagged region of the transport: 8-byte words {half a value | tag << 32} that carry their own arrival signal,
+// written and polled from inside the persistent subcycle kernel.  A neighbour's segment holds, for the cells it
+// sends, planes of words [stress 0..2][corner][low / high word][place] and, behind them, for its vertices
+// [u, v][low / high word][place]; "place" is the entity's rank in the SENDER's own numbering among what it sends
+// to that neighbour, so that the lanes of a sending wave, which hold consecutive cells, write consecutive words.
 struct sih_comm_tagged {
     int generation = 0, nRanks = 0;
     char *myBase = nullptr;  // half 0 of this block's region
     size_t myHalfBytes = 0;
-    std::vector<size_t> mySlotOff;                 // first slot of the segment for messages from rank p
-    std::vector<char *> peerBase;                  // rank p's region (half 0) in this address space
-    std::vector<size_t> peerHalfBytes, peerSlotOff;  // its half size; first slot of this rank's segment there
+    std::vector<size_t> myWordOff;                   // first word of the segment for messages from rank p
+    std::vector<char *> peerBase;                    // rank p's region (half 0) in this address space
+    std::vector<size_t> peerHalfBytes, peerWordOff;  // its half size; first word of this rank's segment there
+    std::vector<int> sendPos[2], recvPos[2];         // per entry of the send / receive lists (cells, vertices): its place
 };
 bool sih_comm_tagged_info(sih_ctx *c, sih_comm_tagged *out);
 // n iterations in the persistent kernel with the halo update of velocities and stresses inside it, after every
