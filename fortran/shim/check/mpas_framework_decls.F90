@@ -234,6 +234,11 @@ contains
     real(kind=RKIND), intent(in) :: r
     real(kind=RKIND), intent(out) :: global_min
   end subroutine mpas_dmpar_min_real
+  subroutine mpas_dmpar_min_int(dminfo, i, global_min)
+    type(dm_info), intent(in) :: dminfo
+    integer, intent(in) :: i
+    integer, intent(out) :: global_min
+  end subroutine mpas_dmpar_min_int
   subroutine mpas_dmpar_sum_real(dminfo, r, global_sum)
     type(dm_info), intent(in) :: dminfo
     real(kind=RKIND), intent(in) :: r
