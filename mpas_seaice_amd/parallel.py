@@ -379,7 +379,7 @@ class DistComm(CommBase):
 class PeerComm(DistComm):
     """One block per process; the halo messages travel inside the library (sih_halo_exchange): every neighbour
     stores its message straight into this block's receive buffer, mapped through HIP IPC (over xGMI between
-    GPUs), and the receiver waits for it on the device.  ``torch.distributed`` only carries the 1.2 KB handles
+    GPUs), and the receiver waits for it on the device.  ``torch.distributed`` only carries the 2.7 KB handles
     at set-up and the scalar reductions; no collective and no host synchronisation is on the data path."""
     in_library = True  # the subcycle loop can run with its exchanges inside the library
 
