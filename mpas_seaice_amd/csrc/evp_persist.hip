@@ -968,7 +968,8 @@ int sih_persist_status(sih_ctx *c)
     unsigned long long st = 0;
     HIPCHK(hipMemcpy(&st, c->persist->a.state + PS_STATUS, sizeof st, hipMemcpyDeviceToHost));
     if (st) {
-        sih_set_error(st == 1   ? "persistent subcycle kernel: its workgroups were not resident together"
+        sih_set_error(st == 1   ? "persistent subcycle kernel: its workgroups were not resident together (is the GPU shared with other "
+                                  "work? SIH_PERSISTENT=0 or sih_evp_set_persistent(ctx, 0) keeps the two-kernel form)"
                       : st == 2 ? "persistent subcycle kernel: a wait for a neighbouring tile ran out of time"
                                 : "persistent subcycle kernel: a neighbouring block's halo values did not arrive in time");
         c->persist->usable = false;
