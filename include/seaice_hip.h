@@ -278,7 +278,8 @@ int sih_evp_subcycle_persistent(sih_ctx *ctx, int n);
  * qualifies: 0 the two-kernel form; 1 (the default) the persistent kernel with the halo exchanges between its
  * launches; 2 the persistent kernel with the exchanges of sih_evp_subcycle_exchange inside it: one launch for all
  * iterations but the last, in which the tiles at the block's edge store their velocities and stresses straight into
- * the neighbours' memory and poll for theirs, and the tiles inside never wait for a neighbour.  Mode 2 speaks
+ * the neighbours' memory and poll for theirs (for at most SIH_HALO_TIMEOUT_MS, default 10 s, then the launch ends
+ * with an error), and the tiles inside never wait for a neighbour.  Mode 2 speaks
  * another protocol than the exchange between launches, so all blocks that exchange with each other must run it or
  * none: the host asks every block (sih_get_info "persistentExchangeReady" = 1 when the block qualifies and its
  * transport is connected), takes the minimum over the ranks and sets mode 2 on all of them or on none.  -1 goes

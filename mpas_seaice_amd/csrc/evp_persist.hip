@@ -46,7 +46,7 @@
 #define COS_TURN 1.0
 
 // words of the state array; the census counters sit 128 bytes apart behind the first line
-enum { PS_EPOCH = 0, PS_LAUNCHES = 1, PS_STATUS = 2, PS_TICKS = 3, PS_XSEQ = 4, PS_CENSUS = 16, PS_CENSUS_N = 32, PS_CENSUS_STRIDE = 16,
+enum { PS_EPOCH = 0, PS_LAUNCHES = 1, PS_STATUS = 2, PS_TICKS = 3, PS_XSEQ = 4, PS_XTICKS = 5, PS_CENSUS = 16, PS_CENSUS_N = 32, PS_CENSUS_STRIDE = 16,
        PS_WORDS = PS_CENSUS + PS_CENSUS_N * PS_CENSUS_STRIDE };
 #define PS_MARKER 0xFFF8C0DEDEADBEEFULL  // "not written yet": a NaN with a payload no operation produces
 
@@ -191,7 +191,10 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
         const int b = blockIdx.x, q = nT / 8, r = nT % 8, x = b % 8;
         tile = x * q + (x < r ? x : r) + b / 8;
     }
-    const unsigned long long limit = ldAgent(&p.state[PS_TICKS]);
+    // time limits (read where a wait looks at the clock, every eighth turn: no register is held for them): of the
+    // census, and of the waits for sums and halo values.  With the exchange inside, a tile that waits for sums may
+    // be waiting, through its neighbours, for another block that entered its step later: the longer limit.
+    constexpr int LIMIT_WORD = XCHG ? PS_XTICKS : PS_TICKS;
     const unsigned long long launches = ldAgent(&p.state[PS_LAUNCHES]);
     const unsigned long long epoch = ldAgent(&p.state[PS_EPOCH]);  // iterations done by earlier launches
     const unsigned long long xseq0 = XCHG ? ldAgent(&p.state[PS_XSEQ]) : 0ULL;  // exchanges done by earlier launches
@@ -309,7 +312,7 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
         while (good) {
             const unsigned long long have = ldAgent(&p.state[PS_CENSUS + j * PS_CENSUS_STRIDE]);
             if (__all(have >= want)) break;
-            if ((unsigned long long)(wall_clock64() - t0) > limit || ldAgent(&p.state[PS_STATUS]) != 0ULL) {
+            if ((unsigned long long)(wall_clock64() - t0) > ldAgent(&p.state[PS_TICKS]) || ldAgent(&p.state[PS_STATUS]) != 0ULL) {
                 if (tid == 0)
                     __hip_atomic_fetch_max(&p.state[PS_STATUS], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 good = false;
@@ -431,7 +434,7 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
                     const long long now = wall_clock64();
                     if (t0 == 0) {
                         t0 = now;
-                    } else if ((unsigned long long)(now - t0) > limit || ldAgent(&p.state[PS_STATUS]) != 0ULL) {
+                    } else if ((unsigned long long)(now - t0) > ldAgent(&p.state[LIMIT_WORD]) || ldAgent(&p.state[PS_STATUS]) != 0ULL) {
                         // give up: this iteration runs to its end on whatever was read, then everyone leaves
                         if (lane == 0) {
                             __hip_atomic_fetch_max(&p.state[PS_STATUS], 2ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -553,7 +556,7 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
                         const long long now = wall_clock64();
                         if (t0 == 0) {
                             t0 = now;
-                        } else if ((unsigned long long)(now - t0) > limit || ldAgent(&p.state[PS_STATUS]) != 0ULL) {
+                        } else if ((unsigned long long)(now - t0) > ldAgent(&p.state[LIMIT_WORD]) || ldAgent(&p.state[PS_STATUS]) != 0ULL) {
                             if (lane == 0) {
                                 __hip_atomic_fetch_max(&p.state[PS_STATUS], 3ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 sDead = 1;
@@ -729,6 +732,11 @@ int sih_persist_setup(sih_ctx *c)
     unsigned long long ticks = 2ULL * 100000000ULL;  // 2 s of the 100 MHz wall clock
     if (const char *e = getenv("SIH_PERSIST_TIMEOUT_MS")) ticks = (unsigned long long)(atof(e) * 100000.0);
     HIPCHK(hipMemcpy(a.state + PS_TICKS, &ticks, sizeof ticks, hipMemcpyHostToDevice));
+    // waits for another block's halo values: that block may start its step later (10 s, or what was asked for)
+    unsigned long long xticks = 10ULL * 100000000ULL;
+    if (const char *e = getenv("SIH_HALO_TIMEOUT_MS")) xticks = (unsigned long long)(atof(e) * 100000.0);
+    if (getenv("SIH_PERSIST_TIMEOUT_MS") || xticks < ticks) xticks = ticks;
+    HIPCHK(hipMemcpy(a.state + PS_XTICKS, &xticks, sizeof xticks, hipMemcpyHostToDevice));
     // probe: a launch of zero iterations runs the census only.  If its workgroups are not all resident together it
     // says so within the time limit and the two-kernel form stays in use.
     s->usable = true;
