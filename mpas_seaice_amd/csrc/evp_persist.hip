@@ -63,7 +63,7 @@ struct PersistArgs {
 // launch without exchange pays nothing for it).  Velocities and stresses travel as in the exchange between launches
 // (uVelocity, vVelocity, stress11/22/12 of every list entry), but each value is two 8-byte words
 // {low 32 bits | tag << 32}, {high 32 bits | tag << 32} with tag = number of the exchange: a word is there when its
-// tag is, no flag and no fence.  The words exist twice (parity of the tag).  They are laid out in planes ordered by
+// tag is, no flag and no fence.  The words exist in four copies used in turn (tag modulo 4).  They are laid out in planes ordered by
 // the sender's own numbering, so that a sending wave, whose lanes hold consecutive cells, writes consecutive words
 // (whole lines on the link, not one 8-byte packet a value).  A thread sends what its own corner
 // (or the vertex it stores at the end) holds, straight from its registers into the neighbour's memory, and goes
@@ -72,19 +72,19 @@ struct PersistArgs {
 struct PersistXchg {
     const int *tileActive;                         // per tile: it sends or receives something
     // what a cell sends: destinations [cellDestStart[c], cellDestStart[c+1]), each the address of the cell's first
-    // word (stress11, corner 0, low word) in half 0 of a neighbour's region, that region's half size, and the
+    // word (stress11, corner 0, low word) in copy 0 of a neighbour's region, the size of one copy, and the
     // neighbour's count of received cells: the words are planes of that many, [stress][corner][low / high]
     const int *cellDestStart;
     const unsigned long long *cellDestAddr, *cellDestHalf;
     const int *cellDestCnt;
     // what the entries of tileVerts send (only the copy that is stored at the end has destinations): the low word
-    // of uVelocity, the half size, the neighbour's count of received vertices (planes [u, v][low / high])
+    // of uVelocity, the size of one copy, the neighbour's count of received vertices (planes [u, v][low / high])
     const int *vertDestStart;
     const unsigned long long *vertDestAddr, *vertDestHalf;
     const int *vertDestCnt;
     const int *recvCBase, *recvCStride;            // per (corner, cell) [g * padC + c]: first word (-1: none), words in a plane
     const int *recvVBase, *recvVStride;            // per entry of tileVerts
-    const char *myBase;                            // this block's tagged region, half 0
+    const char *myBase;                            // this block's tagged region, copy 0
     unsigned long long myHalf;
     const double *stress11, *stress22, *stress12;  // for the corners the kernel does not update
 };
@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
             if (xp->tileActive[tile] == 0) continue;  // nothing of this tile travels (the same answer in every thread)
             const PersistXchg X = *xp;
             const unsigned long long tag = ((xseq0 + xDone) & 0xffffffffULL) << 32;
-            const unsigned long long par = (xseq0 + xDone) & 1ULL;
+            const unsigned long long par = (xseq0 + xDone) % SIH_TAGGED_COPIES;
             if (inRange) {
                 for (int e = X.cellDestStart[c], eEnd = X.cellDestStart[c + 1]; e < eEnd; e++) {
                     // A corner the kernel does not update (no ice, or past the cell's last edge) sends what memory

@@ -151,10 +151,16 @@ bool sih_comm_ready(sih_ctx *c);
 // sends, planes of words [stress 0..2][corner][low / high word][place] and, behind them, for its vertices
 // [u, v][low / high word][place]; "place" is the entity's rank in the SENDER's own numbering among what it sends
 // to that neighbour, so that the lanes of a sending wave, which hold consecutive cells, write consecutive words.
+// The words exist SIH_TAGGED_COPIES times, used in turn (number of the exchange modulo the count).  Two would do
+// when a block can never be two exchanges ahead of the neighbour that still reads: that holds through the chain
+// "what I send in exchange e+2 depends on what you sent in e+1, which you computed after reading e", but the
+// chain runs from tile to tile inside the reading block and needs the halo to be thin against the exchange
+// interval; with four copies no such argument is needed for any interval >= 1.
+#define SIH_TAGGED_COPIES 4
 struct sih_comm_tagged {
     int generation = 0, nRanks = 0;
-    char *myBase = nullptr;  // half 0 of this block's region
-    size_t myHalfBytes = 0;
+    char *myBase = nullptr;  // copy 0 of this block's region
+    size_t myHalfBytes = 0;  // bytes of one copy
     std::vector<size_t> myWordOff;                   // first word of the segment for messages from rank p
     std::vector<char *> peerBase;                    // rank p's region (half 0) in this address space
     std::vector<size_t> peerHalfBytes, peerWordOff;  // its half size; first word of this rank's segment there
