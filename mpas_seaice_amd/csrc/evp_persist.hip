@@ -171,7 +171,7 @@ constexpr int persistLdsDoubles() { return 5 * M * 64 + 2 * 64 * M + 3 * M * 64 
 
 template <int M, bool XCHG>
 __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, PersistArgs p, int nIter,
-                                                             const PersistXchg *__restrict__ xp, int xInterval)
+                                                             const PersistXchg *__restrict__ xp, int xInterval, int xCells)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double(*su)[64] = (double(*)[64])(smem);
@@ -498,7 +498,9 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
             const PersistXchg X = *xp;
             const unsigned long long tag = ((xseq0 + xDone) & 0xffffffffULL) << 32;
             const unsigned long long par = (xseq0 + xDone) % SIH_TAGGED_COPIES;
-            if (inRange) {
+            // (xCells == 0: an exchange after every iteration carries the velocities only, as the reference's does;
+            // the stresses of the halo cells are then computed here from the received velocities)
+            if (inRange && xCells) {
                 for (int e = X.cellDestStart[c], eEnd = X.cellDestStart[c + 1]; e < eEnd; e++) {
                     // A corner the kernel does not update (no ice, or past the cell's last edge) sends what memory
                     // holds, as the exchange between launches does.
@@ -527,7 +529,7 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
                     stSystem(dst + 3 * cnt, (bv >> 32) | tag);
                 }
             }
-            const int rb = inRange ? X.recvCBase[k] : -1, rs = rb >= 0 ? X.recvCStride[k] : 0;
+            const int rb = inRange && xCells ? X.recvCBase[k] : -1, rs = rb >= 0 ? X.recvCStride[k] : 0;
             const int vb = hasV ? X.recvVBase[v0 + tid] : -1, vstr = vb >= 0 ? X.recvVStride[v0 + tid] : 0;
             const unsigned long long *mine = (const unsigned long long *)(X.myBase + par * X.myHalf);
             // The upper half of every word is the tag: poll those (ten dwords a thread at most), fetch the words
@@ -590,7 +592,7 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
     //      exchange)
     if (alive) {
         // with the exchange inside, what was received goes to memory too, updated by this kernel or not
-        const bool gotC = XCHG && xDone > 0 && inRange && xp->recvCBase[k] >= 0;
+        const bool gotC = XCHG && xCells && xDone > 0 && inRange && xp->recvCBase[k] >= 0;
         const bool gotV = XCHG && xDone > 0 && hasV && xp->recvVBase[v0 + tid] >= 0;
         if (corner || gotC) {
             d.stress11[k] = o11;
@@ -772,10 +774,10 @@ static void launchPersist(sih_ctx *c, int n, int interval)
     const size_t lds = persistLdsDoubles<M>() * sizeof(double);
     if (interval > 0)
         hipLaunchKernelGGL((k_sub_persistent<M, true>), dim3((unsigned)a.nTiles), dim3(64, M), lds, c->stream,
-                           makePersistDev(c->dev), a, n, (const PersistXchg *)c->persist->d_x, interval);
+                           makePersistDev(c->dev), a, n, (const PersistXchg *)c->persist->d_x, interval, interval > 1 ? 1 : 0);
     else
         hipLaunchKernelGGL((k_sub_persistent<M, false>), dim3((unsigned)a.nTiles), dim3(64, M), lds, c->stream,
-                           makePersistDev(c->dev), a, n, (const PersistXchg *)nullptr, 1);
+                           makePersistDev(c->dev), a, n, (const PersistXchg *)nullptr, 1, 0);
 }
 
 static int launchAny(sih_ctx *c, int n, int interval)

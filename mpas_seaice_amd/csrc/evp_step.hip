@@ -1739,7 +1739,9 @@ extern "C" int sih_evp_subcycle_exchange(sih_ctx *c, int n, int last, int interv
     int done = 0;
     bool pending = false;
     // a small block whose transport allows it: all the iterations and the exchanges between them as one launch
-    if (interval > 1 && nMain >= 2 && persistentMode(c) == 2 && usePersistent(c, nMain) && sih_persist_exchange_usable(c)) {
+    // (interval 1, the reference's order: the velocities after every iteration; deeper halos: velocities and
+    // stresses after every interval-th)
+    if (nMain >= 2 && persistentMode(c) == 2 && !c->sbVelocity && usePersistent(c, nMain) && sih_persist_exchange_usable(c)) {
         if ((rc = sih_persist_launch_exchange(c, nMain, interval))) return rc;
         done = nMain;
     }

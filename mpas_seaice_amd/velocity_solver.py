@@ -293,7 +293,7 @@ def subcycle_velocity_solver(domain, clock=None):
     if getattr(comm, "in_library", False) and not _weak_strain(domain) \
             and not domain.configs["config_average_variational_strain"]:
         # the whole loop, exchanges included, runs inside the library (sih_evp_subcycle_exchange)
-        if k > 1 and hasattr(comm, "agree_on_exchange_inside") and not hasattr(comm, "exchange_inside"):
+        if hasattr(comm, "agree_on_exchange_inside") and not hasattr(comm, "exchange_inside"):
             comm.agree_on_exchange_inside(domain)
         for b in domain.blocklist:
             b.ctx.subcycle_exchange(n, last=True, interval=k,

@@ -98,14 +98,16 @@ def _run_ranks(mesh, ranks, extra, env_extra, timeout=400):
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
 
 
-def test_exchange_inside_the_kernel_changes_no_bit(tmp_path):
-    """the same three-rank run with the exchanges between the launches and inside the one launch: every array of
-    every block, halo entries included, must be the same bits"""
+@pytest.mark.parametrize("extra", [["p2p", "deep"], ["p2p"]])
+def test_exchange_inside_the_kernel_changes_no_bit(tmp_path, extra):
+    """the same three-rank run with the exchanges between the launches and inside the one launch (velocities and
+    stresses every third iteration with three halo layers; velocities after every iteration, the reference's
+    order): every array of every block, halo entries included, must be the same bits"""
     res = []
     for inside in ("0", "1"):
         d = tmp_path / inside
         d.mkdir()
-        out = _run_ranks("QU240", 3, ["p2p", "deep"], {"SIH_PERSIST_EXCHANGE": inside, "SIH_TEST_DUMP": str(d)})
+        out = _run_ranks("QU240", 3, extra, {"SIH_PERSIST_EXCHANGE": inside, "SIH_TEST_DUMP": str(d)})
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
         assert out.stdout.count(f"with exchange {inside}") == 3, out.stdout
         res.append([np.load(d / f"rank{r}.npz") for r in range(3)])
