@@ -591,7 +591,7 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
     # they vote, and then check it on this machine's links -- one step each way from the same state must give the
     # same bits on every rank -- before the timed loop relies on it.
     inside, inside_note = False, ""
-    if transport == "p2p" and interval > 1:
+    if transport == "p2p":
         inside = dom.comm.agree_on_exchange_inside(dom)
         if inside:
             b0 = dom.blocklist[0]
