@@ -111,8 +111,8 @@ def cpu_baseline(mesh, name, max_seconds=25.0):
 def advection_timing(dom, mesh, name, reps=7, with_cpu=True):
     """Secondary measurement: one incremental-remap advection step (7 tracers, 19 layer fields x 5
     categories = 95 scalars per cell) on the same mesh, tracers resident on the device, timed with HIP
-    events inside the library; next to it the CPU oracle on a smaller mesh (it materialises the reference's
-    per-quadrature-point arrays, which at QU60 take tens of GB)."""
+    events inside the library; next to it the CPU oracle on the same mesh (it materialises the reference's
+    per-quadrature-point arrays: 15 GB of host memory at QU60; meshes beyond 200 000 cells fall back to QU240)."""
     from mpas_seaice_amd import advection as adv
     adv.seaice_init_advection(dom)
     b = dom.blocklist[0]
@@ -143,14 +143,17 @@ def advection_timing(dom, mesh, name, reps=7, with_cpu=True):
     if with_cpu:
         from mpas_seaice_amd import cases, mesh as meshmod
         from oracle import evp_flow as ora, ir_flow as ir
-        small = "QU240"
-        m2 = meshmod.make_named_mesh(small)
-        d2 = cases.make_domain(m2, small, configs={"config_elastic_subcycle_number": 4})
+        if mesh.nCells <= 200000:
+            small, m2 = name, mesh
+        else:
+            small = "QU240"
+            m2 = meshmod.make_named_mesh(small)
+        d2 = cases.make_domain(m2, small if small.startswith("QU") else None, configs={"config_elastic_subcycle_number": 4})
         ora.seaice_init_velocity_solver(d2)
         ir.seaice_init_advection(d2)
         ora.seaice_run_velocity_solver(d2)
         t0 = time.perf_counter()
-        nrep = 5
+        nrep = 5 if m2.nCells < 50000 else 3
         for _ in range(nrep):
             ir.seaice_run_advection(d2)
         dtc = (time.perf_counter() - t0) / nrep
