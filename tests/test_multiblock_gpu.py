@@ -98,11 +98,12 @@ def _run_ranks(mesh, ranks, extra, env_extra, timeout=400):
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
 
 
-@pytest.mark.parametrize("extra", [["p2p", "deep"], ["p2p"]])
+@pytest.mark.parametrize("extra", [["p2p", "deep"], ["p2p"], ["p2p", "graph", "deep"]])
 def test_exchange_inside_the_kernel_changes_no_bit(tmp_path, extra):
     """the same three-rank run with the exchanges between the launches and inside the one launch (velocities and
     stresses every third iteration with three halo layers; velocities after every iteration, the reference's
-    order): every array of every block, halo entries included, must be the same bits"""
+    order; the chunks between two exchanges replayed from HIP graphs that hold the persistent kernel): every array
+    of every block, halo entries included, must be the same bits"""
     res = []
     for inside in ("0", "1"):
         d = tmp_path / inside
