@@ -16,14 +16,15 @@
 // the two-kernel form.
 //
 // Hand-off rules (per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed):
-//   - the sums live in three buffers used in turn (iteration number modulo 3).  At the top of iteration t a corner
-//     stores a marker (a NaN bit pattern that arithmetic never produces) into its slot of buffer t+1, drains that
-//     store (s_waitcnt vmcnt(0)) and only then stores its sums of iteration t into buffer t; all of these are
-//     agent-scope atomic stores (write-through);
+//   - the sums live in four buffers used in turn (iteration number modulo 4).  In iteration t a corner drains its
+//     earlier stores (s_waitcnt vmcnt(0)), stores its sums of iteration t into buffer t and then a marker (a NaN bit
+//     pattern that arithmetic never produces) into its slot of buffer t+2; all of these are agent-scope atomic
+//     stores (write-through).  The marker of buffer t+1 was stored one iteration earlier, so the drain finds it
+//     done and costs nothing;
 //   - a vertex reads its three sums of iteration t with agent-scope atomic loads (L1 bypassed) again and again
 //     until none of them is the marker.  It cannot meet older data: it read the same three slots of buffer t-1
 //     one iteration ago, and their writers had the marker of buffer t acknowledged before they stored those;
-//   - a corner may overwrite buffer t+1 (the sums of iteration t-2): a reader of those is a tile that shares the
+//   - a corner may overwrite buffer t+2 (the sums of iteration t-2): a reader of those is a tile that shares the
 //     vertex, whose sums of iteration t-1 this tile has read since, and that tile stored them only after all its
 //     vertices had finished iteration t-2;
 //   - every wait is bounded by the wall clock; a wait that runs out sets a status word, every workgroup leaves
@@ -48,6 +49,7 @@
 // words of the state array; the census counters sit 128 bytes apart behind the first line
 enum { PS_EPOCH = 0, PS_LAUNCHES = 1, PS_STATUS = 2, PS_TICKS = 3, PS_XSEQ = 4, PS_XTICKS = 5, PS_CENSUS = 16, PS_CENSUS_N = 32, PS_CENSUS_STRIDE = 16,
        PS_WORDS = PS_CENSUS + PS_CENSUS_N * PS_CENSUS_STRIDE };
+#define PS_RING 4  // buffers of the partial sums, used in turn
 #define PS_MARKER 0xFFF8C0DEDEADBEEFULL  // "not written yet": a NaN with a payload no operation produces
 
 struct PersistArgs {
@@ -55,7 +57,7 @@ struct PersistArgs {
     const int *tileVertStart, *tileVerts;  // vertices of a tile's cells: tileVerts[tileVertStart[t] .. tileVertStart[t+1])
     const int *tileVertOwned;              // same indexing: 1 where this tile is the one that stores the vertex at the end
     const int *cornerSlot;                 // per (corner, cell) [g * padC + c]: position of its vertex in the tile's list
-    unsigned long long *part;              // the partial sums: [buffer 0..2][U, V][corner * padC + cell]
+    unsigned long long *part;              // the partial sums: [buffer 0..PS_RING-1][U, V][corner * padC + cell]
     unsigned long long *state;             // PS_* words
 };
 
@@ -291,10 +293,13 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
     // ---- census: every workgroup of the launch is resident, and has marked its slots of the first buffer, before
     //      anything is computed
     {
-        unsigned long long *b1 = p.part + ((epoch + 1ULL) % 3ULL) * 2ULL * plane;
+        unsigned long long *b1 = p.part + ((epoch + 1ULL) % PS_RING) * 2ULL * plane;
+        unsigned long long *b2 = p.part + ((epoch + 2ULL) % PS_RING) * 2ULL * plane;
         if (corner) {
             stAgent(&b1[k], PS_MARKER);
             stAgent(&b1[plane + k], PS_MARKER);
+            stAgent(&b2[k], PS_MARKER);
+            stAgent(&b2[plane + k], PS_MARKER);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -332,17 +337,12 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
     unsigned int xDone = 0;  // exchanges of this launch so far
     const double dtE = d.dtE, T = d.dampT, brlx = d.brlx, dtD = d.dtDyn;
     const int relation = d.relation;
-    int sl = (int)(epoch % 3ULL);  // buffer of the iteration before the one at hand
+    int sl = (int)(epoch % PS_RING);  // buffer of the iteration before the one at hand
 
     for (int it = 1; it <= nIter && alive; it++) {
-        sl = sl == 2 ? 0 : sl + 1;
+        sl = (sl + 1) % PS_RING;
         unsigned long long *pU = p.part + (size_t)sl * 2 * plane, *pV = pU + plane;
         // ================= cells: strain, stress, partial sums of the divergence (k_sub_cells_split)
-        if (corner) {
-            unsigned long long *nU = p.part + (size_t)(sl == 2 ? 0 : sl + 1) * 2 * plane;
-            stAgent(&nU[k], PS_MARKER);
-            stAgent(&nU[plane + k], PS_MARKER);
-        }
         const double ug = uT[slot], vg = vT[slot];
         su[g][lane] = corner ? ug : 0.0;
         sv[g][lane] = corner ? vg : 0.0;
@@ -406,10 +406,16 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
                     cv = cv - x22 * bv - x12 * bu + x11 * bm * tg;
                 }
             }
-            // the markers of the next buffer are in memory before these sums can be seen
+            // the markers of the next buffer (stored one iteration ago) are in memory before these sums can be seen
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stAgent(&pU[k], bitsOf(cu));
             stAgent(&pV[k], bitsOf(cv));
+            // ... and the buffer after the next takes its markers now: it holds the sums of two iterations ago, which
+            // every reader has finished with (this tile has since read what those readers computed from them), and the
+            // stores have a whole iteration to land before the wait above comes round again
+            unsigned long long *nU = p.part + (size_t)((sl + 2) % PS_RING) * 2 * plane;
+            stAgent(&nU[k], PS_MARKER);
+            stAgent(&nU[plane + k], PS_MARKER);
         }
 
         // ================= vertices: divergence, ocean stress coefficient, velocity solve (k_sub_vertices), for
@@ -715,7 +721,7 @@ int sih_persist_setup(sih_ctx *c)
         ownedFlag.push_back(0);
     }
     // the three buffers of the partial sums, zero where no corner ever writes (the slot that stands for "no cell")
-    if ((rc = sih_add_field(c, "_partRing", LOC_CELL, 6 * M, false))) return rc;
+    if ((rc = sih_add_field(c, "_partRing", LOC_CELL, 2 * PS_RING * M, false))) return rc;
     s->hVStart = vStart;
     s->hVerts = verts;
     s->hOwned = ownedFlag;
