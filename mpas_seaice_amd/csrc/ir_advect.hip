@@ -657,12 +657,31 @@ __global__ void __launch_bounds__(256) k_ir_reconstruct(IrDev d, const IrTabEntr
             for (int ie = 0; ie < M; ie++)
                 if (ie < n && nb[ie] < d.nCells && P->val[lp1 + nb[ie]] > EPS11) mnbS |= 1u << ie;
         }
+        // the values of a layer (the cell's and its neighbours') are requested one layer ahead, so that their way
+        // through memory overlaps the arithmetic of the layer before (2 waves a SIMD hide nothing of it: 0.70 ->
+        // 0.52 ms at QU60; asking for a tracer's first layer during the tracer before it gained nothing more)
+        double fNext = 0.0, fnbNext[M];
+        {
+            const size_t k0 = (size_t)(cat * T.L) * pc + c;
+            fNext = T.val[k0];
+#pragma unroll
+            for (int ie = 0; ie < M; ie++) fnbNext[ie] = ice ? T.val[k0 - c + (((valid >> ie) & 1u) ? nb[ie] : c)] : 0.0;
+        }
         for (int l0 = 0; l0 < T.L; l0 += IR_LCHUNK) {
         const int nlc = min(IR_LCHUNK, T.L - l0);
         for (int layer = l0; layer < l0 + nlc; layer++) {
             const size_t k = (size_t)(cat * T.L + layer) * pc + c;
             const size_t lp = hasParent ? (size_t)(P->L == 1 ? cat : cat * T.L + layer) * pc : 0;
-            const double f = T.val[k];
+            const double f = fNext;
+            double fnbCur[M];
+#pragma unroll
+            for (int ie = 0; ie < M; ie++) fnbCur[ie] = fnbNext[ie];
+            if (layer + 1 < T.L) {  // the tracers' values are inputs here: nothing writes them
+                const size_t k1 = k + pc;
+                fNext = T.val[k1];
+#pragma unroll
+                for (int ie = 0; ie < M; ie++) fnbNext[ie] = ice ? T.val[k1 - c + (((valid >> ie) & 1u) ? nb[ie] : c)] : 0.0;
+            }
             T.prod[k] = (hasParent ? (sharedMask ? pprodS : P->prod[lp + c]) : 1.0) * f;
             double xb, yb;
             if (sharedMask) {
@@ -685,7 +704,7 @@ __global__ void __launch_bounds__(256) k_ir_reconstruct(IrDev d, const IrTabEntr
                 for (int ie = 0; ie < M; ie++) {
                     const bool has = ((valid >> ie) & 1u) != 0;
                     const int nbi = has ? nb[ie] : c;
-                    const double fnb = T.val[k - c + nbi];
+                    const double fnb = fnbCur[ie];
                     bool mnb = has;
                     if (hasParent) mnb = mnb && (sharedMask ? ((mnbS >> ie) & 1u) != 0 : (P->val[lp + nbi] > EPS11));
                     // sg * (fnb - f) with sg = +-1 is the difference taken one way or the other
