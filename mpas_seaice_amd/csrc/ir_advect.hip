@@ -1158,12 +1158,21 @@ struct IrStep {
 // one tracer (all its layers) on one triangle: value at the quadrature points times the parent's (level > 0),
 // the integral added to the tracer's rows in LDS, the values left for the children if it has any
 template <int LEVEL>
-__device__ __forceinline__ void irWalkStep(const IrDev &d, const double *__restrict__ rec, int L, double *f, double area,
+__device__ __forceinline__ void irWalkStep(const IrDev &d, const double *__restrict__ rec, int L,
+                                           const double *__restrict__ nextRec, double (&cur)[3], double *f, double area,
                                            const double (&xq)[6], const double (&yq)[6], const double (&par)[6],
                                            double (&own)[6], bool keep, bool first)
 {
     for (int ly = 0; ly < L; ly++) {
-        const double cj = rec[ly * 3], gxj = rec[ly * 3 + 1], gyj = rec[ly * 3 + 2];
+        // `cur` holds this layer's record; the next one (the next layer's, or the first of the next tracer) is
+        // requested now, so that it travels while this layer is worked on
+        const double cj = cur[0], gxj = cur[1], gyj = cur[2];
+        const double *nx = ly + 1 < L ? rec + (ly + 1) * 3 : nextRec;
+        if (nx) {
+            cur[0] = nx[0];
+            cur[1] = nx[1];
+            cur[2] = nx[2];
+        }
         double val[6];
 #pragma unroll
         for (int q = 0; q < 6; q++) {
@@ -1187,7 +1196,7 @@ __device__ __forceinline__ void irWalkStep(const IrDev &d, const double *__restr
     }
 }
 
-__global__ void __launch_bounds__(256) k_ir_flux_walk(IrDev d, const IrTabEntry *__restrict__ tab,
+__global__ void __launch_bounds__(256, 4) k_ir_flux_walk(IrDev d, const IrTabEntry *__restrict__ tab,
                                                       const IrStep *__restrict__ steps, int nSteps, int nSlots)
 {
     extern __shared__ double fl[];  // [nSlots][256]
@@ -1217,24 +1226,37 @@ __global__ void __launch_bounds__(256) k_ir_flux_walk(IrDev d, const IrTabEntry 
         double lv0[6], lv1[6], lv2[6];  // values of the current ancestors at the quadrature points, by level
 #pragma unroll
         for (int q = 0; q < 6; q++) lv0[q] = lv1[q] = lv2[q] = 1.0;
+        double cur[3];
+        {
+            const IrTabEntry T0 = tab[steps[0].ti];
+            const double *r0 = T0.rec + IR_REC(T0, cat, pc, c, 0);
+            cur[0] = r0[0];
+            cur[1] = r0[1];
+            cur[2] = r0[2];
+        }
         for (int si = 0; si < nSteps; si++) {
             const IrStep S = steps[si];  // the same for every lane: the branches below are scalar
             const IrTabEntry T = tab[S.ti];
             const double *rec = T.rec + IR_REC(T, cat, pc, c, 0);
+            const double *nextRec = nullptr;
+            if (si + 1 < nSteps) {
+                const IrTabEntry &N = tab[steps[si + 1].ti];
+                nextRec = N.rec + IR_REC(N, cat, pc, c, 0);
+            }
             double *f = fl + S.slot * 256 + tid;
             const bool first = S.ti == 0;
             switch (S.level) {
             case 0:
-                irWalkStep<0>(d, rec, T.L, f, area, xq, yq, lv0, lv0, S.keep != 0, first);
+                irWalkStep<0>(d, rec, T.L, nextRec, cur, f, area, xq, yq, lv0, lv0, S.keep != 0, first);
                 break;
             case 1:
-                irWalkStep<1>(d, rec, T.L, f, area, xq, yq, lv0, lv1, S.keep != 0, first);
+                irWalkStep<1>(d, rec, T.L, nextRec, cur, f, area, xq, yq, lv0, lv1, S.keep != 0, first);
                 break;
             case 2:
-                irWalkStep<2>(d, rec, T.L, f, area, xq, yq, lv1, lv2, S.keep != 0, first);
+                irWalkStep<2>(d, rec, T.L, nextRec, cur, f, area, xq, yq, lv1, lv2, S.keep != 0, first);
                 break;
             default:
-                irWalkStep<3>(d, rec, T.L, f, area, xq, yq, lv2, lv2, false, first);
+                irWalkStep<3>(d, rec, T.L, nextRec, cur, f, area, xq, yq, lv2, lv2, false, first);
             }
         }
     }
