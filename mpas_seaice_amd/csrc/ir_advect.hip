@@ -1208,10 +1208,22 @@ __global__ void __launch_bounds__(256, 4) k_ir_flux_walk(IrDev d, const IrTabEnt
     const size_t pe = d.padE, pc = d.padC;
     for (int sl = 0; sl < nSlots; sl++) fl[sl * 256 + tid] = 0.0;
     const int cnt = e < d.nEdges ? d.triCount[e] : 0;
+    // area and source cell of a triangle are requested one triangle ahead, and the first record of the next
+    // triangle with the last step of this one: a triangle then starts with one memory round trip in front of it
+    // (its vertices) instead of two in a row (its source cell, then that cell's first record)
+    double areaN = cnt > 0 ? d.triArea[e] : 0.0;
+    int cellN = cnt > 0 ? d.triCell[e] : 0;
+    double cur[3] = {0.0, 0.0, 0.0};
+    bool curReady = false;  // `cur` holds the first record of the triangle at hand
+    const IrTabEntry T0 = tab[steps[0].ti];
     for (int t = 0; t < cnt; t++) {
-        const double area = d.triArea[(size_t)t * pe + e];
-        if (area == 0.0) continue;
-        const int c = d.triCell[(size_t)t * pe + e];
+        const double area = areaN;
+        const int c = cellN;
+        if (t + 1 < cnt) {
+            areaN = d.triArea[(size_t)(t + 1) * pe + e];
+            cellN = d.triCell[(size_t)(t + 1) * pe + e];
+        }
+        if (area == 0.0) continue;  // (nothing was requested for it: see the last step below)
         const double x1 = d.xTri[(size_t)(t * 3) * pe + e], x2 = d.xTri[(size_t)(t * 3 + 1) * pe + e],
                      x3 = d.xTri[(size_t)(t * 3 + 2) * pe + e];
         const double y1 = d.yTri[(size_t)(t * 3) * pe + e], y2 = d.yTri[(size_t)(t * 3 + 1) * pe + e],
@@ -1226,9 +1238,7 @@ __global__ void __launch_bounds__(256, 4) k_ir_flux_walk(IrDev d, const IrTabEnt
         double lv0[6], lv1[6], lv2[6];  // values of the current ancestors at the quadrature points, by level
 #pragma unroll
         for (int q = 0; q < 6; q++) lv0[q] = lv1[q] = lv2[q] = 1.0;
-        double cur[3];
-        {
-            const IrTabEntry T0 = tab[steps[0].ti];
+        if (!curReady) {
             const double *r0 = T0.rec + IR_REC(T0, cat, pc, c, 0);
             cur[0] = r0[0];
             cur[1] = r0[1];
@@ -1242,6 +1252,9 @@ __global__ void __launch_bounds__(256, 4) k_ir_flux_walk(IrDev d, const IrTabEnt
             if (si + 1 < nSteps) {
                 const IrTabEntry &N = tab[steps[si + 1].ti];
                 nextRec = N.rec + IR_REC(N, cat, pc, c, 0);
+            } else {
+                curReady = t + 1 < cnt && areaN != 0.0;
+                if (curReady) nextRec = T0.rec + IR_REC(T0, cat, pc, cellN, 0);
             }
             double *f = fl + S.slot * 256 + tid;
             const bool first = S.ti == 0;
