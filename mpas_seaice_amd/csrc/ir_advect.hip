@@ -1291,7 +1291,7 @@ __global__ void __launch_bounds__(256, 4) k_ir_flux_walk(IrDev d, const IrTabEnt
 // as possible) with coalesced loads into LDS, one layer field ahead of its use, and a thread takes its six fluxes
 // from there; only the edges outside the run are gathered from memory.  (With all six gathered, the kernel took
 // 0.30 ms at QU60, of which 0.10 ms were the gathers' own.)
-#define IR_UPD_WIN 1024
+#define IR_UPD_WIN 768
 template <int M>
 __global__ void __launch_bounds__(256) k_ir_update(IrDev d, const IrTabEntry *__restrict__ tab, int nT)
 {
