@@ -915,34 +915,51 @@ __global__ void __launch_bounds__(128) k_ir_triangles(IrDev d)
         d.triCount[e] = 0;
         return;
     }
+    // everything the branches below may read of this edge is requested here, in one go: read where it is needed,
+    // each of these loads was a memory round trip of its own behind a branch (the kernel spent 84 % of its
+    // wave-cycles waiting)
+    double xo[6], yo[6];  // the edge's two vertices, then the far vertices of E1..E4
+    int en4[4], cell4[4];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        xo[j] = d.xVOE[(size_t)j * pe + e];
+        yo[j] = d.yVOE[(size_t)j * pe + e];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        en4[j] = d.eoer[(size_t)j * pe + e];
+        cell4[j] = d.coer[(size_t)j * pe + e];
+    }
     double ev[2][2], dp[2][2];
-    ev[0][0] = d.xVOE[e];
-    ev[0][1] = d.yVOE[e];
-    ev[1][0] = d.xVOE[pe + e];
-    ev[1][1] = d.yVOE[pe + e];
+    ev[0][0] = xo[0];
+    ev[0][1] = yo[0];
+    ev[1][0] = xo[1];
+    ev[1][1] = yo[1];
     dp[0][0] = ev[0][0] + d1x;
     dp[0][1] = ev[0][1] + d1y;
     dp[1][0] = ev[1][0] + d2x;
     dp[1][1] = ev[1][1] + d2y;
     int tc = 0;
     // side triangles :5711-5968
+#pragma unroll
     for (int k = 0; k < 2; k++) {
+#pragma unroll
         for (int side = 0; side < 2; side++) {
             int ieoe = k + 2 * side;  // 0-based E index: E1,E3 at V1; E2,E4 at V2
-            int en = d.eoer[(size_t)ieoe * pe + e];
+            int en = en4[ieoe];
             bool hit = false;
             double ix = 0.0, iy = 0.0, nx = 0.0, ny = 0.0;
             if (en < d.nEdges) {
-                nx = d.xVOE[(size_t)(ieoe + 2) * pe + e];
-                ny = d.yVOE[(size_t)(ieoe + 2) * pe + e];
+                nx = xo[ieoe + 2];
+                ny = yo[ieoe + 2];
                 hit = lineIntersect(dp[0][0], dp[0][1], dp[1][0], dp[1][1], ev[k][0], ev[k][1], nx, ny, ix, iy);
             }
             if (hit) {
                 double xt[3] = {ev[k][0], dp[k][0], ix}, yt[3] = {ev[k][1], dp[k][1], iy};
-                int cell = d.coer[(size_t)(k + 2) * pe + e];
+                int cell = cell4[k + 2];
                 int other = ieoe + 2;
                 if (other > 3) other = other - 4;
-                double ox = d.xVOE[(size_t)(other + 2) * pe + e], oy = d.yVOE[(size_t)(other + 2) * pe + e];
+                double ox = xo[other + 2], oy = yo[other + 2];
                 if (tc < NTRI)
                     emitTriangle(d, e, tc, xt, yt, k, cell, nx - ev[k][0], ny - ev[k][1], ox - ev[k][0], oy - ev[k][1],
                                  side == 0 ? 1 : -1);
@@ -963,6 +980,7 @@ __global__ void __launch_bounds__(128) k_ir_triangles(IrDev d)
         doCentral = (t1 + t2) > 0.0;
     }
     if (doCentral) {
+#pragma unroll
         for (int k = 0; k < 2; k++) {
             const int o = 1 - k;
             double xt[3], yt[3];
@@ -980,9 +998,9 @@ __global__ void __launch_bounds__(128) k_ir_triangles(IrDev d)
                 xt[2] = dp[1][0];  yt[2] = dp[1][1];
             }
             bool inHP = inHalfPlane(ev[0][0], ev[0][1], ev[1][0], ev[1][1], dp[k][0], dp[k][1]);
-            int cell = d.coer[(size_t)(inHP ? 0 : 1) * pe + e];
+            int cell = inHP ? cell4[0] : cell4[1];
             int other = inHP ? k : k + 2;
-            double ox = d.xVOE[(size_t)(other + 2) * pe + e], oy = d.yVOE[(size_t)(other + 2) * pe + e];
+            double ox = xo[other + 2], oy = yo[other + 2];
             if (tc < NTRI)
                 emitTriangle(d, e, tc, xt, yt, k, cell, ev[o][0] - ev[k][0], ev[o][1] - ev[k][1], ox - ev[k][0],
                              oy - ev[k][1], inHP ? 1 : -1);
