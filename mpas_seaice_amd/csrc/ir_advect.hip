@@ -56,6 +56,7 @@ struct IrDev {
     int *triCount, *triCell;
     double *xTri, *yTri, *triArea;
     int *maskCell, *flag;
+    int *triSlot;       // per (remap cell 0..3, edge vertex 0..1, edge): where that vertex sits in that cell (emitTriangle)
     const int *updWin;  // per block of 256 owned cells: first edge of the window of fluxes its update stages in LDS
 };
 
@@ -845,21 +846,48 @@ __global__ void k_ir_departure_points(IrDev d, double dt)
 }
 
 // shift_vertices_of_departure_triangle :6270-6500 followed by the signed area (:6231), then stored
-__device__ inline void emitTriangle(const IrDev &d, int e, int t, double xt[3], double yt[3], int tvoe, int cell,
-                                    double e1x, double e1y, double e2x, double e2y, int sign)
+// Set-up: for each of an edge's four remap cells and each of its two vertices, the place of that vertex among the
+// cell's vertices (0 when it is not one of them, as the search of shift_vertices_of_departure_triangle :6270 leaves
+// it) and the places before and after it, packed place | before << 8 | after << 16.
+__global__ void k_ir_init_tri_slots(IrDev d)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= d.nEdges) return;
+    const size_t pe = d.padE, pc = d.padC;
+    for (int j = 0; j < 4; j++) {
+        const int cell = d.coer[(size_t)j * pe + e];
+        for (int tvoe = 0; tvoe < 2; tvoe++) {
+            int packed = 0;
+            if (cell < d.nCells) {
+                const int n = d.nEdgesOnCell[cell];
+                const int vShared = d.voe[(size_t)tvoe * pe + e];
+                int tvoc = 0;
+                for (int iv = 0; iv < n; iv++)
+                    if (d.voc[(size_t)iv * pc + cell] == vShared) tvoc = iv;
+                const int im1 = tvoc - 1 < 0 ? tvoc - 1 + n : tvoc - 1;
+                const int ip1 = tvoc + 1 >= n ? tvoc + 1 - n : tvoc + 1;
+                packed = tvoc | (im1 << 8) | (ip1 << 16);
+            }
+            d.triSlot[(size_t)(j * 2 + tvoe) * pe + e] = packed;
+        }
+    }
+}
+
+// One departure triangle: its source cell, its vertices moved to that cell's frame (shift_vertices :6270), its signed
+// area.  `slot` = d.triSlot of (source cell, edge vertex tvoe); xe, ye = that vertex in the edge's frame.
+__device__ inline void emitTriangle(const IrDev &d, int e, int t, double xt[3], double yt[3], int slot, double xe, double ye,
+                                    int cell, double e1x, double e1y, double e2x, double e2y, int sign)
 {
     const size_t pe = d.padE, pc = d.padC;
     d.triCell[(size_t)t * pe + e] = cell;
     double area = 0.0;
     if (cell < d.nCells) {
-        const int n = d.nEdgesOnCell[cell];
-        int tvoc = 0;
-        const int vShared = d.voe[(size_t)tvoe * pe + e];
-        for (int iv = 0; iv < n; iv++)
-            if (d.voc[(size_t)iv * pc + cell] == vShared) tvoc = iv;
-        const double xe = d.xVOE[(size_t)tvoe * pe + e], ye = d.yVOE[(size_t)tvoe * pe + e];
+        const int tvoc = slot & 255;
         const double xc = d.xVOC[(size_t)tvoc * pc + cell], yc = d.yVOC[(size_t)tvoc * pc + cell];
         if (d.onSphere) {
+            const int im1 = (slot >> 8) & 255, ip1 = (slot >> 16) & 255;
+            double c1x = d.xVOC[(size_t)im1 * pc + cell] - xc, c1y = d.yVOC[(size_t)im1 * pc + cell] - yc;
+            double c2x = d.xVOC[(size_t)ip1 * pc + cell] - xc, c2y = d.yVOC[(size_t)ip1 * pc + cell] - yc;
             double cp = cross2(e1x, e1y, e2x, e2y);
             if (fabs(cp) < EPS11) atomicOr(d.flag, FLAG_PARALLEL);
             if (cp > 0.0) {
@@ -869,10 +897,6 @@ __device__ inline void emitTriangle(const IrDev &d, int e, int t, double xt[3], 
                 e2x = tx;
                 e2y = ty;
             }
-            int im1 = tvoc - 1 < 0 ? tvoc - 1 + n : tvoc - 1;
-            int ip1 = tvoc + 1 >= n ? tvoc + 1 - n : tvoc + 1;
-            double c1x = d.xVOC[(size_t)im1 * pc + cell] - xc, c1y = d.yVOC[(size_t)im1 * pc + cell] - yc;
-            double c2x = d.xVOC[(size_t)ip1 * pc + cell] - xc, c2y = d.yVOC[(size_t)ip1 * pc + cell] - yc;
             double denom = e1x * e2y - e2x * e1y;
             for (int k = 0; k < 3; k++) {
                 xt[k] = xt[k] - xe;
@@ -898,7 +922,6 @@ __device__ inline void emitTriangle(const IrDev &d, int e, int t, double xt[3], 
     d.triArea[(size_t)t * pe + e] = area;
 }
 
-// find_departure_triangles :5365-6254, one edge per thread
 __global__ void __launch_bounds__(128) k_ir_triangles(IrDev d)
 {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -919,7 +942,9 @@ __global__ void __launch_bounds__(128) k_ir_triangles(IrDev d)
     // each of these loads was a memory round trip of its own behind a branch (the kernel spent 84 % of its
     // wave-cycles waiting)
     double xo[6], yo[6];  // the edge's two vertices, then the far vertices of E1..E4
-    int en4[4], cell4[4];
+    int en4[4], cell4[4], slot8[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) slot8[j] = d.triSlot[(size_t)j * pe + e];
 #pragma unroll
     for (int j = 0; j < 6; j++) {
         xo[j] = d.xVOE[(size_t)j * pe + e];
@@ -961,8 +986,8 @@ __global__ void __launch_bounds__(128) k_ir_triangles(IrDev d)
                 if (other > 3) other = other - 4;
                 double ox = xo[other + 2], oy = yo[other + 2];
                 if (tc < NTRI)
-                    emitTriangle(d, e, tc, xt, yt, k, cell, nx - ev[k][0], ny - ev[k][1], ox - ev[k][0], oy - ev[k][1],
-                                 side == 0 ? 1 : -1);
+                    emitTriangle(d, e, tc, xt, yt, slot8[(k + 2) * 2 + k], ev[k][0], ev[k][1], cell, nx - ev[k][0], ny - ev[k][1],
+                                 ox - ev[k][0], oy - ev[k][1], side == 0 ? 1 : -1);
                 tc = tc + 1;
                 dp[k][0] = ix;
                 dp[k][1] = iy;
@@ -1002,8 +1027,8 @@ __global__ void __launch_bounds__(128) k_ir_triangles(IrDev d)
             int other = inHP ? k : k + 2;
             double ox = xo[other + 2], oy = yo[other + 2];
             if (tc < NTRI)
-                emitTriangle(d, e, tc, xt, yt, k, cell, ev[o][0] - ev[k][0], ev[o][1] - ev[k][1], ox - ev[k][0],
-                             oy - ev[k][1], inHP ? 1 : -1);
+                emitTriangle(d, e, tc, xt, yt, inHP ? slot8[k] : slot8[2 + k], ev[k][0], ev[k][1], cell, ev[o][0] - ev[k][0],
+                             ev[o][1] - ev[k][1], ox - ev[k][0], oy - ev[k][1], inHP ? 1 : -1);
             tc = tc + 1;
         }
     }
@@ -1699,7 +1724,7 @@ extern "C" int sih_ir_init(sih_ctx *c, const sih_ir_desc *m)
     const Spec specs[] = {
         {"_eoc", LOC_CELL, M, true}, {"_coe", LOC_EDGE, 2, true}, {"_voe", LOC_EDGE, 2, true},
         {"_eov", LOC_VERTEX, 3, true}, {"remapEdge", LOC_EDGE, 1, true}, {"_eoer", LOC_EDGE, 4, true},
-        {"_coer", LOC_EDGE, 4, true}, {"_g2c", LOC_CELL, 6, false},
+        {"_coer", LOC_EDGE, 4, true}, {"_triSlot", LOC_EDGE, 8, true}, {"_g2c", LOC_CELL, 6, false},
         {"xVertexOnCell", LOC_CELL, M, false}, {"yVertexOnCell", LOC_CELL, M, false},
         {"xVertexOnEdge", LOC_EDGE, 6, false}, {"yVertexOnEdge", LOC_EDGE, 6, false},
         {"geomAvgCell", LOC_CELL, 14, false}, {"minLengthEdgesOnVertex", LOC_VERTEX, 1, false},
@@ -1740,6 +1765,7 @@ extern "C" int sih_ir_init(sih_ctx *c, const sih_ir_desc *m)
     d.remapEdge = fi("remapEdge");
     d.eoer = fi("_eoer");
     d.coer = fi("_coer");
+    d.triSlot = fi("_triSlot");
     d.g2c = fd("_g2c");
     d.xVOC = fd("xVertexOnCell");
     d.yVOC = fd("yVertexOnCell");
@@ -1772,6 +1798,7 @@ extern "C" int sih_ir_init(sih_ctx *c, const sih_ir_desc *m)
     hipLaunchKernelGGL(k_ir_init_edge_vertices, dim3((nE + 255) / 256), blk, 0, c->stream, d, a);
     hipLaunchKernelGGL(k_ir_init_vertices, dim3((nV + 255) / 256), blk, 0, c->stream, d, a);
     hipLaunchKernelGGL(k_ir_init_geom, dim3((nC + 255) / 256), blk, 0, c->stream, d);
+    hipLaunchKernelGGL(k_ir_init_tri_slots, dim3((nE + 255) / 256), blk, 0, c->stream, d);
     HIPCHK(hipGetLastError());
     int flag = 0;
     HIPCHK(hipMemcpyAsync(&flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
