@@ -1335,10 +1335,28 @@ __global__ void __launch_bounds__(256, 4) k_ir_flux_walk(IrDev d, const IrTabEnt
 // from there; only the edges outside the run are gathered from memory.  (With all six gathered, the kernel took
 // 0.30 ms at QU60, of which 0.10 ms were the gathers' own.)
 #define IR_UPD_WIN 768
+// the layer field after (ti, layer) in the order (tracer, layer); ti == number of tracers after the last one
+__device__ inline void irNextField(const IrTabEntry *__restrict__ tab, int &ti, int &layer)
+{
+    if (layer + 1 < tab[ti].L)
+        layer++;
+    else {
+        ti++;
+        layer = 0;
+    }
+}
+__device__ inline const double *irFluxPlane(const IrTabEntry *__restrict__ tab, int ti, int layer, int cat, size_t pe)
+{
+    return tab[ti].flux + (size_t)(cat * tab[ti].L + layer) * pe;
+}
 template <int M>
 __global__ void __launch_bounds__(256) k_ir_update(IrDev d, const IrTabEntry *__restrict__ tab, int nT)
 {
-    __shared__ double win[2][IR_UPD_WIN];
+    __shared__ double winStore[2 * IR_UPD_WIN];
+    // addressed as LDS explicitly: with generic pointers the compiler merged the LDS read and the gather below into
+    // one access through a pointer of either kind and then failed to select instructions for it
+    typedef __attribute__((address_space(3))) double LdsDouble;
+    LdsDouble *win = (LdsDouble *)winStore;
     const int tid = threadIdx.x;
     const int cRaw = blockIdx.x * blockDim.x + tid;
     const bool live = cRaw < d.nCellsSolve;
@@ -1367,11 +1385,24 @@ __global__ void __launch_bounds__(256) k_ir_update(IrDev d, const IrTabEntry *__
     int wi[IR_UPD_WIN / 256];
 #pragma unroll
     for (int j = 0; j < IR_UPD_WIN / 256; j++) wi[j] = min(eLo + j * 256 + tid, (int)pe - 1);
-    double nextW[IR_UPD_WIN / 256];
+    // Layer fields are taken in the order (tracer, layer).  The window of field i + 2 and the old product of field
+    // i + 1 are requested while field i is worked on; the window of field i + 1, requested one field earlier, goes
+    // to LDS at the end of field i: every load has a whole field's work to arrive in.
+    int ti1 = 0, ly1 = 0;  // field i + 1
+    irNextField(tab, ti1, ly1);
+    int ti2 = ti1, ly2 = ly1;  // field i + 2
+    if (ti2 < nT) irNextField(tab, ti2, ly2);
+    double pendW[IR_UPD_WIN / 256], prodNext = 0.0;
     {
-        const double *f0 = tab[0].flux + (size_t)(cat * tab[0].L) * pe;
+        const double *f0 = irFluxPlane(tab, 0, 0, cat, pe);
 #pragma unroll
-        for (int j = 0; j < IR_UPD_WIN / 256; j++) win[0][j * 256 + tid] = f0[wi[j]];
+        for (int j = 0; j < IR_UPD_WIN / 256; j++) win[j * 256 + tid] = f0[wi[j]];
+        if (ti1 < nT) {
+            const double *f1 = irFluxPlane(tab, ti1, ly1, cat, pe);
+#pragma unroll
+            for (int j = 0; j < IR_UPD_WIN / 256; j++) pendW[j] = f1[wi[j]];
+        }
+        prodNext = tab[0].prod[(size_t)cat * tab[0].L * pc + c];
     }
     __syncthreads();
     int buf = 0;
@@ -1382,33 +1413,32 @@ __global__ void __launch_bounds__(256) k_ir_update(IrDev d, const IrTabEntry *__
         for (int layer = 0; layer < T.L; layer++) {
             const int l = cat * T.L + layer;
             const size_t k = (size_t)l * pc + c;
-            // the window of the next layer field is on its way while this one is worked on
-            const double *fn = nullptr;
-            if (layer + 1 < T.L)
-                fn = T.flux + (size_t)(l + 1) * pe;
-            else if (ti + 1 < nT)
-                fn = tab[ti + 1].flux + (size_t)(cat * tab[ti + 1].L) * pe;
-            if (fn) {
+            const bool more1 = ti1 < nT, more2 = ti2 < nT;
+            double newW[IR_UPD_WIN / 256];
+            if (more2) {
+                const double *f2 = irFluxPlane(tab, ti2, ly2, cat, pe);
 #pragma unroll
-                for (int j = 0; j < IR_UPD_WIN / 256; j++) nextW[j] = fn[wi[j]];
+                for (int j = 0; j < IR_UPD_WIN / 256; j++) newW[j] = f2[wi[j]];
             }
+            const double prodOld = prodNext;
+            if (more1) prodNext = tab[ti1].prod[(size_t)(cat * tab[ti1].L + ly1) * pc + c];
             const double *fp = T.flux + (size_t)l * pe;
             double flux = 0.0;
 #pragma unroll
             for (int ie = 0; ie < M; ie++)
                 if (ie < n) {
-                    double fe = win[buf][rel[ie] >= 0 ? rel[ie] : 0];
+                    double fe = win[buf * IR_UPD_WIN + (rel[ie] >= 0 ? rel[ie] : 0)];
                     if (rel[ie] < 0) fe = fp[ed[ie]];
                     flux = flux + fe * ((plus >> ie) & 1u ? 1.0 : -1.0);
                 }
             const double pp = hasParent ? P->prod[(size_t)(P->L == 1 ? cat : l) * pc + c] : 1.0;
             double nv;
             if (pp > 0.0)
-                nv = (T.prod[k] - (flux / area)) / pp;
+                nv = (prodOld - (flux / area)) / pp;
             else
                 nv = 0.0;
             if (live) {
-                T.prod[k] = pp * nv;
+                if (T.hasChild) T.prod[k] = pp * nv;  // read by the children below, by nothing after this kernel
                 if (!hasParent) {  // :7465-7507
                     if (nv < -EPS11 * EPS11)
                         negMass = true;
@@ -1417,17 +1447,24 @@ __global__ void __launch_bounds__(256) k_ir_update(IrDev d, const IrTabEntry *__
                 }
                 T.val[k] = nv;
             }
-            if (fn) {
+            if (more1) {
 #pragma unroll
-                for (int j = 0; j < IR_UPD_WIN / 256; j++) win[buf ^ 1][j * 256 + tid] = nextW[j];
+                for (int j = 0; j < IR_UPD_WIN / 256; j++) win[(buf ^ 1) * IR_UPD_WIN + j * 256 + tid] = pendW[j];
             }
-            // one barrier per layer field: the buffer written above was last read two layer fields ago, and every
-            // thread has passed the barrier in between since
+#pragma unroll
+            for (int j = 0; j < IR_UPD_WIN / 256; j++) pendW[j] = newW[j];
+            ti1 = ti2;
+            ly1 = ly2;
+            if (more2) irNextField(tab, ti2, ly2);
+            // one barrier per layer field: the buffer written above was last read one field ago, before the barrier
+            // that ended that field
             __syncthreads();
             buf ^= 1;
         }
     }
-    if (negMass) atomicOr(d.flag, FLAG_NEGMASS);  // "IR: Negative mass in IR", reported once the launch has ended
+    if (negMass)
+        __hip_atomic_fetch_or((__attribute__((address_space(1))) int *)d.flag, FLAG_NEGMASS, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_AGENT);  // "IR: Negative mass in IR", reported once the launch has ended
 }
 
 // zap_small_mass :8764-8886: thread = (owned cell, category).  A separate launch: the conservation sums of
