@@ -1334,7 +1334,13 @@ __global__ void __launch_bounds__(256, 4) k_ir_flux_walk(IrDev d, const IrTabEnt
 // as possible) with coalesced loads into LDS, one layer field ahead of its use, and a thread takes its six fluxes
 // from there; only the edges outside the run are gathered from memory.  (With all six gathered, the kernel took
 // 0.30 ms at QU60, of which 0.10 ms were the gathers' own.)
-#define IR_UPD_WIN 768
+#ifndef IR_UPD_BLOCK
+#define IR_UPD_BLOCK 256
+#endif
+#ifndef IR_UPD_PER
+#define IR_UPD_PER 3
+#endif
+#define IR_UPD_WIN (IR_UPD_PER * IR_UPD_BLOCK)
 // the layer field after (ti, layer) in the order (tracer, layer); ti == number of tracers after the last one
 __device__ inline void irNextField(const IrTabEntry *__restrict__ tab, int &ti, int &layer)
 {
@@ -1350,7 +1356,7 @@ __device__ inline const double *irFluxPlane(const IrTabEntry *__restrict__ tab, 
     return tab[ti].flux + (size_t)(cat * tab[ti].L + layer) * pe;
 }
 template <int M>
-__global__ void __launch_bounds__(256) k_ir_update(IrDev d, const IrTabEntry *__restrict__ tab, int nT)
+__global__ void __launch_bounds__(IR_UPD_BLOCK) k_ir_update(IrDev d, const IrTabEntry *__restrict__ tab, int nT)
 {
     __shared__ double winStore[2 * IR_UPD_WIN];
     // addressed as LDS explicitly: with generic pointers the compiler merged the LDS read and the gather below into
@@ -1381,10 +1387,10 @@ __global__ void __launch_bounds__(256) k_ir_update(IrDev d, const IrTabEntry *__
     }
     const double area = d.areaCell[c];
     bool negMass = false;
-    // what a thread copies of a window: IR_UPD_WIN / 256 entries, 256 apart
-    int wi[IR_UPD_WIN / 256];
+    // what a thread copies of a window: IR_UPD_PER entries, 256 apart
+    int wi[IR_UPD_PER];
 #pragma unroll
-    for (int j = 0; j < IR_UPD_WIN / 256; j++) wi[j] = min(eLo + j * 256 + tid, (int)pe - 1);
+    for (int j = 0; j < IR_UPD_PER; j++) wi[j] = min(eLo + j * IR_UPD_BLOCK + tid, (int)pe - 1);
     // Layer fields are taken in the order (tracer, layer).  The window of field i + 2 and the old product of field
     // i + 1 are requested while field i is worked on; the window of field i + 1, requested one field earlier, goes
     // to LDS at the end of field i: every load has a whole field's work to arrive in.
@@ -1392,15 +1398,15 @@ __global__ void __launch_bounds__(256) k_ir_update(IrDev d, const IrTabEntry *__
     irNextField(tab, ti1, ly1);
     int ti2 = ti1, ly2 = ly1;  // field i + 2
     if (ti2 < nT) irNextField(tab, ti2, ly2);
-    double pendW[IR_UPD_WIN / 256], prodNext = 0.0;
+    double pendW[IR_UPD_PER], prodNext = 0.0;
     {
         const double *f0 = irFluxPlane(tab, 0, 0, cat, pe);
 #pragma unroll
-        for (int j = 0; j < IR_UPD_WIN / 256; j++) win[j * 256 + tid] = f0[wi[j]];
+        for (int j = 0; j < IR_UPD_PER; j++) win[j * IR_UPD_BLOCK + tid] = f0[wi[j]];
         if (ti1 < nT) {
             const double *f1 = irFluxPlane(tab, ti1, ly1, cat, pe);
 #pragma unroll
-            for (int j = 0; j < IR_UPD_WIN / 256; j++) pendW[j] = f1[wi[j]];
+            for (int j = 0; j < IR_UPD_PER; j++) pendW[j] = f1[wi[j]];
         }
         prodNext = tab[0].prod[(size_t)cat * tab[0].L * pc + c];
     }
@@ -1414,11 +1420,11 @@ __global__ void __launch_bounds__(256) k_ir_update(IrDev d, const IrTabEntry *__
             const int l = cat * T.L + layer;
             const size_t k = (size_t)l * pc + c;
             const bool more1 = ti1 < nT, more2 = ti2 < nT;
-            double newW[IR_UPD_WIN / 256];
+            double newW[IR_UPD_PER];
             if (more2) {
                 const double *f2 = irFluxPlane(tab, ti2, ly2, cat, pe);
 #pragma unroll
-                for (int j = 0; j < IR_UPD_WIN / 256; j++) newW[j] = f2[wi[j]];
+                for (int j = 0; j < IR_UPD_PER; j++) newW[j] = f2[wi[j]];
             }
             const double prodOld = prodNext;
             if (more1) prodNext = tab[ti1].prod[(size_t)(cat * tab[ti1].L + ly1) * pc + c];
@@ -1449,10 +1455,10 @@ __global__ void __launch_bounds__(256) k_ir_update(IrDev d, const IrTabEntry *__
             }
             if (more1) {
 #pragma unroll
-                for (int j = 0; j < IR_UPD_WIN / 256; j++) win[(buf ^ 1) * IR_UPD_WIN + j * 256 + tid] = pendW[j];
+                for (int j = 0; j < IR_UPD_PER; j++) win[(buf ^ 1) * IR_UPD_WIN + j * IR_UPD_BLOCK + tid] = pendW[j];
             }
 #pragma unroll
-            for (int j = 0; j < IR_UPD_WIN / 256; j++) pendW[j] = newW[j];
+            for (int j = 0; j < IR_UPD_PER; j++) pendW[j] = newW[j];
             ti1 = ti2;
             ly1 = ly2;
             if (more2) irNextField(tab, ti2, ly2);
@@ -1725,11 +1731,11 @@ extern "C" int sih_ir_init(sih_ctx *c, const sih_ir_desc *m)
     ir->nCat = m->nCategories;
     {
         // per block of 256 owned cells: the run of IR_UPD_WIN consecutive edges that holds most of its cells' edges
-        const int nB = std::max(1, (c->nCellsSolve + 255) / 256);
+        const int nB = std::max(1, (c->nCellsSolve + IR_UPD_BLOCK - 1) / IR_UPD_BLOCK);
         std::vector<int> winStart(nB, 0);
         for (int b = 0; b < nB; b++) {
             std::vector<int> es;
-            for (int i = b * 256; i < std::min(c->nCellsSolve, (b + 1) * 256); i++) {
+            for (int i = b * IR_UPD_BLOCK; i < std::min(c->nCellsSolve, (b + 1) * IR_UPD_BLOCK); i++) {
                 const int h = c->cellPerm[i];
                 for (int sIdx = 0; sIdx < c->hNe[i]; sIdx++) {
                     const int e = m->edgesOnCell[(size_t)h * M + sIdx];
@@ -2010,7 +2016,7 @@ static void launchCellKernels(sih_ir_state *ir, hipStream_t s, bool update)
         hipLaunchKernelGGL(k_ir_reconstruct<M>, dim3(xcdGrid((d.nCells + 255) / 256, d.nCat)), dim3(256), 0, s, d,
                            ir->d_tab, nT);
     else
-        hipLaunchKernelGGL(k_ir_update<M>, dim3((d.nCellsSolve + 255) / 256, d.nCat), dim3(256), 0, s, d, ir->d_tab,
+        hipLaunchKernelGGL(k_ir_update<M>, dim3((d.nCellsSolve + IR_UPD_BLOCK - 1) / IR_UPD_BLOCK, d.nCat), dim3(IR_UPD_BLOCK), 0, s, d, ir->d_tab,
                            nT);
 }
 
