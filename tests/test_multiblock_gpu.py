@@ -120,8 +120,10 @@ def test_exchange_inside_the_kernel_changes_no_bit(tmp_path, extra):
 
 def test_a_silent_neighbour_ends_the_kernel_with_the_exchange_inside():
     """Rank 1 agrees to exchange inside the kernel and then never launches: rank 0's launch must not hang.  Its
-    waits are bounded (here 300 ms), every workgroup leaves, and the host gets an error that says why."""
-    out = _run_ranks("geo8", 2, ["p2p", "deep", "silent"], {"SIH_PERSIST_TIMEOUT_MS": "300"}, timeout=120)
+    waits are bounded (here 300 ms, and as much for the exchanges between launches that precede it in the step), every
+    workgroup leaves, and the host gets an error that says why."""
+    out = _run_ranks("geo8", 2, ["p2p", "deep", "silent"], {"SIH_PERSIST_TIMEOUT_MS": "300", "SIH_HALO_TIMEOUT_MS": "300"},
+                     timeout=120)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "rank 0 reported:" in out.stdout and "did not arrive in time" in out.stdout, out.stdout
 
