@@ -333,6 +333,19 @@ def main():
                 "frac_layout": None, "traffic": None, "frac_counter": None,
                 "traffic_source": "equivalent rate of a chip-resident kernel: bytes of the two-kernel form per iteration "
                                   "over the time an iteration took (step time / iterations, exchanges included)"})
+        elif res.get("fused_kernel"):
+            # a block of this size runs one launch per iteration over tiles of 64 cells (the vertices of one iteration,
+            # then the cells of the next): the two-kernel timings above are not what ran
+            it_ms = ms_per_step / nsub
+            eq = (b_cell + b_vert) * block_cells / (it_ms * 1e-3) / 1e9
+            out["roofline"].update({
+                "kernel": "k_sub_fused (one launch per iteration: velocity solve of the tile's vertices, then strain, EVP "
+                          "stress and stress-divergence partial sums of its 64 cells; halo values exchanged between launches)",
+                "bound": "hbm", "achieved": eq, "frac": eq / HBM_PEAK_GBS, "kernel_ms": it_ms, "vertex_kernel_ms": None,
+                "algorithmic_bytes_per_launch": (b_cell + b_vert) * block_cells, "layout_bytes_per_launch": None,
+                "frac_layout": None, "traffic": None, "frac_counter": None,
+                "traffic_source": "bytes of one iteration (cells and vertices) over the time an iteration took (step "
+                                  "time / iterations, exchanges included)"})
     if world == 1 and not args.no_hbm_only and mesh_label == "QU60":
         out["roofline"]["hbm_only"] = hbm_only_pass(local_rank)
     if world == 1 and advection is not None:

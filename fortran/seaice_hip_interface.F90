@@ -303,6 +303,15 @@ module seaice_hip_interface
        integer(c_int) :: ierr
      end function sih_evp_subcycle_persistent
 
+     ! n iterations as n + 1 launches of the fused kernel (vertices of one iteration, cells of the next; blocks too
+     ! large for the persistent kernel; SIH_ERR_UNSUPPORTED where a block does not qualify: "fusedKernel")
+     function sih_evp_subcycle_fused(ctx, n) bind(C, name="sih_evp_subcycle_fused") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n
+       integer(c_int) :: ierr
+     end function sih_evp_subcycle_fused
+
      ! 0 two-kernel form, 1 persistent kernel, 2 persistent kernel with the halo exchange inside (default where a
      ! block qualifies), -1 back to the environment; the same on every block of a run
      function sih_evp_set_persistent(ctx, mode) bind(C, name="sih_evp_set_persistent") result(ierr)

@@ -274,6 +274,18 @@ int sih_evp_subcycle_graph(sih_ctx *ctx, int n);
  * default 2000) is reported by sih_sync / sih_evp_run as SIH_ERR_STATE.  The GPU must not be shared with other
  * work that could keep some of the workgroups from being resident. */
 int sih_evp_subcycle_persistent(sih_ctx *ctx, int n);
+/* the same n iterations (last = 0) as n + 1 launches of one kernel over the same tiles: a launch is "the vertices
+ * of iteration t - 1, then the cells of iteration t" (velocity_solver.F:2478-2592 cut between the stress divergence's
+ * inner and outer sums instead of after the velocity solve), the first launch the cells only, the last the vertices
+ * only.  For blocks too large to stay resident in the persistent kernel, or not alone on their device: half the
+ * launches of the two-kernel form and two dependent memory round trips a launch instead of four or five.  Same
+ * bits as sih_evp_subcycle; nothing waits inside a launch, so it has no residency condition and no time limit.
+ * sih_evp_subcycle_graph, sih_evp_run and sih_evp_subcycle_exchange (between its exchanges, without overlap) choose
+ * it by themselves where the persistent kernel does not apply and the block has at most SIH_FUSED_MAX_CELLS cells
+ * (sih_get_info "fusedKernel" = 1: default scheme, compact gradients, at most 64 * maxEdges vertices in a tile of 64
+ * cells); mode 0 of sih_evp_set_persistent and SIH_FUSED=0 keep the two-kernel form.  Returns SIH_ERR_UNSUPPORTED
+ * where the block does not qualify. */
+int sih_evp_subcycle_fused(sih_ctx *ctx, int n);
 /* which form sih_evp_subcycle_graph, sih_evp_run and sih_evp_subcycle_exchange choose for this block where it
  * qualifies: 0 the two-kernel form; 1 (the default) the persistent kernel with the halo exchanges between its
  * launches; 2 the persistent kernel with the exchanges of sih_evp_subcycle_exchange inside it: one launch for all
@@ -490,7 +502,8 @@ int sih_upwind_get_sums(sih_ctx *ctx, const char *tracer, double *initSums, doub
 
 /* introspection for tests and reports.  Keys: sparseGradient, splitCellKernel, persistentKernel (and persistentPerCU,
  * persistentTiles, persistentReason, persistentArrived, persistentLaunches, persistentExchangeLaunches,
- * persistentExchangeReady (see sih_evp_set_persistent): workgroups of
+ * persistentExchangeReady (see sih_evp_set_persistent), fusedKernel and fusedLaunches (sih_evp_subcycle_fused), iterationForm (what the last loop of iterations ran as: 0 two
+ * kernels an iteration, 1 the persistent kernel, 2 the fused kernel): workgroups of
  * the persistent subcycle kernel a CU holds, its tiles, why the block does not qualify (1 option, 2 too many tiles,
  * 3 too many vertices in a tile, 5 not resident together in the trial launch), workgroups that arrived in a failed
  * trial, launches so far and those with the halo exchange inside), dampingTimescale,

@@ -126,6 +126,11 @@ struct sih_persist_state {
     int arrived = 0;
     int perCU = 0, reason = 0;  // why not usable: 1 option, 2 too many tiles, 3 vertices per tile, 5 probe
     bool usable = false;
+    bool fusedReady = false;  // the tile tables exist: the one-launch-per-iteration form (k_sub_fused) can run
+    int fusedLaunches = 0;
+    double *uAlt = nullptr, *vAlt = nullptr;  // the second copy of the velocities that form alternates with
+    const int *tvVert = nullptr, *tvOwned = nullptr;  // the tiles' vertex lists padded to 64 M entries a tile (-1: none)
+    int *tvQ = nullptr;                               // [3][tiles * 64 M]: where such a vertex finds its three partial sums
     bool unchecked = false;  // a launch since the status word was last read
     std::vector<void *> allocs;
     // the tiles' vertex lists on the host, for the tables of the in-kernel exchange
@@ -612,6 +617,240 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// One launch per iteration, for blocks too large to stay on the chip (or not alone on their device): the same tiles
+// and the same statements, but a launch is "vertices of iteration t-1, then cells of iteration t" -- the boundary
+// between two launches is the hand-off of the partial sums, so nothing waits and nothing needs to be resident.  A
+// loop of m iterations is m + 1 launches (cells only; m - 1 of both; vertices only) instead of 2 m, and the
+// dependent chain of a launch is two memory round trips (tables, then operands) instead of the four or five of
+// the cell kernel followed by the vertex kernel: a tile's vertices, the places of their sums and whether it stores
+// them come from tables laid out per tile, and the velocities and tan(lat) reach the corners through LDS.
+// The velocities alternate between two arrays (a tile reads those of all its vertices while the tile that owns a
+// vertex stores the new one), the partial sums between two buffers of the ring.
+struct FusedArgs {
+    const int *tvVert, *tvOwned, *tvQ, *cornerSlot;
+    size_t nEntries;  // tiles * 64 M
+    const double *uIn, *vIn;
+    double *uOut, *vOut;  // may be null (cells only, nothing to copy)
+    const double *sumsIn;
+    double *sumsOut;
+};
+
+#ifndef SIH_FUSED_MIN_WAVES
+#define SIH_FUSED_MIN_WAVES 5
+#endif
+template <int M, bool VERTS, bool CELLS>
+__global__ void __launch_bounds__(64 * M, SIH_FUSED_MIN_WAVES) k_sub_fused(PersistDev d, FusedArgs f, int nT)
+{
+    __shared__ double su[M][64], sv[M][64], s11[M][64], s22[M][64], s12[M][64];
+    __shared__ double uT[64 * M], vT[64 * M], tT[64 * M];
+    const int lane = threadIdx.x, g = threadIdx.y, tid = g * 64 + lane;
+    int tile;  // consecutive tiles on one XCD, as in the persistent kernel
+    {
+        const int b = blockIdx.x, q = nT / 8, r = nT % 8, x = b % 8;
+        tile = x * q + (x < r ? x : r) + b / 8;
+    }
+    const int P = d.padC;
+    int c = tile * 64 + lane;
+    const bool inRange = c < d.nCells;
+    if (!inRange) c = 0;
+    const size_t k = (size_t)g * P + c;
+    // ---- one vertex of the tile's cells
+    const size_t j = (size_t)tile * (64 * M) + tid;
+    const int vRaw = f.tvVert[j];
+    const bool hasV = vRaw >= 0;
+    const int v = hasV ? vRaw : 0;
+    const bool owned = hasV && f.tvOwned[j] != 0;
+    double uu = f.uIn[v], vv = f.vIn[v];
+    const double tl = d.tanLat[v];
+    if (VERTS) {
+        const int q0 = f.tvQ[j], q1 = f.tvQ[f.nEntries + j], q2 = f.tvQ[2 * f.nEntries + j];
+        const size_t plane = (size_t)M * P;
+        const bool solV = hasV && (d.haloVertices ? d.vActive[v] != 0 : v < d.nVerticesSolve) && d.solveVelocity[v] == 1;
+        // operands of the solve, for every lane (what a lane without a solved vertex reads is valid memory, unused)
+        const double pu0 = f.sumsIn[q0], pu1 = f.sumsIn[q1], pu2 = f.sumsIn[q2];
+        const double pv0 = f.sumsIn[plane + q0], pv1 = f.sumsIn[plane + q1], pv2 = f.sumsIn[plane + q2];
+        const double den0 = d.varDenom[v], m = d.totalMassVertex[v], mf = d.massF[v];
+        const double airU = d.airVertU[v], airV = d.airVertV[v], tiltU = d.tiltForceU[v], tiltV = d.tiltForceV[v];
+        const double osU = d.ocnStressU[v], osV = d.ocnStressV[v], uo = d.uOcnVert[v], vo = d.vOcnVert[v];
+        const double aV = d.useOcean ? d.iceAreaVertex[v] : 0.0;
+        const double dtE = d.dtE, brlx = d.brlx, dtD = d.dtDyn;
+        const int relation = d.relation;
+        if (solV) {
+            double dU = 0.0, dV = 0.0;
+            dU = dU + pu0;
+            dV = dV + pv0;
+            dU = dU + pu1;
+            dV = dV + pv1;
+            dU = dU + pu2;
+            dV = dV + pv2;
+            dU = dU / den0;
+            dV = dV / den0;
+            double coeff = 0.0;
+            if (d.useOcean) {
+                if (d.quadratic) {
+                    double du = uo - uu, dv = vo - vv;
+                    coeff = DRAGIO * RHOW * aV * sqrt(du * du + dv * dv);
+                } else {
+                    coeff = DRAGIO * RHOW * aV;
+                }
+            }
+            double l11, l22, r1, r2;
+            const double l12 = -mf - coeff * SIN_TURN * sign1p(mf);
+            const double l21 = mf + coeff * SIN_TURN * sign1p(mf);
+            if (relation == 2) {
+                l11 = (brlx + 1.0) * (m / dtD) + coeff * COS_TURN;
+                l22 = (brlx + 1.0) * (m / dtD) + coeff * COS_TURN;
+                r1 = dU + airU + tiltU + coeff * osU + (m * (brlx * uu + d.uInit[v])) / dtD;
+                r2 = dV + airV + tiltV + coeff * osV + (m * (brlx * vv + d.vInit[v])) / dtD;
+            } else {
+                l11 = m / dtE + coeff * COS_TURN;
+                l22 = m / dtE + coeff * COS_TURN;
+                r1 = dU + airU + tiltU + coeff * osU + (m * uu) / dtE;
+                r2 = dV + airV + tiltV + coeff * osV + (m * vv) / dtE;
+            }
+            if (relation != 3) {
+                const double den = l11 * l22 - l12 * l21;
+                const double un = (l22 * r1 - l12 * r2) / den;
+                const double vn = (l11 * r2 - l21 * r1) / den;
+                uu = un;
+                vv = vn;
+            }
+        }
+    }
+    // the tile that owns a vertex stores it, solved or not: both arrays hold every vertex of a tile
+    if (owned && f.uOut) {
+        f.uOut[v] = uu;
+        f.vOut[v] = vv;
+    }
+    if (!CELLS) return;
+    // ---- what the cell phase reads from memory is requested now, when the vertex phase has given its registers
+    //      back, whether the corner turns out to be one or not (the planes are padded: every address is valid).
+    //      (Requested at the top of the kernel instead, these 27 doubles took it from 90 to 122 registers.)
+    int solveFlag = 0, E = 0, slot = 0;
+    double P_ice = 0.0, o11 = 0.0, o22 = 0.0, o12 = 0.0;
+    double gu3[3] = {0.0, 0.0, 0.0}, gv3[3] = {0.0, 0.0, 0.0};
+    double bu[M], bv[M], bm[M];
+    {
+        solveFlag = d.solveStress[c];
+        E = d.nEdgesOnCell[c];
+        slot = f.cornerSlot[k];
+        P_ice = d.icePressure[c];
+        o11 = d.stress11[k];
+        o22 = d.stress22[k];
+        o12 = d.stress12[k];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            gu3[q] = d.gradU3[(size_t)(q * M + g) * P + c];
+            gv3[q] = d.gradV3[(size_t)(q * M + g) * P + c];
+        }
+#pragma unroll
+        for (int s = 0; s < M; s++) {
+            const size_t kb = (size_t)(g * M + s) * P + c;
+            bu[s] = d.SU[kb];
+            bv[s] = d.SV[kb];
+            bm[s] = d.SM[kb];
+        }
+    }
+    uT[tid] = uu;
+    vT[tid] = vv;
+    tT[tid] = tl;
+    __syncthreads();
+    // ---- cells: strain, stress, partial sums of the divergence (k_sub_cells_split)
+    const bool corner = inRange && solveFlag == 1 && g < E;
+    const double ug = uT[slot], vg = vT[slot], tg = tT[slot];
+    su[g][lane] = corner ? ug : 0.0;
+    sv[g][lane] = corner ? vg : 0.0;
+    __syncthreads();
+    const int relation = d.relation;
+    double a11 = 0.0, a22 = 0.0, a12 = 0.0;
+    if (corner) {
+        const double dtE = d.dtE, T = d.dampT;
+        double e11 = 0.0, e22 = 0.0, e12 = 0.0;
+        int i0, i1, i2;
+        if (g == 0) {
+            i0 = 0;
+            i1 = 1;
+            i2 = E - 1;
+        } else if (g == E - 1) {
+            i0 = 0;
+            i1 = g - 1;
+            i2 = g;
+        } else {
+            i0 = g - 1;
+            i1 = g;
+            i2 = g + 1;
+        }
+        const double xu[3] = {su[i0][lane], su[i1][lane], su[i2][lane]};
+        const double xv[3] = {sv[i0][lane], sv[i1][lane], sv[i2][lane]};
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            e11 = e11 + xu[q] * gu3[q];
+            e22 = e22 + xv[q] * gv3[q];
+            e12 = e12 + 0.5 * (xu[q] * gv3[q] + xv[q] * gu3[q]);
+        }
+        e11 = e11 - vg * tg;
+        e12 = e12 + ug * tg * 0.5;
+        if (relation == 3) {
+            a11 = 1.0 * e11;
+            a22 = 1.0 * e22;
+            a12 = 1.0 * e12;
+        } else {
+            a11 = o11;
+            a22 = o22;
+            a12 = o12;
+            double eD = e11 + e22, eT = e11 - e22, eS = e12 * 2.0;
+            double st1 = a11 + a22, st2 = a11 - a22;
+            double Delta = sqrt(eD * eD + (eT * eT + eS * eS) / ECC2);
+            double pc = P_ice / fmax(Delta, PUNY);
+            double den;
+            if (relation == 1) {
+                pc = (pc * dtE) / (2.0 * T);
+                den = 1.0 + (0.5 * dtE) / T;
+            } else {
+                pc = (pc * 2.0 * 5.5e-3) / 0.86;
+                den = 1.0 + (2.0 * 5.5e-3) / 0.86;
+            }
+            st1 = (st1 + pc * (eD - Delta)) / den;
+            st2 = (st2 + (pc / ECC2) * eT) / den;
+            a12 = (a12 + (pc / ECC2) * eS * 0.5) / den;
+            a11 = 0.5 * (st1 + st2);
+            a22 = 0.5 * (st1 - st2);
+        }
+        d.stress11[k] = a11;
+        d.stress22[k] = a22;
+        d.stress12[k] = a12;
+    }
+    s11[g][lane] = a11;
+    s22[g][lane] = a22;
+    s12[g][lane] = a12;
+    __syncthreads();
+    if (corner) {
+        double cu = 0.0, cv = 0.0;
+#pragma unroll
+        for (int s = 0; s < M; s++) {
+            if (s < E) {
+                const double x11 = s11[s][lane], x22 = s22[s][lane], x12 = s12[s][lane];
+                cu = cu - x11 * bu[s] - x12 * bv[s] - x12 * bm[s] * tg;
+                cv = cv - x22 * bv[s] - x12 * bu[s] + x11 * bm[s] * tg;
+            }
+        }
+        f.sumsOut[k] = cu;
+        f.sumsOut[(size_t)M * P + k] = cv;
+    }
+}
+
+// where the vertices of the padded tile lists find their partial sums
+__global__ void k_fused_tables(const int *__restrict__ tvVert, const int *__restrict__ gidx, int *__restrict__ tvQ, size_t n,
+                               int padV, int noCell)
+{
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int v = tvVert[j];
+    for (int q = 0; q < 3; q++) tvQ[q * n + j] = v >= 0 ? gidx[(size_t)q * padV + v] : noCell;
+}
+
 // ------------------------------------------------------------------------------------------------ host
 void sih_persist_destroy(sih_ctx *c)
 {
@@ -678,7 +917,7 @@ int sih_persist_setup(sih_ctx *c)
     s->capacity = perCU * prop.multiProcessorCount;
     if (const char *e = getenv("SIH_PERSIST_CAPACITY")) s->capacity = atoi(e);
     const int nT = (nC + 63) / 64;
-    if (nT < 1 || nT > s->capacity) {
+    if (nT < 1) {
         s->reason = 2;
         return SIH_OK;
     }
@@ -732,6 +971,36 @@ int sih_persist_setup(sih_ctx *c)
     if ((rc = upload(s, &a.tileVerts, verts))) return rc;
     if ((rc = upload(s, &a.tileVertOwned, ownedFlag))) return rc;
     if ((rc = upload(s, &a.cornerSlot, slot))) return rc;
+    {
+        // the same lists with 64 M entries a tile (what k_sub_fused reads: no look-up of where a tile's list begins),
+        // the places of the vertices' partial sums beside them, and the second copy of the velocities
+        const size_t nE = (size_t)nT * 64 * M;
+        std::vector<int> pv(nE, -1), po(nE, 0);
+        for (int t = 0; t < nT; t++)
+            for (int jj = vStart[t]; jj < vStart[t + 1]; jj++) {
+                pv[(size_t)t * 64 * M + (jj - vStart[t])] = verts[jj];
+                po[(size_t)t * 64 * M + (jj - vStart[t])] = ownedFlag[jj];
+            }
+        if ((rc = upload(s, &s->tvVert, pv))) return rc;
+        if ((rc = upload(s, &s->tvOwned, po))) return rc;
+        void *tq = nullptr;
+        HIPCHK(hipMalloc(&tq, sizeof(int) * 3 * nE));
+        s->allocs.push_back(tq);
+        s->tvQ = (int *)tq;
+        hipLaunchKernelGGL(k_fused_tables, dim3((unsigned)((nE + 255) / 256)), dim3(256), 0, c->stream, s->tvVert, c->dev.gidx,
+                           s->tvQ, nE, c->padV, nC);
+        HIPCHK(hipGetLastError());
+        if ((rc = sih_add_field(c, "_uAlt", LOC_VERTEX, 1, false))) return rc;
+        if ((rc = sih_add_field(c, "_vAlt", LOC_VERTEX, 1, false))) return rc;
+        s->uAlt = (double *)sih_find_field(c, "_uAlt")->d;
+        s->vAlt = (double *)sih_find_field(c, "_vAlt")->d;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        s->fusedReady = true;
+    }
+    if (nT > s->capacity) {  // too many tiles to be resident together: no persistent kernel for this block
+        s->reason = 2;
+        return SIH_OK;
+    }
     void *q = nullptr;
     HIPCHK(hipMalloc(&q, sizeof(unsigned long long) * PS_WORDS));
     s->allocs.push_back(q);
@@ -767,7 +1036,8 @@ double sih_persist_info(sih_ctx *c, int what)
 {
     if (!c->persist) return 0.0;
     const sih_persist_state *s = c->persist;
-    return what == 0 ? s->perCU : what == 1 ? s->reason : what == 2 ? s->a.nTiles : what == 3 ? s->arrived : what == 4 ? s->launches : s->xLaunches;
+    return what == 0 ? s->perCU : what == 1 ? s->reason : what == 2 ? s->a.nTiles : what == 3 ? s->arrived : what == 4 ? s->launches
+           : what == 5 ? s->xLaunches : s->fusedLaunches;
 }
 
 // the kernel reads the compact gradients: a put of a basis array switches it off until sih_evp_static_changed()
@@ -805,6 +1075,75 @@ static int launchAny(sih_ctx *c, int n, int interval)
 
 // n iterations (none the last of the dynamics step) as one launch; asynchronous
 int sih_persist_launch(sih_ctx *c, int n) { return launchAny(c, n, 0); }
+
+// ---- the one-launch-per-iteration form
+bool sih_fused_usable(sih_ctx *c) { return c->persist && c->persist->fusedReady && c->sparseGrad; }
+
+template <int M>
+static void launchFused(sih_ctx *c, int m)
+{
+    sih_persist_state *s = c->persist;
+    const int nT = s->a.nTiles;
+    const PersistDev pd = makePersistDev(c->dev);
+    const size_t ringBuf = (size_t)2 * M * c->padC;  // doubles in one buffer of the ring (U planes, then V planes)
+    double *sums[2] = {(double *)s->a.part, (double *)s->a.part + ringBuf};
+    double *ub[2] = {c->dev.u, s->uAlt}, *vb[2] = {c->dev.v, s->vAlt};
+    FusedArgs f{};
+    f.tvVert = s->tvVert;
+    f.tvOwned = s->tvOwned;
+    f.tvQ = s->tvQ;
+    f.cornerSlot = s->a.cornerSlot;
+    f.nEntries = (size_t)nT * 64 * M;
+    const dim3 grid((unsigned)nT), block(64, M);
+    // Launch 1: cells of iteration 1.  Launch i = 2 .. m: vertices of iteration i-1, cells of iteration i.  Launch
+    // m + 1: vertices of iteration m, which must land in the block's own arrays: the launches write the two copies
+    // of the velocities in turn, and with an odd m the first launch (which reads the velocities of all its vertices
+    // anyway) copies them over, so that the turn comes out right.
+    const bool copyFirst = (m % 2) == 1;
+    int in = 0;
+    f.uIn = ub[0];
+    f.vIn = vb[0];
+    f.uOut = copyFirst ? ub[1] : nullptr;
+    f.vOut = copyFirst ? vb[1] : nullptr;
+    f.sumsIn = sums[0];
+    f.sumsOut = sums[1];
+    hipLaunchKernelGGL((k_sub_fused<M, false, true>), grid, block, 0, c->stream, pd, f, nT);
+    if (copyFirst) in = 1;
+    for (int i = 2; i <= m + 1; i++) {
+        f.uIn = ub[in];
+        f.vIn = vb[in];
+        f.uOut = ub[in ^ 1];
+        f.vOut = vb[in ^ 1];
+        f.sumsIn = sums[(i - 1) % 2];
+        f.sumsOut = sums[i % 2];
+        if (i <= m)
+            hipLaunchKernelGGL((k_sub_fused<M, true, true>), grid, block, 0, c->stream, pd, f, nT);
+        else
+            hipLaunchKernelGGL((k_sub_fused<M, true, false>), grid, block, 0, c->stream, pd, f, nT);
+        in ^= 1;
+    }
+}
+
+// m iterations (none the last of the dynamics step) as m + 1 launches on the context's stream; asynchronous, and
+// plain launches: it may be captured in a graph
+int sih_fused_launch(sih_ctx *c, int m)
+{
+    if (!sih_fused_usable(c) || m < 1) {
+        sih_set_error("fused subcycle kernel: not available for this block");
+        return SIH_ERR_UNSUPPORTED;
+    }
+    switch (c->M) {
+        case 3: launchFused<3>(c, m); break;
+        case 4: launchFused<4>(c, m); break;
+        case 5: launchFused<5>(c, m); break;
+        case 6: launchFused<6>(c, m); break;
+        case 7: launchFused<7>(c, m); break;
+        default: launchFused<8>(c, m); break;
+    }
+    HIPCHK(hipGetLastError());
+    c->persist->fusedLaunches++;
+    return SIH_OK;
+}
 
 template <typename T>
 static int uploadX(sih_persist_state *s, const T **dst, const std::vector<T> &v)

@@ -1265,6 +1265,45 @@ static bool usePersistent(sih_ctx *c, int iterations)
     return persistentMode(c) >= 1 && iterations >= 2 && sih_persist_usable(c) && sih_live_contexts(c->device) == 1;
 }
 
+// Where the persistent kernel does not apply (block too large to be resident, or not alone on its device), loops of
+// two or more iterations run as one launch per iteration over the same tiles (k_sub_fused, evp_persist.hip) up to
+// the size where the two-kernel form, bound by memory bandwidth there, is as fast: SIH_FUSED_MAX_CELLS (default
+// below), SIH_FUSED=0 never, SIH_FUSED=1 at any size.
+static bool useFused(sih_ctx *c, int iterations)
+{
+    static const int fromEnv = [] {
+        const char *e = getenv("SIH_FUSED");
+        return e ? atoi(e) : -1;
+    }();
+    static const int maxCells = [] {
+        const char *e = getenv("SIH_FUSED_MAX_CELLS");
+        return e ? atoi(e) : SIH_FUSED_MAX_CELLS_DEFAULT;
+    }();
+    if (fromEnv == 0 || persistentMode(c) == 0 || iterations < 2 || usePersistent(c, iterations) || !sih_fused_usable(c))
+        return false;
+    return fromEnv == 1 || c->nCells <= maxCells;
+}
+
+// which of the three forms queueIterations takes: part of the key of a captured graph
+static int iterationForm(sih_ctx *c, int m)
+{
+    c->lastForm = usePersistent(c, m) ? 1 : useFused(c, m) ? 2 : 0;  // sih_get_info "iterationForm"
+    return c->lastForm;
+}
+
+// m iterations (none the last of the dynamics step) queued on the context's stream in the form that suits the block
+static int queueIterations(sih_ctx *c, int m)
+{
+    const int form = iterationForm(c, m);
+    if (form == 1) return sih_persist_launch(c, m);
+    if (form == 2) return sih_fused_launch(c, m);
+    for (int it = 0; it < m; it++) {
+        launchCellKernel(c, false);
+        launchVertexKernel(c, false);
+    }
+    return SIH_OK;
+}
+
 extern "C" int sih_evp_set_persistent(sih_ctx *c, int mode)
 {
     if (!c || mode < -1 || mode > 2) {
@@ -1391,22 +1430,23 @@ extern "C" int sih_evp_subcycle_graph(sih_ctx *c, int n)
         return SIH_ERR_ARG;
     }
     beginSubcycles(c);
-    if (usePersistent(c, n)) return sih_persist_launch(c, n);  // small block: the whole loop as one resident launch
-    if (!c->graphExec || c->graphN != n) {
+    const int form = iterationForm(c, n);
+    if (form == 1) return sih_persist_launch(c, n);  // small block: the whole loop as one resident launch
+    if (!c->graphExec || c->graphN != n || c->graphForm != form) {
         if (c->graphExec) {
             (void)hipGraphExecDestroy(c->graphExec);
             c->graphExec = nullptr;
         }
         hipGraph_t graph;
         HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        for (int it = 0; it < n; it++) {
-            launchCellKernel(c, false);
-            launchVertexKernel(c, false);
-        }
-        HIPCHK(hipStreamEndCapture(c->stream, &graph));
+        rc = queueIterations(c, n);
+        hipError_t e = hipStreamEndCapture(c->stream, &graph);
+        if (rc) return rc;
+        HIPCHK(e);
         HIPCHK(hipGraphInstantiate(&c->graphExec, graph, nullptr, nullptr, 0));
         HIPCHK(hipGraphDestroy(graph));
         c->graphN = n;
+        c->graphForm = form;
     }
     HIPCHK(hipGraphLaunch(c->graphExec, c->stream));
     return SIH_OK;
@@ -1429,6 +1469,25 @@ extern "C" int sih_evp_subcycle_persistent(sih_ctx *c, int n)
     }
     beginSubcycles(c);
     return sih_persist_launch(c, n);
+}
+
+// n iterations (none the last of the dynamics step) as n + 1 launches of the fused kernel; an error if the block
+// does not qualify for it (sih_get_info "fusedKernel")
+extern "C" int sih_evp_subcycle_fused(sih_ctx *c, int n)
+{
+    int rc = checkInit(c, "sih_evp_subcycle_fused");
+    if (rc) return rc;
+    if (n < 1) {
+        sih_set_error("sih_evp_subcycle_fused: n must be >= 1");
+        return SIH_ERR_ARG;
+    }
+    if (!sih_fused_usable(c)) {
+        sih_set_error("sih_evp_subcycle_fused: this block does not qualify (an option that needs the two-kernel form)");
+        return SIH_ERR_UNSUPPORTED;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    beginSubcycles(c);
+    return sih_fused_launch(c, n);
 }
 
 // ---------------------------------------------------------------------------- special boundaries
@@ -1653,14 +1712,7 @@ static int queueChunk(sih_ctx *c, int m, bool overlap, bool pendingIn, bool more
 {
     int rc;
     if (!overlap) {
-        if (usePersistent(c, m)) {
-            if ((rc = sih_persist_launch(c, m))) return rc;
-        } else {
-            for (int it = 0; it < m; it++) {
-                launchCellKernel(c, false);
-                launchVertexKernel(c, false);
-            }
-        }
+        if ((rc = queueIterations(c, m))) return rc;
         if ((rc = sih_comm_push(c, nNames, names, c->stream))) return rc;
         if ((rc = sih_comm_pull(c, nNames, names, c->stream))) return rc;
         if (c->sbDeferred) applySpecialBoundaryVelocity(c);  // velocity_solver.F:2449-2456
@@ -1743,6 +1795,7 @@ extern "C" int sih_evp_subcycle_exchange(sih_ctx *c, int n, int last, int interv
     // stresses after every interval-th)
     if (nMain >= 2 && persistentMode(c) == 2 && !c->sbVelocity && usePersistent(c, nMain) && sih_persist_exchange_usable(c)) {
         if ((rc = sih_persist_launch_exchange(c, nMain, interval))) return rc;
+        c->lastForm = 1;
         done = nMain;
     }
     while (done < nMain) {
@@ -1750,7 +1803,7 @@ extern "C" int sih_evp_subcycle_exchange(sih_ctx *c, int n, int last, int interv
         const bool more = done + m < nMain;
         if (useGraph) {
             std::vector<int> key = {-1000, m, overlap ? 1 : 0, pending ? 1 : 0, more ? 1 : 0, c->sparseGrad ? 1 : 0,
-                                    usePersistent(c, m) ? 1 : 0};
+                                    overlap ? 0 : iterationForm(c, m)};
             auto it = c->partGraphs.find(key);
             if (it == c->partGraphs.end()) {
                 hipGraph_t graph;
@@ -1798,7 +1851,7 @@ extern "C" int sih_evp_subcycle_timed(sih_ctx *c, int n, int useGraph, int sampl
     if (vertexMs) *vertexMs = 0.0;
     beginSubcycles(c);
     if (useGraph) {
-        if (!c->graphExec || c->graphN != n) {
+        if (!c->graphExec || c->graphN != n || c->graphForm != 0) {  // the two kernels, whatever the block's own form
             if (c->graphExec) {
                 (void)hipGraphExecDestroy(c->graphExec);
                 c->graphExec = nullptr;
@@ -1813,6 +1866,7 @@ extern "C" int sih_evp_subcycle_timed(sih_ctx *c, int n, int useGraph, int sampl
             HIPCHK(hipGraphInstantiate(&c->graphExec, graph, nullptr, nullptr, 0));
             HIPCHK(hipGraphDestroy(graph));
             c->graphN = n;
+            c->graphForm = 0;
         }
         if ((rc = ensureEvents(c, 2))) return rc;
         HIPCHK(hipEventRecord(c->events[0], c->stream));

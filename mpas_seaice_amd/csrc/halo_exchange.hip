@@ -171,7 +171,6 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_halo_pull(PullArgs a)
 {
     __shared__ int ok;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int fi = blockIdx.y;
     const unsigned long long seq = __hip_atomic_load(&a.state[ST_RECV_SEQ], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ULL;
     const unsigned long long par = seq & 1ULL;
@@ -198,19 +197,24 @@ __global__ void __launch_bounds__(256) k_halo_pull(PullArgs a)
     }
     __syncthreads();
     if (ok) {
+        // a workgroup takes every gridDim.x-th run of 256 entries: the launch is a few hundred workgroups whatever
+        // the size of the halo (all of them wait above)
         const char *half = a.base + par * a.halfBytes;
+        const int stride = gridDim.x * blockDim.x;
         if (fi < a.nfC) {
-            if (t < a.nC) {
+            for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < a.nC; t += stride) {
                 const int p = a.peerC[t];
                 const size_t off = (size_t)fi * a.cntC[p] + a.relC[t];
                 const T *src = (const T *)(half + a.srcOff[p]) + off;
                 ((T *)a.planes[fi])[a.idxC[t]] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-        } else if (t < a.nV) {
-            const int p = a.peerV[t];
-            const size_t off = (size_t)a.nfC * a.cntC[p] + (size_t)(fi - a.nfC) * a.cntV[p] + a.relV[t];
-            const T *src = (const T *)(half + a.srcOff[p]) + off;
-            ((T *)a.planes[fi])[a.idxV[t]] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < a.nV; t += stride) {
+                const int p = a.peerV[t];
+                const size_t off = (size_t)a.nfC * a.cntC[p] + (size_t)(fi - a.nfC) * a.cntV[p] + a.relV[t];
+                const T *src = (const T *)(half + a.srcOff[p]) + off;
+                ((T *)a.planes[fi])[a.idxV[t]] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
     __syncthreads();
@@ -764,7 +768,13 @@ int sih_comm_pull(sih_ctx *c, int nFields, const char *const *names, hipStream_t
     a.recvPeers = s->d_recvPeers;
     a.nRecvPeers = s->nRecvPeers;
     a.state = s->d_state;
-    dim3 grid((unsigned)std::max(1, (std::max(nC, nV) + 255) / 256), (unsigned)std::max(1, tb->nPlanesC + tb->nPlanesV));
+    // Every workgroup of this kernel waits for the neighbours' flags before it copies, so its size is bounded (about
+    // one workgroup a CU in all) and the workgroups stride over the entries: sized by the halo, a deep halo of a large
+    // block made thousands of waiting waves, and several blocks sharing one device (ranks rehearsed on one GPU)
+    // could fill it with them and keep out the very kernels they were waiting for.
+    const int nPlanes = std::max(1, tb->nPlanesC + tb->nPlanesV);
+    const int needX = std::max(1, (std::max(nC, nV) + 255) / 256);
+    dim3 grid((unsigned)std::min(needX, std::max(1, 256 / nPlanes)), (unsigned)nPlanes);
     if (tb->isInt)
         hipLaunchKernelGGL(k_halo_pull<unsigned int>, grid, dim3(256), 0, stream, a);
     else

@@ -121,6 +121,8 @@ struct sih_ctx {
     std::map<std::string, HaloTable> haloTables;  // plane-pointer tables of the field groups exchanged so far
     hipGraphExec_t graphExec = nullptr;
     int graphN = 0;
+    int lastForm = 0;   // the form the last loop of iterations took: 0 two kernels, 1 persistent, 2 fused
+    int graphForm = 0;  // what the graph holds: 0 the two kernels per iteration, 2 the fused kernel
     int *d_flag = nullptr;
     std::vector<hipEvent_t> events;
 };
@@ -142,6 +144,10 @@ bool sih_persist_usable(sih_ctx *c);
 int sih_persist_launch(sih_ctx *c, int n);
 int sih_persist_status(sih_ctx *c);
 double sih_persist_info(sih_ctx *c, int what);
+// the same tiles as one launch per iteration, for blocks that cannot stay resident (evp_persist.hip)
+#define SIH_FUSED_MAX_CELLS_DEFAULT 100000
+bool sih_fused_usable(sih_ctx *c);
+int sih_fused_launch(sih_ctx *c, int m);
 int sih_comm_push(sih_ctx *c, int nFields, const char *const *names, hipStream_t stream);
 int sih_comm_pull(sih_ctx *c, int nFields, const char *const *names, hipStream_t stream);
 int sih_comm_prepare(sih_ctx *c, int nFields, const char *const *names);  // builds the group's tables (not capturable)

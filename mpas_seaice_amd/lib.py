@@ -82,7 +82,7 @@ EXPORTS = [
     "sih_evp_strain_tensor", "sih_evp_stress_divergence",
     "sih_comm_handle_size", "sih_comm_create", "sih_comm_get_handle", "sih_comm_connect", "sih_comm_destroy",
     "sih_halo_exchange", "sih_halo_exchange_start", "sih_halo_exchange_finish", "sih_comm_set_timeout",
-    "sih_comm_status", "sih_evp_subcycle_exchange", "sih_field_get_noalloc", "sih_device_count", "sih_evp_subcycle_persistent", "sih_column_get", "sih_column_put", "sih_evp_set_persistent",
+    "sih_comm_status", "sih_evp_subcycle_exchange", "sih_field_get_noalloc", "sih_device_count", "sih_evp_subcycle_persistent", "sih_evp_subcycle_fused", "sih_column_get", "sih_column_put", "sih_evp_set_persistent",
 ]
 
 
@@ -128,6 +128,7 @@ def load():
     lib.sih_evp_post_subcycle.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.sih_evp_subcycle_graph.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.sih_evp_subcycle_persistent.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.sih_evp_subcycle_fused.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.sih_evp_set_persistent.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.sih_evp_set_special_boundaries.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4
     lib.sih_evp_overlap_setup.argtypes = [ctypes.c_void_p]
@@ -316,6 +317,9 @@ class BlockContext:
 
     def subcycle_persistent(self, n):
         check(self._lib.sih_evp_subcycle_persistent(self.handle, int(n)), "sih_evp_subcycle_persistent")
+
+    def subcycle_fused(self, n):
+        check(self._lib.sih_evp_subcycle_fused(self.handle, int(n)), "sih_evp_subcycle_fused")
 
     def set_special_boundaries(self, vertexBoundaryType=None, vertexBoundarySourceLocal=None,
                                solveVelocitySpecialBoundaries=None, solveStressSpecialBoundaries=None):

@@ -649,6 +649,7 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
     sync()
     wall = time.perf_counter() - t0
     launches_timed = ctx.info("persistentLaunches") - launches0
+    form_timed = ctx.info("iterationForm")  # of the last loop of the timed steps: 0 two kernels, 1 persistent, 2 fused
     wall = reduce_scalar(wall, dist.ReduceOp.MAX)
     if transport == "p2p":
         dom.comm.check(dom)  # raises if any message of the timed loop failed to arrive
@@ -674,6 +675,8 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
         raise SystemExit("non-finite velocities after the benchmark loop")
     n_block_cells = dom.blocklist[0].dimensions["nCells"]
     persistent_launches = reduce_scalar(launches_timed, dist.ReduceOp.MIN)  # of the timed loop, on every rank
+    form_all = reduce_scalar(form_timed, dist.ReduceOp.MIN)
+    form_same = reduce_scalar(form_timed, dist.ReduceOp.MAX) == form_all
     if transport == "p2p":
         dom.comm.check(dom)
     dist.barrier()
@@ -695,4 +698,5 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
             "overlap": overlap, "graph": bool(use_graph), "transport": transport, "transport_text": how,
             "transport_note": note, "exchange_us": ex_us, "rendezvous_backend": real_backend,
             "exchange_inside_kernel": bool(inside), "exchange_inside_note": inside_note,
-            "persistent_kernel": bool(persistent_launches > 0)}
+            "persistent_kernel": bool(persistent_launches > 0 or (form_same and form_all == 1.0)),
+            "fused_kernel": bool(form_same and form_all == 2.0)}

@@ -57,6 +57,14 @@ out["persistent_tiles"], out["persistent_arrived"] = ctx.info("persistentTiles")
 if out["persistent_kernel"]:
     out["persistent_us_per_subcycle"] = timed(lambda: ctx.subcycle_persistent(k), args.chunks) / k
     out["persistent_us_per_subcycle_120"] = timed(lambda: ctx.subcycle_persistent(120), 20) / 120
+out["fused_kernel"] = ctx.info("fusedKernel")
+if out["fused_kernel"]:
+    out["fused_us_per_subcycle"] = timed(lambda: ctx.subcycle_fused(k), args.chunks) / k
+    out["fused_us_per_subcycle_119"] = timed(lambda: ctx.subcycle_fused(119), 20) / 119
+ctx.set_persistent(0)
+out["two_kernel_graph_us_per_subcycle"] = timed(lambda: ctx.subcycle_graph(k), args.chunks) / k
+out["two_kernel_graph_us_per_subcycle_119"] = timed(lambda: ctx.subcycle_graph(119), 20) / 119
+ctx.set_persistent(-1)
 body = [CR, VA] + [CA, VA] * (k - 2) + [CA, VS]
 tail = [VR, CI]
 

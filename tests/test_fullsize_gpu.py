@@ -191,6 +191,11 @@ def test_qu60_eight_blocks_as_the_benchmark_partitions_them_equal_one_block(qu60
         dom.comm = parallel.LocalComm(dom, halos, 8)
         vs.seaice_init_velocity_solver(dom)
         vs.seaice_run_velocity_solver(dom)
+        # eight contexts share the device, so none of them may hold it with the persistent kernel: the chunks run as
+        # one launch per iteration over tiles (the form a block too large to be resident takes as well)
+        for b in dom.blocklist:
+            assert b.ctx.info("persistentLaunches") <= 1.0  # the trial launch of the set-up, if the block is small enough
+            assert b.ctx.info("fusedLaunches") > 0.0
     finally:
         vs.seaice_mesh_pool_destroy(dom)
     b0 = device_qu60.blocklist[0]
