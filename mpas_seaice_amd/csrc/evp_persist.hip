@@ -47,7 +47,7 @@
 #define COS_TURN 1.0
 
 // words of the state array; the census counters sit 128 bytes apart behind the first line
-enum { PS_EPOCH = 0, PS_LAUNCHES = 1, PS_STATUS = 2, PS_TICKS = 3, PS_XSEQ = 4, PS_XTICKS = 5, PS_CENSUS = 16, PS_CENSUS_N = 32, PS_CENSUS_STRIDE = 16,
+enum { PS_EPOCH = 0, PS_LAUNCHES = 1, PS_STATUS = 2, PS_TICKS = 3, PS_XSEQ = 4, PS_XTICKS = 5, PS_XLAUNCHES = 6, PS_CENSUS = 16, PS_CENSUS_N = 32, PS_CENSUS_STRIDE = 16,
        PS_WORDS = PS_CENSUS + PS_CENSUS_N * PS_CENSUS_STRIDE };
 #define PS_RING 4  // buffers of the partial sums, used in turn
 #define PS_MARKER 0xFFF8C0DEDEADBEEFULL  // "not written yet": a NaN with a payload no operation produces
@@ -131,6 +131,9 @@ struct sih_persist_state {
     double *uAlt = nullptr, *vAlt = nullptr;  // the second copy of the velocities that form alternates with
     const int *tvVert = nullptr, *tvOwned = nullptr;  // the tiles' vertex lists padded to 64 M entries a tile (-1: none)
     int *tvQ = nullptr;                               // [3][tiles * 64 M]: where such a vertex finds its three partial sums
+    const int *fusedSlot = nullptr;                   // per (corner, cell): place of its vertex in the list of its 64-cell tile
+    int fusedTiles = 0;
+    int tileCells = 64;                               // cells of a tile of the persistent kernel
     bool unchecked = false;  // a launch since the status word was last read
     std::vector<void *> allocs;
     // the tiles' vertex lists on the host, for the tables of the in-kernel exchange
@@ -173,23 +176,26 @@ __device__ inline double sign1p(double x) { return copysign(1.0, x); }
 // (2 * 64 M), the integral rows (3 M * 64 M).  Requested at launch, not declared statically: with the size in the
 // kernel the compiler takes the two workgroups a CU's LDS holds for the occupancy and lets the registers grow past
 // 128 a lane, where the hardware no longer admits the second workgroup.
-template <int M>
-constexpr int persistLdsDoubles() { return 5 * M * 64 + 2 * 64 * M + 3 * M * 64 * M; }
+// TC: cells of a tile (64, or 42: four waves a workgroup, four workgroups a CU).  STREAM: the rows of the metric
+// integrals are not kept in LDS but read from memory (L2) in every iteration: two thirds of the LDS a cell, so that
+// four workgroups of 42 cells fit a CU: 43 008 cells instead of 32 768.
+template <int M, int TC, bool STREAM>
+constexpr int persistLdsDoubles() { return 5 * M * TC + 2 * TC * M + (STREAM ? 2 : 3) * M * TC * M; }
 
-template <int M, bool XCHG>
-__global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, PersistArgs p, int nIter,
+template <int M, int TC, bool XCHG, bool STREAM>
+__global__ void __launch_bounds__(TC * M, 4) k_sub_persistent(PersistDev d, PersistArgs p, int nIter,
                                                              const PersistXchg *__restrict__ xp, int xInterval, int xCells)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double(*su)[64] = (double(*)[64])(smem);
-    double(*sv)[64] = (double(*)[64])(smem + M * 64);
-    double(*s11)[64] = (double(*)[64])(smem + 2 * M * 64);
-    double(*s22)[64] = (double(*)[64])(smem + 3 * M * 64);
-    double(*s12)[64] = (double(*)[64])(smem + 4 * M * 64);
-    double *uT = smem + 5 * M * 64, *vT = uT + 64 * M;       // velocities of the tile's vertices
-    double(*sInt)[64 * M] = (double(*)[64 * M])(vT + 64 * M);  // this thread's rows of basisIntegralsU / V / Metric
+    double(*su)[TC] = (double(*)[TC])(smem);
+    double(*sv)[TC] = (double(*)[TC])(smem + M * TC);
+    double(*s11)[TC] = (double(*)[TC])(smem + 2 * M * TC);
+    double(*s22)[TC] = (double(*)[TC])(smem + 3 * M * TC);
+    double(*s12)[TC] = (double(*)[TC])(smem + 4 * M * TC);
+    double *uT = smem + 5 * M * TC, *vT = uT + TC * M;       // velocities of the tile's vertices
+    double(*sInt)[TC * M] = (double(*)[TC * M])(vT + TC * M);  // this thread's rows of basisIntegralsU / V (/ Metric)
     __shared__ int okShared, sDead;
-    const int lane = threadIdx.x, g = threadIdx.y, tid = g * 64 + lane;
+    const int lane = threadIdx.x, g = threadIdx.y, tid = g * TC + lane;
     // consecutive tiles on one XCD (workgroups are dealt round-robin over the eight XCDs): neighbouring tiles then
     // mostly hand their sums over through one L2
     const int nT = p.nTiles;
@@ -205,10 +211,11 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
     const unsigned long long launches = ldAgent(&p.state[PS_LAUNCHES]);
     const unsigned long long epoch = ldAgent(&p.state[PS_EPOCH]);  // iterations done by earlier launches
     const unsigned long long xseq0 = XCHG ? ldAgent(&p.state[PS_XSEQ]) : 0ULL;  // exchanges done by earlier launches
+    const unsigned long long xl0 = XCHG ? ldAgent(&p.state[PS_XLAUNCHES]) : 0ULL;  // earlier launches with the exchange inside
 
     // ---- what this thread keeps for all iterations: its cell corner ...
     const int P = d.padC, PV = d.padV;
-    int c = tile * 64 + lane;
+    int c = tile * TC + lane;
     const bool inRange = c < d.nCells;
     if (!inRange) c = 0;
     const size_t k = (size_t)g * P + c;
@@ -226,11 +233,11 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
             const size_t kb = (size_t)(g * M + s) * P + c;
             x = d.SU[kb];
             y = d.SV[kb];
-            z = d.SM[kb];
+            if (!STREAM) z = d.SM[kb];
         }
         sInt[s][tid] = x;
         sInt[M + s][tid] = y;
-        sInt[2 * M + s][tid] = z;
+        if (!STREAM) sInt[2 * M + s][tid] = z;
     }
     if (corner) {
         tg = d.tanLat[d.voc[k]];
@@ -337,7 +344,10 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
     if (alive && tile == 0 && tid == 0) {
         stAgent(&p.state[PS_EPOCH], epoch + (unsigned long long)nIter);
         stAgent(&p.state[PS_LAUNCHES], launches + 1ULL);
-        if (XCHG) stAgent(&p.state[PS_XSEQ], xseq0 + (unsigned long long)((nIter + xInterval - 1) / xInterval));
+        if (XCHG) {
+            stAgent(&p.state[PS_XSEQ], xseq0 + (unsigned long long)((nIter + xInterval - 1) / xInterval));
+            stAgent(&p.state[PS_XLAUNCHES], xl0 + 1ULL);
+        }
     }
     unsigned int xDone = 0;  // exchanges of this launch so far
     const double dtE = d.dtE, T = d.dampT, brlx = d.brlx, dtD = d.dtDyn;
@@ -351,6 +361,14 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
         const double ug = uT[slot], vg = vT[slot];
         su[g][lane] = corner ? ug : 0.0;
         sv[g][lane] = corner ? vg : 0.0;
+        // the streamed rows of the metric integrals are requested here and used at the end of the cell phase: they
+        // travel (from L2) while strain and stress are computed (requested where they are used: 13.4 instead of 10.7 us
+        // an iteration at QU120; requested one iteration ahead, across the wait for the sums: 14.3)
+        double bmS[M];
+        if (STREAM) {
+#pragma unroll
+            for (int s = 0; s < M; s++) bmS[s] = corner ? d.SM[(size_t)(g * M + s) * P + c] : 0.0;
+        }
         __syncthreads();
         double a11 = 0.0, a22 = 0.0, a12 = 0.0;
         if (corner) {
@@ -406,7 +424,7 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
             for (int s = 0; s < M; s++) {
                 if (s < E) {
                     const double x11 = s11[s][lane], x22 = s22[s][lane], x12 = s12[s][lane];
-                    const double bu = sInt[s][tid], bv = sInt[M + s][tid], bm = sInt[2 * M + s][tid];
+                    const double bu = sInt[s][tid], bv = sInt[M + s][tid], bm = STREAM ? bmS[s] : sInt[2 * M + s][tid];
                     cu = cu - x11 * bu - x12 * bv - x12 * bm * tg;
                     cv = cv - x22 * bv - x12 * bu + x11 * bm * tg;
                 }
@@ -508,7 +526,9 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
             if (xp->tileActive[tile] == 0) continue;  // nothing of this tile travels (the same answer in every thread)
             const PersistXchg X = *xp;
             const unsigned long long tag = ((xseq0 + xDone) & 0xffffffffULL) << 32;
-            const unsigned long long par = (xseq0 + xDone) % SIH_TAGGED_COPIES;
+            // the copy: exchange xDone of this launch, in the bank of this launch's parity (the host splits loops with
+            // more exchanges than a bank has copies)
+            const unsigned long long par = (xl0 & 1ULL) * (SIH_TAGGED_COPIES / 2) + (unsigned long long)((xDone - 1) % (SIH_TAGGED_COPIES / 2));
             // (xCells == 0: an exchange after every iteration carries the velocities only, as the reference's does;
             // the stresses of the halo cells are then computed here from the received velocities)
             if (inRange && xCells) {
@@ -580,19 +600,35 @@ __global__ void __launch_bounds__(64 * M, 4) k_sub_persistent(PersistDev d, Pers
                     __builtin_amdgcn_s_sleep(2);
                 }
             }
+            // every word is checked once more as it is taken: one that carries another tag than this exchange's
+            // (overwritten by a later exchange before it was read, which the two banks rule out) ends the launch with
+            // an error instead of passing on a wrong value
+            bool intact = true;
             if (rb >= 0) {
                 const unsigned long long *q = mine + (size_t)rb;
                 const size_t fs = 2 * (size_t)M * rs;
-                o11 = valueOf((ldSystem(q) & 0xffffffffULL) | (ldSystem(q + rs) << 32));
-                o22 = valueOf((ldSystem(q + fs) & 0xffffffffULL) | (ldSystem(q + fs + rs) << 32));
-                o12 = valueOf((ldSystem(q + 2 * fs) & 0xffffffffULL) | (ldSystem(q + 2 * fs + rs) << 32));
+                const unsigned long long w0 = ldSystem(q), w1 = ldSystem(q + rs), w2 = ldSystem(q + fs), w3 = ldSystem(q + fs + rs);
+                const unsigned long long w4 = ldSystem(q + 2 * fs), w5 = ldSystem(q + 2 * fs + rs);
+                intact = (unsigned int)(w0 >> 32) == tag32 && (unsigned int)(w1 >> 32) == tag32 && (unsigned int)(w2 >> 32) == tag32 &&
+                         (unsigned int)(w3 >> 32) == tag32 && (unsigned int)(w4 >> 32) == tag32 && (unsigned int)(w5 >> 32) == tag32;
+                o11 = valueOf((w0 & 0xffffffffULL) | (w1 << 32));
+                o22 = valueOf((w2 & 0xffffffffULL) | (w3 << 32));
+                o12 = valueOf((w4 & 0xffffffffULL) | (w5 << 32));
             }
             if (vb >= 0) {
                 const unsigned long long *q = mine + (size_t)vb;
-                uu = valueOf((ldSystem(q) & 0xffffffffULL) | (ldSystem(q + vstr) << 32));
-                vv = valueOf((ldSystem(q + 2 * (size_t)vstr) & 0xffffffffULL) | (ldSystem(q + 3 * (size_t)vstr) << 32));
+                const unsigned long long w0 = ldSystem(q), w1 = ldSystem(q + vstr), w2 = ldSystem(q + 2 * (size_t)vstr),
+                                         w3 = ldSystem(q + 3 * (size_t)vstr);
+                intact = intact && (unsigned int)(w0 >> 32) == tag32 && (unsigned int)(w1 >> 32) == tag32 &&
+                         (unsigned int)(w2 >> 32) == tag32 && (unsigned int)(w3 >> 32) == tag32;
+                uu = valueOf((w0 & 0xffffffffULL) | (w1 << 32));
+                vv = valueOf((w2 & 0xffffffffULL) | (w3 << 32));
                 uT[tid] = uu;
                 vT[tid] = vv;
+            }
+            if (!intact && !sDead) {  // (a wait that ran out has said so already)
+                __hip_atomic_fetch_max(&p.state[PS_STATUS], 4ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sDead = 1;
             }
             __syncthreads();
             if (sDead) break;
@@ -862,11 +898,14 @@ void sih_persist_destroy(sih_ctx *c)
     c->persist = nullptr;
 }
 
-template <int M>
+#define PS_SMALL_TILE 42  // cells of the small tile: 42 x 6 corners = 252 threads = four waves, one a SIMD
+
+template <int M, int TC, bool STREAM>
 static int occupancyFor(int *perCU)
 {
     int n = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (k_sub_persistent<M, true>), 64 * M, persistLdsDoubles<M>() * sizeof(double));
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (k_sub_persistent<M, TC, true, STREAM>), TC * M,
+                                                                persistLdsDoubles<M, TC, STREAM>() * sizeof(double));
     if (e != hipSuccess) return sih_hip_fail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor", __FILE__, __LINE__);
     *perCU = n;
     return SIH_OK;
@@ -885,8 +924,53 @@ static int upload(sih_persist_state *s, const T **dst, const std::vector<T> &v)
 
 int sih_persist_launch(sih_ctx *c, int n);
 
+// The block cut into tiles of tc consecutive cells.  Every tile lists the vertices of its cells (a vertex shared
+// with neighbouring tiles is in each of their lists); the tile that holds the lowest-numbered cell of a vertex is the
+// one that stores it at the end.
+struct TileTables {
+    int tc = 0, nT = 0;
+    std::vector<int> vStart, verts, owned, slot;  // slot: per (corner, cell), the place of its vertex in the tile's list
+    bool ok = false;                              // false: a tile has more vertices than threads
+};
+
+static void buildTiles(const sih_ctx *c, int tc, const std::vector<std::vector<int>> &cellsOfVertex, TileTables &t)
+{
+    const int M = c->M, nC = c->nCells, nV = c->nVertices;
+    t.tc = tc;
+    t.nT = (nC + tc - 1) / tc;
+    t.vStart.assign(t.nT + 1, 0);
+    t.verts.clear();
+    t.owned.clear();
+    t.slot.assign((size_t)M * c->padC, 0);
+    t.ok = false;
+    std::vector<int> where(nV, -1);  // position of a vertex in the current tile's list
+    for (int tl = 0; tl < t.nT; tl++) {
+        const int first = (int)t.verts.size();
+        for (int i = tl * tc; i < std::min(nC, (tl + 1) * tc); i++)
+            for (int sIdx = 0; sIdx < c->hNe[i]; sIdx++) {
+                const int v = c->hVoc[(size_t)sIdx * c->padC + i];
+                if (v >= nV) continue;  // "no vertex": the corner reads the zero slot, which position 0 never is
+                if (where[v] < first) {
+                    where[v] = (int)t.verts.size();
+                    t.verts.push_back(v);
+                    int low = nC;
+                    for (int cc : cellsOfVertex[v]) low = std::min(low, cc);
+                    t.owned.push_back(low / tc == tl ? 1 : 0);
+                }
+                t.slot[(size_t)sIdx * c->padC + i] = where[v] - first;
+            }
+        t.vStart[tl + 1] = (int)t.verts.size();
+        if (t.vStart[tl + 1] - t.vStart[tl] > tc * M) return;  // more vertices than threads: not this block
+    }
+    if (t.verts.empty()) {
+        t.verts.push_back(0);
+        t.owned.push_back(0);
+    }
+    t.ok = true;
+}
+
 // Builds the tile tables.  Returns SIH_OK with c->persist->usable = false when the block does not qualify
-// (then the two-kernel form runs); an error only for HIP failures.
+// (then the fused or the two-kernel form runs); an error only for HIP failures.
 int sih_persist_setup(sih_ctx *c)
 {
     sih_persist_destroy(c);
@@ -899,90 +983,43 @@ int sih_persist_setup(sih_ctx *c)
         return SIH_OK;
     }
     HIPCHK(hipSetDevice(c->device));
-    int perCU = 0, rc = SIH_OK;
-    switch (M) {
-        case 3: rc = occupancyFor<3>(&perCU); break;
-        case 4: rc = occupancyFor<4>(&perCU); break;
-        case 5: rc = occupancyFor<5>(&perCU); break;
-        case 6: rc = occupancyFor<6>(&perCU); break;
-        case 7: rc = occupancyFor<7>(&perCU); break;
-        default: rc = occupancyFor<8>(&perCU); break;
-    }
-    if (rc) return rc;
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, c->device));
-    // the runtime's answer can be one too high for kernels that hold many scalar registers; the probe launch below
-    // settles whether this grid is resident at once
-    s->perCU = perCU;
-    s->capacity = perCU * prop.multiProcessorCount;
-    if (const char *e = getenv("SIH_PERSIST_CAPACITY")) s->capacity = atoi(e);
-    const int nT = (nC + 63) / 64;
-    if (nT < 1) {
+    int rc = SIH_OK;
+    if (nC < 1) {
         s->reason = 2;
         return SIH_OK;
     }
-
-    // Every tile lists the vertices of its cells (a vertex shared with neighbouring tiles is in each of their
-    // lists); the tile that holds the lowest-numbered cell of a vertex is the one that stores it at the end.
     std::vector<std::vector<int>> cellsOfVertex(nV);
     for (int i = 0; i < nC; i++)
         for (int sIdx = 0; sIdx < c->hNe[i]; sIdx++) {
             const int v = c->hVoc[(size_t)sIdx * c->padC + i];
             if (v < nV) cellsOfVertex[v].push_back(i);
         }
-    std::vector<int> vStart(nT + 1, 0), verts, ownedFlag, slot((size_t)M * c->padC, 0);
-    {
-        std::vector<int> where(nV, -1);  // position of a vertex in the current tile's list
-        for (int t = 0; t < nT; t++) {
-            const int first = (int)verts.size();
-            for (int i = t * 64; i < std::min(nC, (t + 1) * 64); i++)
-                for (int sIdx = 0; sIdx < c->hNe[i]; sIdx++) {
-                    const int v = c->hVoc[(size_t)sIdx * c->padC + i];
-                    if (v >= nV) continue;  // "no vertex": the corner reads the zero slot, which position 0 never is
-                    if (where[v] < first) {
-                        where[v] = (int)verts.size();
-                        verts.push_back(v);
-                        int low = nC;
-                        for (int cc : cellsOfVertex[v]) low = std::min(low, cc);
-                        ownedFlag.push_back(low / 64 == t ? 1 : 0);
-                    }
-                    slot[(size_t)sIdx * c->padC + i] = where[v] - first;
-                }
-            vStart[t + 1] = (int)verts.size();
-            if (vStart[t + 1] - vStart[t] > 64 * M) {  // more vertices than threads: not this block
-                s->reason = 3;
-                return SIH_OK;
-            }
-        }
+    TileTables t64;
+    buildTiles(c, 64, cellsOfVertex, t64);
+    if (!t64.ok) {
+        s->reason = 3;
+        return SIH_OK;
     }
-    if (verts.empty()) {
-        verts.push_back(0);
-        ownedFlag.push_back(0);
-    }
-    // the three buffers of the partial sums, zero where no corner ever writes (the slot that stands for "no cell")
+    // the buffers of the partial sums, zero where no corner ever writes (the slot that stands for "no cell")
     if ((rc = sih_add_field(c, "_partRing", LOC_CELL, 2 * PS_RING * M, false))) return rc;
-    s->hVStart = vStart;
-    s->hVerts = verts;
-    s->hOwned = ownedFlag;
     PersistArgs &a = s->a;
-    a.nTiles = nT;
     a.part = (unsigned long long *)sih_find_field(c, "_partRing")->d;
-    if ((rc = upload(s, &a.tileVertStart, vStart))) return rc;
-    if ((rc = upload(s, &a.tileVerts, verts))) return rc;
-    if ((rc = upload(s, &a.tileVertOwned, ownedFlag))) return rc;
-    if ((rc = upload(s, &a.cornerSlot, slot))) return rc;
     {
-        // the same lists with 64 M entries a tile (what k_sub_fused reads: no look-up of where a tile's list begins),
-        // the places of the vertices' partial sums beside them, and the second copy of the velocities
+        // what k_sub_fused reads: the lists of the 64-cell tiles with 64 M entries a tile (no look-up of where a
+        // tile's list begins), the places of the vertices' partial sums beside them, the corners' places in the
+        // lists, and the second copy of the velocities
+        const int nT = t64.nT;
         const size_t nE = (size_t)nT * 64 * M;
         std::vector<int> pv(nE, -1), po(nE, 0);
         for (int t = 0; t < nT; t++)
-            for (int jj = vStart[t]; jj < vStart[t + 1]; jj++) {
-                pv[(size_t)t * 64 * M + (jj - vStart[t])] = verts[jj];
-                po[(size_t)t * 64 * M + (jj - vStart[t])] = ownedFlag[jj];
+            for (int jj = t64.vStart[t]; jj < t64.vStart[t + 1]; jj++) {
+                pv[(size_t)t * 64 * M + (jj - t64.vStart[t])] = t64.verts[jj];
+                po[(size_t)t * 64 * M + (jj - t64.vStart[t])] = t64.owned[jj];
             }
         if ((rc = upload(s, &s->tvVert, pv))) return rc;
         if ((rc = upload(s, &s->tvOwned, po))) return rc;
+        if ((rc = upload(s, &s->fusedSlot, t64.slot))) return rc;
+        s->fusedTiles = nT;
         void *tq = nullptr;
         HIPCHK(hipMalloc(&tq, sizeof(int) * 3 * nE));
         s->allocs.push_back(tq);
@@ -997,10 +1034,64 @@ int sih_persist_setup(sih_ctx *c)
         HIPCHK(hipStreamSynchronize(c->stream));
         s->fusedReady = true;
     }
-    if (nT > s->capacity) {  // too many tiles to be resident together: no persistent kernel for this block
-        s->reason = 2;
-        return SIH_OK;
+
+    // ---- the persistent kernel: tiles of 64 cells with all integral rows in LDS if the block fits, else (maxEdges
+    //      6) tiles of 42 cells with the metric rows streamed, which hold a third more cells
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, c->device));
+    int perCU = 0;
+    switch (M) {
+        case 3: rc = occupancyFor<3, 64, false>(&perCU); break;
+        case 4: rc = occupancyFor<4, 64, false>(&perCU); break;
+        case 5: rc = occupancyFor<5, 64, false>(&perCU); break;
+        case 6: rc = occupancyFor<6, 64, false>(&perCU); break;
+        case 7: rc = occupancyFor<7, 64, false>(&perCU); break;
+        default: rc = occupancyFor<8, 64, false>(&perCU); break;
     }
+    if (rc) return rc;
+    // the runtime's answer can be one too high for kernels that hold many scalar registers; the probe launch below
+    // settles whether this grid is resident at once
+    s->perCU = perCU;
+    s->capacity = perCU * prop.multiProcessorCount;
+    if (const char *e = getenv("SIH_PERSIST_CAPACITY")) s->capacity = atoi(e);
+    TileTables tSmall;
+    const TileTables *use = &t64;
+    s->tileCells = 64;
+    const char *smallEnv = getenv("SIH_PERSIST_SMALL_TILES");  // 0: tiles of 64 cells only
+    const bool smallTiles = !(smallEnv && atoi(smallEnv) == 0);
+    if (t64.nT > s->capacity) {
+        bool fits = false;
+        if (M == 6 && smallTiles) {
+            int perCUs = 0;
+            if ((rc = occupancyFor<6, PS_SMALL_TILE, true>(&perCUs))) return rc;
+            int cap = perCUs * prop.multiProcessorCount;
+            if (const char *e = getenv("SIH_PERSIST_CAPACITY_SMALL")) cap = atoi(e);
+            buildTiles(c, PS_SMALL_TILE, cellsOfVertex, tSmall);
+            if (tSmall.ok && tSmall.nT <= cap) {
+                fits = true;
+                use = &tSmall;
+                s->tileCells = PS_SMALL_TILE;
+                s->perCU = perCUs;
+                s->capacity = cap;
+            }
+        }
+        if (!fits) {  // too many tiles to be resident together: no persistent kernel for this block
+            a.nTiles = t64.nT;
+            s->reason = 2;
+            return SIH_OK;
+        }
+    }
+    s->hVStart = use->vStart;
+    s->hVerts = use->verts;
+    s->hOwned = use->owned;
+    a.nTiles = use->nT;
+    if ((rc = upload(s, &a.tileVertStart, use->vStart))) return rc;
+    if ((rc = upload(s, &a.tileVerts, use->verts))) return rc;
+    if ((rc = upload(s, &a.tileVertOwned, use->owned))) return rc;
+    if (use == &t64)
+        a.cornerSlot = s->fusedSlot;
+    else if ((rc = upload(s, &a.cornerSlot, use->slot)))
+        return rc;
     void *q = nullptr;
     HIPCHK(hipMalloc(&q, sizeof(unsigned long long) * PS_WORDS));
     s->allocs.push_back(q);
@@ -1015,7 +1106,7 @@ int sih_persist_setup(sih_ctx *c)
     if (getenv("SIH_PERSIST_TIMEOUT_MS") || xticks < ticks) xticks = ticks;
     HIPCHK(hipMemcpy(a.state + PS_XTICKS, &xticks, sizeof xticks, hipMemcpyHostToDevice));
     // probe: a launch of zero iterations runs the census only.  If its workgroups are not all resident together it
-    // says so within the time limit and the two-kernel form stays in use.
+    // says so within the time limit and the other forms stay in use.
     s->usable = true;
     HIPCHK(hipStreamSynchronize(c->stream));
     if ((rc = sih_persist_launch(c, 0))) return rc;
@@ -1037,23 +1128,35 @@ double sih_persist_info(sih_ctx *c, int what)
     if (!c->persist) return 0.0;
     const sih_persist_state *s = c->persist;
     return what == 0 ? s->perCU : what == 1 ? s->reason : what == 2 ? s->a.nTiles : what == 3 ? s->arrived : what == 4 ? s->launches
-           : what == 5 ? s->xLaunches : s->fusedLaunches;
+           : what == 5 ? s->xLaunches : what == 6 ? s->fusedLaunches : s->tileCells;
 }
 
 // the kernel reads the compact gradients: a put of a basis array switches it off until sih_evp_static_changed()
 bool sih_persist_usable(sih_ctx *c) { return c->persist && c->persist->usable && c->sparseGrad; }
 
+template <int M, int TC, bool STREAM>
+static void launchPersistVariant(sih_ctx *c, int n, int interval)
+{
+    const PersistArgs &a = c->persist->a;
+    const size_t lds = persistLdsDoubles<M, TC, STREAM>() * sizeof(double);
+    if (interval > 0)
+        hipLaunchKernelGGL((k_sub_persistent<M, TC, true, STREAM>), dim3((unsigned)a.nTiles), dim3(TC, M), lds, c->stream,
+                           makePersistDev(c->dev), a, n, (const PersistXchg *)c->persist->d_x, interval, interval > 1 ? 1 : 0);
+    else
+        hipLaunchKernelGGL((k_sub_persistent<M, TC, false, STREAM>), dim3((unsigned)a.nTiles), dim3(TC, M), lds, c->stream,
+                           makePersistDev(c->dev), a, n, (const PersistXchg *)nullptr, 1, 0);
+}
+
 template <int M>
 static void launchPersist(sih_ctx *c, int n, int interval)
 {
-    const PersistArgs &a = c->persist->a;
-    const size_t lds = persistLdsDoubles<M>() * sizeof(double);
-    if (interval > 0)
-        hipLaunchKernelGGL((k_sub_persistent<M, true>), dim3((unsigned)a.nTiles), dim3(64, M), lds, c->stream,
-                           makePersistDev(c->dev), a, n, (const PersistXchg *)c->persist->d_x, interval, interval > 1 ? 1 : 0);
-    else
-        hipLaunchKernelGGL((k_sub_persistent<M, false>), dim3((unsigned)a.nTiles), dim3(64, M), lds, c->stream,
-                           makePersistDev(c->dev), a, n, (const PersistXchg *)nullptr, 1, 0);
+    if constexpr (M == 6) {
+        if (c->persist->tileCells == PS_SMALL_TILE) {
+            launchPersistVariant<6, PS_SMALL_TILE, true>(c, n, interval);
+            return;
+        }
+    }
+    launchPersistVariant<M, 64, false>(c, n, interval);
 }
 
 static int launchAny(sih_ctx *c, int n, int interval)
@@ -1083,7 +1186,7 @@ template <int M>
 static void launchFused(sih_ctx *c, int m)
 {
     sih_persist_state *s = c->persist;
-    const int nT = s->a.nTiles;
+    const int nT = s->fusedTiles;
     const PersistDev pd = makePersistDev(c->dev);
     const size_t ringBuf = (size_t)2 * M * c->padC;  // doubles in one buffer of the ring (U planes, then V planes)
     double *sums[2] = {(double *)s->a.part, (double *)s->a.part + ringBuf};
@@ -1092,7 +1195,7 @@ static void launchFused(sih_ctx *c, int m)
     f.tvVert = s->tvVert;
     f.tvOwned = s->tvOwned;
     f.tvQ = s->tvQ;
-    f.cornerSlot = s->a.cornerSlot;
+    f.cornerSlot = s->fusedSlot;
     f.nEntries = (size_t)nT * 64 * M;
     const dim3 grid((unsigned)nT), block(64, M);
     // Launch 1: cells of iteration 1.  Launch i = 2 .. m: vertices of iteration i-1, cells of iteration i.  Launch
@@ -1196,7 +1299,7 @@ static int exchangeSetup(sih_ctx *c)
                 cAddr.push_back((unsigned long long)(uintptr_t)t.peerBase[p] + 8ULL * (t.peerWordOff[p] + (size_t)t.sendPos[0][at]));
                 cHalf.push_back(t.peerHalfBytes[p]);
                 cCnt.push_back(cnt);
-                tileActive[cell / 64] = 1;
+                tileActive[cell / s->tileCells] = 1;
             }
         }
         at = 0;
@@ -1248,7 +1351,7 @@ static int exchangeSetup(sih_ctx *c)
                     rcBase[(size_t)g * P + cell] = (int)(t.myWordOff[p] + (size_t)2 * g * cnt + (size_t)t.recvPos[0][at]);
                     rcStride[(size_t)g * P + cell] = cnt;
                 }
-                tileActive[cell / 64] = 1;
+                tileActive[cell / s->tileCells] = 1;
             }
         }
         at = 0;
@@ -1311,7 +1414,16 @@ int sih_persist_launch_exchange(sih_ctx *c, int n, int interval)
         sih_set_error("persistent subcycle kernel: the exchange inside the kernel is not available for this block");
         return SIH_ERR_UNSUPPORTED;
     }
-    return launchAny(c, n, interval);
+    // a launch holds at most as many exchanges as a bank of the tagged words has copies (sih_internal.h): longer loops
+    // are split, each part but the last a whole number of intervals, so that the exchanges fall where they would
+    const int most = (SIH_TAGGED_COPIES / 2) * interval;
+    for (int done = 0; done < n;) {
+        const int m = std::min(most, n - done);
+        int rc = launchAny(c, m, interval);
+        if (rc) return rc;
+        done += m;
+    }
+    return SIH_OK;
 }
 
 // waits for the stream; SIH_ERR_STATE if a launch gave up (workgroups not resident together, or a wait ran out)
@@ -1326,7 +1438,9 @@ int sih_persist_status(sih_ctx *c)
         sih_set_error(st == 1   ? "persistent subcycle kernel: its workgroups were not resident together (is the GPU shared with other "
                                   "work? SIH_PERSISTENT=0 or sih_evp_set_persistent(ctx, 0) keeps the two-kernel form)"
                       : st == 2 ? "persistent subcycle kernel: a wait for a neighbouring tile ran out of time"
-                                : "persistent subcycle kernel: a neighbouring block's halo values did not arrive in time");
+                      : st == 3 ? "persistent subcycle kernel: a neighbouring block's halo values did not arrive in time"
+                                : "persistent subcycle kernel: halo values were overwritten before they were read (do all blocks make "
+                                  "the same sequence of calls?)");
         c->persist->usable = false;
         return SIH_ERR_STATE;
     }

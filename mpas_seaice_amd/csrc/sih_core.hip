@@ -1163,6 +1163,7 @@ extern "C" int sih_get_info(sih_ctx *c, const char *key, double *value)
     else if (k == "persistentArrived") *value = sih_persist_info(c, 3);
     else if (k == "persistentLaunches") *value = sih_persist_info(c, 4);
     else if (k == "persistentExchangeLaunches") *value = sih_persist_info(c, 5);
+    else if (k == "persistentTileCells") *value = sih_persist_info(c, 7);
     else if (k == "iterationForm") *value = c->lastForm;
     else if (k == "fusedKernel") *value = sih_fused_usable(c) ? 1.0 : 0.0;
     else if (k == "fusedLaunches") *value = sih_persist_info(c, 6);

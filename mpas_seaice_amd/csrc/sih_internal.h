@@ -157,12 +157,17 @@ bool sih_comm_ready(sih_ctx *c);
 // sends, planes of words [stress 0..2][corner][low / high word][place] and, behind them, for its vertices
 // [u, v][low / high word][place]; "place" is the entity's rank in the SENDER's own numbering among what it sends
 // to that neighbour, so that the lanes of a sending wave, which hold consecutive cells, write consecutive words.
-// The words exist SIH_TAGGED_COPIES times, used in turn (number of the exchange modulo the count).  Two would do
-// when a block can never be two exchanges ahead of the neighbour that still reads: that holds through the chain
-// "what I send in exchange e+2 depends on what you sent in e+1, which you computed after reading e", but the
-// chain runs from tile to tile inside the reading block and needs the halo to be thin against the exchange
-// interval; with four copies no such argument is needed for any interval >= 1.
-#define SIH_TAGGED_COPIES 4
+// The words exist SIH_TAGGED_COPIES times, in two banks: a launch of the persistent kernel writes exchange j of its
+// own (1-based, at most SIH_TAGGED_COPIES / 2 a launch: longer loops are split) into copy j - 1 of the bank of its
+// parity (launches with the exchange inside, counted from the set-up).  A copy is therefore written again two
+// launches later at the earliest, and by then every tile of the reading block has read it: the writer, in launch
+// L, has either received that block's words of launch L (exchange j >= 2) or finished its own launch L - 1, which
+// ended with an exchange in which it received that block's words of launch L - 1 (j = 1); in both cases the
+// reading block has started launch L - 1 at least, hence finished launch L - 2 as a whole.  (A first version used
+// four copies in turn, arguing from what a block can compute before its neighbour has read; but tiles of one
+// block may be several iterations apart, as many as there are tiles between them, and with an exchange after every
+// iteration a slow tile found its words overwritten: wrong halo values on one of the test partitions.)
+#define SIH_TAGGED_COPIES 32
 struct sih_comm_tagged {
     int generation = 0, nRanks = 0;
     char *myBase = nullptr;  // copy 0 of this block's region

@@ -33,6 +33,8 @@ def main():
     ora.set_num_threads(2)
     mesh = get_mesh(meshname)
     cfg = {"config_elastic_subcycle_number": 12, "config_dt": 7200.0}
+    if "long" in sys.argv[3:]:  # more exchanges in a step than one launch of the persistent kernel may hold
+        cfg["config_elastic_subcycle_number"] = 40
     if "overlap" in sys.argv[3:]:  # exchange hidden behind interior work; only the device path has it
         cfg["config_overlap_halo_exchange"] = True
     if "graph" in sys.argv[3:]:  # chunks of the subcycle loop (iterations + exchange) replayed from HIP graphs
@@ -105,7 +107,8 @@ def main():
             advection_upwind.seaice_run_advection_upwind(dom)
         ctx = dom.blocklist[0].ctx
         print(f"rank {rank} persistent kernel {int(ctx.info('persistentKernel'))} launches "
-              f"{int(ctx.info('persistentLaunches'))} with exchange {int(ctx.info('persistentExchangeLaunches'))}", flush=True)
+              f"{int(ctx.info('persistentLaunches'))} with exchange {int(ctx.info('persistentExchangeLaunches'))}"
+              f" tile cells {int(ctx.info('persistentTileCells'))}", flush=True)
         if peer:
             dom.comm.check(dom)
             dist.barrier()  # no rank unmaps its buffer while a neighbour may still write to it

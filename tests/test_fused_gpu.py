@@ -76,6 +76,7 @@ def test_fused_kernel_on_a_block_with_deep_halos():
 def test_whole_steps_choose_the_fused_kernel_for_a_block_too_large_to_be_resident(monkeypatch):
     """QU120 on one GPU (40 962 cells: 641 tiles, more than stay resident): sih_evp_run takes the fused kernel for
     all iterations but the last by itself, and the step gives the bits of the two-kernel form."""
+    monkeypatch.setenv("SIH_PERSIST_SMALL_TILES", "0")  # (with tiles of 42 cells QU120 just fits the persistent kernel)
     mesh = get_mesh("QU120")
     res = []
     for mode in (0, -1):

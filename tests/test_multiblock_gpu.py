@@ -118,6 +118,33 @@ def test_exchange_inside_the_kernel_changes_no_bit(tmp_path, extra):
             assert np.array_equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("mesh,ranks,extra", [("QU240", 2, ["p2p", "deep"]), ("QU240", 3, ["p2p"]), ("QU480", 4, ["p2p", "deep"]),
+                                              ("QU240", 3, ["p2p", "long"])])
+def test_exchange_inside_the_persistent_kernel_with_small_tiles(tmp_path, mesh, ranks, extra):
+    """The variant of the persistent kernel for blocks that tiles of 64 cells cannot hold (tiles of 42 cells, the
+    rows of the metric integrals streamed), forced here on small blocks by declaring room for a single tile of 64:
+    the exchange inside it against the exchange between the launches of the 64-cell form, every array of every
+    block, halo entries included, the same bits; and against the single-block oracle on every rank."""
+    res = []
+    for small in (False, True):
+        d = tmp_path / str(int(small))
+        d.mkdir()
+        env = {"SIH_TEST_DUMP": str(d), "SIH_PERSIST_EXCHANGE": "1" if small else "0"}
+        if small:
+            env.update(SIH_PERSIST_CAPACITY="1", SIH_PERSIST_CAPACITY_SMALL="1024")
+        out = _run_ranks(mesh, ranks, extra, env)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+        assert out.stdout.count(": ok") == ranks, out.stdout
+        assert out.stdout.count(f"tile cells {42 if small else 64}") == ranks, out.stdout
+        # 39 iterations with an exchange after each are three launches: a launch holds at most 16 exchanges
+        assert out.stdout.count(f"with exchange {int(small) * (3 if 'long' in extra else 1)} ") == ranks, out.stdout
+        res.append([np.load(d / f"rank{r}.npz") for r in range(ranks)])
+    for a, b in zip(*res):
+        assert np.abs(a["u"]).max() > 0
+        for k in a.files:
+            assert np.array_equal(a[k], b[k]), k
+
+
 def test_a_silent_neighbour_ends_the_kernel_with_the_exchange_inside():
     """Rank 1 agrees to exchange inside the kernel and then never launches: rank 0's launch must not hang.  Its
     waits are bounded (here 300 ms, and as much for the exchanges between launches that precede it in the step), every

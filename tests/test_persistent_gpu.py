@@ -103,3 +103,31 @@ def test_a_block_too_large_to_be_resident_keeps_the_two_kernel_form():
             b.ctx.subcycle_persistent(3)
     finally:
         vs.seaice_mesh_pool_destroy(dom)
+
+
+def test_small_tiles_hold_a_block_that_tiles_of_64_cells_cannot():
+    """QU120 (40 962 cells): 641 tiles of 64 cells are more than stay resident; 976 tiles of 42 cells, with the rows of
+    the metric integrals read from memory in every iteration instead of kept in LDS, fit four to a CU.  Same bits as
+    the two-kernel form, odd and even launches, interleaved with two-kernel iterations."""
+    mesh = get_mesh("QU120")
+    res = []
+    for persistent in (False, True):
+        dom, b = _prepared(mesh, "QU120", open_water_band=(-0.2, 0.3))
+        try:
+            if persistent:
+                assert b.ctx.info("persistentKernel") == 1.0, b.ctx.info("persistentReason")
+                assert b.ctx.info("persistentTileCells") == 42.0 and b.ctx.info("persistentTiles") == 976.0
+            for n in (7, 1, 12):
+                if persistent:
+                    b.ctx.subcycle_persistent(n)
+                else:
+                    b.ctx.subcycle(n, last=False)
+                b.ctx.subcycle(2, last=False)
+            b.ctx.sync()
+            res.append(_state(b))
+        finally:
+            vs.seaice_mesh_pool_destroy(dom)
+    assert np.abs(res[0]["uVelocity"]).max() > 1e-4
+    for k in res[0]:
+        assert np.isfinite(res[1][k]).all(), k
+        assert np.array_equal(res[0][k], res[1][k]), (k, np.abs(res[0][k] - res[1][k]).max())
