@@ -506,6 +506,7 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
     import torch.distributed as dist
 
     from . import velocity_solver as vs
+    interval_from_env = os.environ.get("SIH_HALO_INTERVAL") if interval is None else str(interval)
     if interval is None:
         # Measured on one GPU (scripts/bench_block.py, QU60, block of an 8-way partition): 14.3 / 14.6 / 14.8 /
         # 16.2 us per subcycle with 2 / 4 / 8 / 16 halo layers; an exchange costs the same two launches whatever
@@ -526,115 +527,156 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
         return float(t.item())
     rank, world = dist.get_rank(), dist.get_world_size()
     overlap = os.environ.get("SIH_OVERLAP", "0") != "0"
-    cfg = {"config_elastic_subcycle_number": nsub, "config_num_halos": max(2, interval),
-           "config_halo_exchange_interval": interval, "config_overlap_halo_exchange": overlap,
-           "config_subcycle_graph": use_graph}
-    dom, halo, _ = make_partitioned_domain(mesh, name, world, configs=cfg, only_block=rank, cell_owner=cell_owner)
-    vs.seaice_mesh_pool_create(dom, device=local_rank, renumber=renumber)
-    ctx = dom.blocklist[0].ctx
-    note = ""
-    if transport == "p2p":
-        ok = 1.0
-        try:
-            dom.comm = PeerComm(dom, halo, world, rank)
-        except Exception as e:  # noqa: BLE001 -- whatever fails, every rank must take the same branch
-            ok, note = 0.0, f"p2p set-up failed on rank {rank}: {e}"
-        if reduce_scalar(ok, dist.ReduceOp.MIN) < 1.0:
-            transport = "torch"
-        else:
-            bad = link_self_test(dom, halo, dom.comm)
-            try:
-                dom.comm.check(dom)
-            except Exception as e:  # noqa: BLE001
-                bad, note = bad + 1, str(e)
-            if reduce_scalar(float(bad), dist.ReduceOp.MAX) > 0.0:
-                transport, note = "torch", note or "p2p link check found wrong halo values"
-                dist.barrier()
-                ctx.comm_destroy()
-    if transport != "p2p":
-        dom.comm = DistComm(dom, halo, world, rank)  # also moves the block onto torch's (explicit) current stream
-    vs.seaice_init_velocity_solver(dom)
-    for b in dom.blocklist:
-        vs._upload(dom, b)
-    torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    vs.velocity_solver_pre_subcycle(dom)
-    torch.cuda.synchronize()
-    ctx.sync()
-    pre_ms = (time.perf_counter() - t0) * 1e3
-    names = ["uVelocity", "vVelocity"] if interval == 1 else ["uVelocity", "vVelocity", "stress11", "stress22",
-                                                               "stress12"]
+    state = {}
+
+    def sync():
+        torch.cuda.synchronize()
+        state["ctx"].sync()  # the block's own stream (the p2p transport does not run on torch's)
 
     def step():
-        if transport == "p2p":
-            ctx.subcycle_exchange(nsub, last=False, interval=interval, overlap=overlap, use_graph=use_graph)
+        ctx, dom, k = state["ctx"], state["dom"], state["interval"]
+        if state["transport"] == "p2p":
+            ctx.subcycle_exchange(nsub, last=False, interval=k, overlap=overlap, use_graph=use_graph)
             return
         if overlap:
-            vs.subcycle_overlapped(dom, dom.comm, nsub, interval, names, use_graph=use_graph)
+            vs.subcycle_overlapped(dom, dom.comm, nsub, k, state["names"], use_graph=use_graph)
             return
         done = 0
         while done < nsub:
-            m = min(interval, nsub - done)
-            if use_graph and m == interval:
+            m = min(k, nsub - done)
+            if use_graph and m == k:
                 ctx.subcycle_graph(m)
             else:
                 ctx.subcycle(m, last=False)
             done += m
-            dom.comm.halo_exchange(dom, names)
+            dom.comm.halo_exchange(dom, state["names"])
 
-    def sync():
+    def setup(k, transport):
+        """partition with k halo layers, block on the device, transport, pre-cycle; then the vote on the exchange
+        inside the kernel and its check on this machine's links"""
+        cfg = {"config_elastic_subcycle_number": nsub, "config_num_halos": max(2, k),
+               "config_halo_exchange_interval": k, "config_overlap_halo_exchange": overlap,
+               "config_subcycle_graph": use_graph}
+        dom, halo, _ = make_partitioned_domain(mesh, name, world, configs=cfg, only_block=rank, cell_owner=cell_owner)
+        vs.seaice_mesh_pool_create(dom, device=local_rank, renumber=renumber)
+        ctx = dom.blocklist[0].ctx
+        note = ""
+        if transport == "p2p":
+            ok = 1.0
+            try:
+                dom.comm = PeerComm(dom, halo, world, rank)
+            except Exception as e:  # noqa: BLE001 -- whatever fails, every rank must take the same branch
+                ok, note = 0.0, f"p2p set-up failed on rank {rank}: {e}"
+            if reduce_scalar(ok, dist.ReduceOp.MIN) < 1.0:
+                transport = "torch"
+            else:
+                bad = link_self_test(dom, halo, dom.comm)
+                try:
+                    dom.comm.check(dom)
+                except Exception as e:  # noqa: BLE001
+                    bad, note = bad + 1, str(e)
+                if reduce_scalar(float(bad), dist.ReduceOp.MAX) > 0.0:
+                    transport, note = "torch", note or "p2p link check found wrong halo values"
+                    dist.barrier()
+                    ctx.comm_destroy()
+        if transport != "p2p":
+            dom.comm = DistComm(dom, halo, world, rank)  # also moves the block onto torch's (explicit) current stream
+        vs.seaice_init_velocity_solver(dom)
+        for b in dom.blocklist:
+            vs._upload(dom, b)
         torch.cuda.synchronize()
-        ctx.sync()  # the block's own stream (the p2p transport does not run on torch's)
+        dist.barrier()
+        t0 = time.perf_counter()
+        vs.velocity_solver_pre_subcycle(dom)
+        torch.cuda.synchronize()
+        ctx.sync()
+        pre_ms = (time.perf_counter() - t0) * 1e3
+        names = ["uVelocity", "vVelocity"] if k == 1 else ["uVelocity", "vVelocity", "stress11", "stress22", "stress12"]
+        state.update(dom=dom, halo=halo, ctx=ctx, interval=k, transport=transport, note=note, pre_ms=pre_ms, names=names)
+        # Small blocks can run all iterations of a step as one launch with the exchanges inside it.  All ranks or
+        # none: they vote, and then check it on this machine's links -- one step each way from the same state must
+        # give the same bits on every rank -- before the timed loop relies on it.
+        inside, inside_note = False, ""
+        if transport == "p2p":
+            inside = dom.comm.agree_on_exchange_inside(dom)
+            if inside:
+                b0 = dom.blocklist[0]
+                nV1, nC1, M = b0.dimensions["nVertices"] + 1, b0.dimensions["nCells"] + 1, b0.dimensions["maxEdges"]
+                shapes = {n: ((nV1,) if n.endswith("Velocity") else (M, nC1)) for n in names}
 
-    # Small blocks can run all iterations of a step as one launch with the exchanges inside it.  All ranks or none:
-    # they vote, and then check it on this machine's links -- one step each way from the same state must give the
-    # same bits on every rank -- before the timed loop relies on it.
-    inside, inside_note = False, ""
-    if transport == "p2p":
-        inside = dom.comm.agree_on_exchange_inside(dom)
-        if inside:
-            b0 = dom.blocklist[0]
-            nV1, nC1, M = b0.dimensions["nVertices"] + 1, b0.dimensions["nCells"] + 1, b0.dimensions["maxEdges"]
-            shapes = {n: ((nV1,) if n.endswith("Velocity") else (M, nC1)) for n in names}
+                def grab():
+                    out = {}
+                    for n, sh in shapes.items():
+                        out[n] = np.zeros(sh, order="F")
+                        ctx.get(n, out[n])
+                    return out
 
-            def grab():
-                out = {}
-                for n, sh in shapes.items():
-                    out[n] = np.zeros(sh, order="F")
-                    ctx.get(n, out[n])
-                return out
-
-            def put_back(st):
-                for n, a in st.items():
-                    ctx.put(n, a)
-            start = grab()
-            res, bad = [], 0.0
-            for mode in (1, 2):
+                def put_back(st):
+                    for n, a in st.items():
+                        ctx.put(n, a)
+                start = grab()
+                res, bad = [], 0.0
+                for mode in (1, 2):
+                    put_back(start)
+                    ctx.set_persistent(mode)
+                    sync()
+                    dist.barrier()
+                    try:
+                        step()
+                        sync()
+                        dom.comm.check(dom)
+                        res.append(grab())
+                    except Exception as e:  # noqa: BLE001 -- every rank must reach the vote below
+                        bad, inside_note = 1.0, f"rank {rank}, mode {mode}: {e}"  # (no way out of the loop: its barriers)
+                if not bad and any(not np.array_equal(res[0][n], res[1][n]) for n in names):
+                    bad, inside_note = 1.0, f"rank {rank}: the exchange inside the kernel changed the results"
+                inside = reduce_scalar(bad, dist.ReduceOp.MAX) == 0.0
+                ctx.set_persistent(2 if inside else 1)
                 put_back(start)
-                ctx.set_persistent(mode)
                 sync()
                 dist.barrier()
-                if mode == 1:  # the form every rank can run: a failure here is a failure of the run
-                    step()
-                    sync()
-                    dom.comm.check(dom)
-                    res.append(grab())
-                    continue
-                try:
-                    step()
-                    sync()
-                    dom.comm.check(dom)
-                    res.append(grab())
-                except Exception as e:  # noqa: BLE001 -- every rank must reach the vote below
-                    bad, inside_note = 1.0, f"rank {rank}: {e}"
-            if not bad and any(not np.array_equal(res[0][n], res[1][n]) for n in names):
-                bad, inside_note = 1.0, f"rank {rank}: the exchange inside the kernel changed the results"
-            inside = reduce_scalar(bad, dist.ReduceOp.MAX) == 0.0
-            ctx.set_persistent(2 if inside else 1)
-            put_back(start)
-            sync()
-            dist.barrier()
+        state.update(inside=inside, inside_note=inside_note)
+
+    def teardown():
+        dom = state["dom"]
+        # what is torn down may be a trial that failed (a launch that gave up, a message that never came): its errors
+        # have been counted in the vote, and every rank must reach the barriers below
+        for wait in (sync, (lambda: dom.comm.check(dom)) if state["transport"] == "p2p" else sync):
+            try:
+                wait()
+            except Exception:  # noqa: BLE001
+                pass
+        dist.barrier()
+        vs.seaice_mesh_pool_destroy(dom)
+        dist.barrier()
+
+    # The halo depth: 8 layers, one exchange per 8 iterations, unless a thinner halo lets every block stay resident in
+    # the persistent kernel with the exchanges inside it (QU60 on 4 GPUs: 46.8 k cells with 8 layers, 42.4 k with 2,
+    # against room for 43 008) -- tried first where the sizes say so, kept only if every rank confirms it.
+    first = interval
+    if interval_from_env is None and transport == "p2p" and int(mesh.maxEdges) == 6 \
+            and os.environ.get("SIH_PERSISTENT", "1") != "0" and os.environ.get("SIH_PERSIST_EXCHANGE", "1") != "0":
+        room = 4 * 42 * torch.cuda.get_device_properties(local_rank).multi_processor_count
+        room = int(os.environ.get("SIH_BENCH_ROOM_CELLS", room))  # (rehearsals of this choice on small meshes)
+
+        def largest_block(k):
+            _, halos = partition_mesh(mesh, world, num_halos=max(2, k), cell_owner=cell_owner)
+            return max(len(h.globalID["cell"]) for h in halos)
+        if largest_block(interval) > room:
+            for k in (4, 2):
+                if k < interval and largest_block(k) <= room:
+                    first = k
+                    break
+    setup(first, transport)
+    if first != interval and not state["inside"]:
+        thin_note = (f"{first} halo layers tried for the persistent kernel: " +
+                     (state["inside_note"] or "not every block could stay resident"))
+        teardown()
+        setup(interval, transport)
+        state["note"] = (state["note"] + "; " if state["note"] else "") + thin_note
+    dom, halo, ctx = state["dom"], state["halo"], state["ctx"]
+    transport, note, pre_ms, names = state["transport"], state["note"], state["pre_ms"], state["names"]
+    interval, inside, inside_note = state["interval"], state["inside"], state["inside_note"]
     for _ in range(warmup):
         step()
     sync()
