@@ -264,8 +264,10 @@ int sih_evp_subcycle_graph(sih_ctx *ctx, int n);
  * vertices of those cells on the chip for all iterations (basis gradients, stresses and vertex constants in
  * registers, integral rows and velocities in LDS); only the per-corner sums of the stress divergence pass through
  * memory, and a vertex waits only for the sums it reads.  For blocks small enough to be resident at once (two
- * workgroups a CU: 32 768 cells on 256 CUs; sih_get_info "persistentKernel" = 1), where the two-kernel form is
- * bound by its kernel boundaries and by re-reading tables that never change.  Same bits as sih_evp_subcycle.
+ * workgroups a CU: 32 768 cells on 256 CUs; with maxEdges 6 also tiles of 42 cells, four workgroups a CU, the rows
+ * of the metric integrals read from memory in every iteration: 43 008 cells; sih_get_info "persistentKernel" = 1,
+ * "persistentTileCells"), where the two-kernel form is bound by its kernel boundaries and by re-reading tables that
+ * never change.  Same bits as sih_evp_subcycle.
  * sih_evp_subcycle_graph, sih_evp_run and sih_evp_subcycle_exchange use it by themselves for loops of two or more
  * iterations where a block qualifies and its context is the only one of the process on the device (the launches
  * of other blocks would take the places of its workgroups); the environment variable SIH_PERSISTENT=0 switches that off;
@@ -502,7 +504,7 @@ int sih_upwind_get_sums(sih_ctx *ctx, const char *tracer, double *initSums, doub
 
 /* introspection for tests and reports.  Keys: sparseGradient, splitCellKernel, persistentKernel (and persistentPerCU,
  * persistentTiles, persistentReason, persistentArrived, persistentLaunches, persistentExchangeLaunches,
- * persistentExchangeReady (see sih_evp_set_persistent), fusedKernel and fusedLaunches (sih_evp_subcycle_fused), iterationForm (what the last loop of iterations ran as: 0 two
+ * persistentExchangeReady (see sih_evp_set_persistent), fusedKernel and fusedLaunches (sih_evp_subcycle_fused), persistentTileCells, iterationForm (what the last loop of iterations ran as: 0 two
  * kernels an iteration, 1 the persistent kernel, 2 the fused kernel): workgroups of
  * the persistent subcycle kernel a CU holds, its tiles, why the block does not qualify (1 option, 2 too many tiles,
  * 3 too many vertices in a tile, 5 not resident together in the trial launch), workgroups that arrived in a failed

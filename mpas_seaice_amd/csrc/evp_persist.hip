@@ -65,7 +65,8 @@ struct PersistArgs {
 // launch without exchange pays nothing for it).  Velocities and stresses travel as in the exchange between launches
 // (uVelocity, vVelocity, stress11/22/12 of every list entry), but each value is two 8-byte words
 // {low 32 bits | tag << 32}, {high 32 bits | tag << 32} with tag = number of the exchange: a word is there when its
-// tag is, no flag and no fence.  The words exist in four copies used in turn (tag modulo 4).  They are laid out in planes ordered by
+// tag is, no flag and no fence.  The words exist in two banks of copies (sih_internal.h: a launch writes exchange j of
+// its own into copy j - 1 of the bank of its parity).  They are laid out in planes ordered by
 // the sender's own numbering, so that a sending wave, whose lanes hold consecutive cells, writes consecutive words
 // (whole lines on the link, not one 8-byte packet a value).  A thread sends what its own corner
 // (or the vertex it stores at the end) holds, straight from its registers into the neighbour's memory, and goes

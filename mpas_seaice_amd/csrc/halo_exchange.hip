@@ -44,8 +44,8 @@ struct sih_comm_blob {
     hipIpcMemHandle_t mem;
     unsigned long long slotOff[SIH_COMM_MAXR];  // byte offset inside one half of the slot for messages from rank p
     unsigned long long slotCap[SIH_COMM_MAXR];  // its capacity in bytes
-    // the tagged region (velocities and stresses exchanged from inside the persistent subcycle kernel): four copies
-    // (used in turn, by the number of the exchange) of 8-byte words behind the plain halves, then the set-up words (one per received cell and vertex, written
+    // the tagged region (velocities and stresses exchanged from inside the persistent subcycle kernel):
+    // SIH_TAGGED_COPIES copies (two banks, see sih_internal.h) of 8-byte words behind the plain halves, then the set-up words (one per received cell and vertex, written
     // once by the sender: its own index of that entity, from which both sides derive the order of the words).
     // Per rank p: cells and vertices received from it, first word of its segment in a half, first set-up word.
     unsigned long long taggedOff, taggedHalfBytes, setupOff;
