@@ -13,4 +13,6 @@ timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_wri
 echo write done
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/block8 -o b -- python3 scripts/bench_block.py --blocks 8 --interval 8 --chunks 50 > $O/block8.log 2>&1
 echo block8 done
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/qu120 -o b -- python3 scripts/bench_block.py --mesh QU120 --blocks 1 --block 0 --interval 8 --chunks 50 > $O/qu120.log 2>&1
+echo qu120 done
 find $O -name "*.csv" | xargs ls -la
