@@ -50,6 +50,7 @@
 enum { PS_EPOCH = 0, PS_LAUNCHES = 1, PS_STATUS = 2, PS_TICKS = 3, PS_XSEQ = 4, PS_XTICKS = 5, PS_XLAUNCHES = 6, PS_CENSUS = 16, PS_CENSUS_N = 32, PS_CENSUS_STRIDE = 16,
        PS_WORDS = PS_CENSUS + PS_CENSUS_N * PS_CENSUS_STRIDE };
 #define PS_RING 4  // buffers of the partial sums, used in turn
+
 #define PS_MARKER 0xFFF8C0DEDEADBEEFULL  // "not written yet": a NaN with a payload no operation produces
 
 struct PersistArgs {
@@ -354,6 +355,11 @@ __global__ void __launch_bounds__(TC * M, 4) k_sub_persistent(PersistDev d, Pers
     const double dtE = d.dtE, T = d.dampT, brlx = d.brlx, dtD = d.dtDyn;
     const int relation = d.relation;
     int sl = (int)(epoch % PS_RING);  // buffer of the iteration before the one at hand
+    // The pause between two looks at the partial sums, in units of 512 clocks: the more tiles poll, the more their
+    // loads stand in the way of the stores they wait for.  Measured per iteration with pauses of 64 / 512 / 1024 /
+    // 2048 / 4096 clocks: 221 tiles 4.70 / 4.67 / 4.75 / 5.05 / 5.77 us, 392 tiles 7.39 / 6.99 / 6.85 / 6.87 / 6.73,
+    // 976 small tiles 10.84 / 10.22 / 9.89 / 9.45 / 9.22.
+    const int napReps = nT <= 256 ? 1 : nT <= 512 ? 2 : 6;
 
     for (int it = 1; it <= nIter && alive; it++) {
         sl = (sl + 1) % PS_RING;
@@ -473,7 +479,8 @@ __global__ void __launch_bounds__(TC * M, 4) k_sub_persistent(PersistDev d, Pers
                         break;
                     }
                 }
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(8);
+                for (int nap = 1; nap < napReps; nap++) __builtin_amdgcn_s_sleep(8);
             }
         }
         if (solV) {
