@@ -1260,9 +1260,21 @@ static int persistentMode(sih_ctx *c)
     return c->persistMode >= 0 ? c->persistMode : fromEnv;
 }
 
+static bool fusedAllowed()
+{
+    static const bool on = [] {
+        const char *e = getenv("SIH_FUSED");
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
+
 static bool usePersistent(sih_ctx *c, int iterations)
 {
-    return persistentMode(c) >= 1 && iterations >= 2 && sih_persist_usable(c) && sih_live_contexts(c->device) == 1;
+    // a launch costs 14 to 25 us before its first iteration (396 to 1 010 workgroups check in): against the two-kernel
+    // form that is won back with the second iteration, against the fused kernel with the fourth
+    const int least = (fusedAllowed() && sih_fused_usable(c)) ? 4 : 2;
+    return persistentMode(c) >= 1 && iterations >= least && sih_persist_usable(c) && sih_live_contexts(c->device) == 1;
 }
 
 // Where the persistent kernel does not apply (block too large to be resident, or not alone on its device), loops of
