@@ -15,6 +15,11 @@
 // the same bits.  Iterations that store the end-of-step diagnostics (the last one of a dynamics step) stay with
 // the two-kernel form.
 //
+// Three forms share the tiles: the persistent kernel with tiles of 64 cells (all integral rows in LDS, two workgroups
+// a CU: 32 768 cells on 256 CUs), the same kernel with tiles of 42 cells and the rows of the metric integrals read
+// from memory in every iteration (four workgroups a CU: 43 008 cells), and, for blocks that cannot stay resident or
+// are not alone on their device, k_sub_fused: one launch per iteration, nothing resident, nothing waits (below).
+//
 // Hand-off rules (per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed):
 //   - the sums live in four buffers used in turn (iteration number modulo 4).  In iteration t a corner drains its
 //     earlier stores (s_waitcnt vmcnt(0)), stores its sums of iteration t into buffer t and then a marker (a NaN bit
@@ -1291,6 +1296,11 @@ static int exchangeSetup(sih_ctx *c)
                 ownerTile[s->hVerts[j]] = tl;
                 ownerPos[s->hVerts[j]] = j - s->hVStart[tl];
             }
+    // The two banks of the tagged words are safe to reuse because whoever writes to a neighbour also waits for words
+    // of that neighbour in every exchange (sih_internal.h): a block that would send to one it receives no vertex
+    // from keeps the exchange between launches.
+    for (int p = 0; p < nR; p++)
+        if (c->hSendCounts[0][p] + c->hSendCounts[1][p] > 0 && c->hRecvCounts[1][p] == 0) return SIH_OK;
     // ---- what every cell and every stored vertex sends
     std::vector<int> tileActive(nT, 0);
     std::vector<std::vector<int>> cellDest(nC), vertDest(s->hVerts.size());  // indices into the flat entry arrays
