@@ -280,7 +280,7 @@ int sih_evp_subcycle_persistent(sih_ctx *ctx, int n);
  * of iteration t - 1, then the cells of iteration t" (velocity_solver.F:2478-2592 cut between the stress divergence's
  * inner and outer sums instead of after the velocity solve), the first launch the cells only, the last the vertices
  * only.  For blocks too large to stay resident in the persistent kernel, or not alone on their device: half the
- * launches of the two-kernel form and two dependent memory round trips a launch instead of four or five.  Same
+ * launches of the two-kernel form and a shorter chain of dependent memory accesses in each.  Same
  * bits as sih_evp_subcycle; nothing waits inside a launch, so it has no residency condition and no time limit.
  * sih_evp_subcycle_graph, sih_evp_run and sih_evp_subcycle_exchange (between its exchanges, without overlap) choose
  * it by themselves where the persistent kernel does not apply and the block has at most SIH_FUSED_MAX_CELLS cells

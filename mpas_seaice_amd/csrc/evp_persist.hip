@@ -672,9 +672,10 @@ __global__ void __launch_bounds__(TC * M, 4) k_sub_persistent(PersistDev d, Pers
 // and the same statements, but a launch is "vertices of iteration t-1, then cells of iteration t" -- the boundary
 // between two launches is the hand-off of the partial sums, so nothing waits and nothing needs to be resident.  A
 // loop of m iterations is m + 1 launches (cells only; m - 1 of both; vertices only) instead of 2 m, and the
-// dependent chain of a launch is two memory round trips (tables, then operands) instead of the four or five of
-// the cell kernel followed by the vertex kernel: a tile's vertices, the places of their sums and whether it stores
-// them come from tables laid out per tile, and the velocities and tan(lat) reach the corners through LDS.
+// dependent chain of a launch is three memory round trips (tables; operands of the vertices; operands of the cells)
+// instead of the four or five of the cell kernel followed by the vertex kernel: a tile's vertices, the places of
+// their sums and whether it stores them come from tables laid out per tile, and the velocities and tan(lat) reach
+// the corners through LDS.
 // The velocities alternate between two arrays (a tile reads those of all its vertices while the tile that owns a
 // vertex stores the new one), the partial sums between two buffers of the ring.
 struct FusedArgs {
