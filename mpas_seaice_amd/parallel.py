@@ -493,6 +493,21 @@ def link_self_test(dom, halo, comm, rounds=3):
     return bad
 
 
+def thinner_halo_that_fits(mesh, nblocks, interval, room_cells, cell_owner=None, candidates=(4, 2)):
+    """The halo depth to try first: `interval` if the largest block of the partition fits `room_cells` with it (or
+    with no candidate either), else the deepest candidate below it with which every block fits.  Every rank computes
+    the same answer from the same partition."""
+    def largest_block(k):
+        _, halos = partition_mesh(mesh, nblocks, num_halos=max(2, k), cell_owner=cell_owner)
+        return max(len(h.globalID["cell"]) for h in halos)
+    if largest_block(interval) <= room_cells:
+        return interval
+    for k in candidates:
+        if k < interval and largest_block(k) <= room_cells:
+            return k
+    return interval
+
+
 def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, interval=None, cell_owner=None):
     """One block per rank: K steps of nsub subcycles; halos are `interval` layers deep and are exchanged every
     `interval` subcycles (uVelocity, vVelocity, stress11/22/12).  Transport (SIH_TRANSPORT): "p2p", the library's
@@ -658,15 +673,7 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
             and os.environ.get("SIH_PERSISTENT", "1") != "0" and os.environ.get("SIH_PERSIST_EXCHANGE", "1") != "0":
         room = 4 * 42 * torch.cuda.get_device_properties(local_rank).multi_processor_count
         room = int(os.environ.get("SIH_BENCH_ROOM_CELLS", room))  # (rehearsals of this choice on small meshes)
-
-        def largest_block(k):
-            _, halos = partition_mesh(mesh, world, num_halos=max(2, k), cell_owner=cell_owner)
-            return max(len(h.globalID["cell"]) for h in halos)
-        if largest_block(interval) > room:
-            for k in (4, 2):
-                if k < interval and largest_block(k) <= room:
-                    first = k
-                    break
+        first = thinner_halo_that_fits(mesh, world, interval, room, cell_owner=cell_owner)
     setup(first, transport)
     if first != interval and not state["inside"]:
         thin_note = (f"{first} halo layers tried for the persistent kernel: " +

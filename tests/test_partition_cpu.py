@@ -75,3 +75,19 @@ def test_two_process_gloo_halo_exchange(extra):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.count(": ok") == 2, out.stdout
+
+
+def test_the_benchmark_tries_a_thinner_halo_only_where_it_makes_the_blocks_fit():
+    """bench.py on N GPUs: 8 halo layers unless the blocks are then too large for the persistent kernel and fewer
+    layers make all of them fit (QU60 on 4 GPUs on the real thing; QU240 here with the room declared accordingly)"""
+    mesh = get_mesh("QU240")
+    sizes = {}
+    for k in (8, 4, 2):
+        _, halos = partition.partition_mesh(mesh, 4, num_halos=k)
+        sizes[k] = max(len(h.globalID["cell"]) for h in halos)
+    assert sizes[8] > sizes[4] > sizes[2]
+    assert parallel.thinner_halo_that_fits(mesh, 4, 8, sizes[8]) == 8          # fits as it is
+    assert parallel.thinner_halo_that_fits(mesh, 4, 8, sizes[8] - 1) == 4      # the deepest halo that fits
+    assert parallel.thinner_halo_that_fits(mesh, 4, 8, sizes[4] - 1) == 2
+    assert parallel.thinner_halo_that_fits(mesh, 4, 8, sizes[2] - 1) == 8      # nothing fits: no change
+    assert parallel.thinner_halo_that_fits(mesh, 4, 2, sizes[2] - 1) == 2      # nothing below the asked depth
