@@ -162,6 +162,94 @@ def advection_timing(dom, mesh, name, reps=7, with_cpu=True):
     return out
 
 
+def _free_port():
+    import socket
+    s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv, extra_env=None, limit_s=None):
+    """`python bench.py --gpus N` without a launcher: starts N fresh rank processes of this file (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run sets them) and waits for them.  The parent never
+    imports torch and never touches a GPU.  Rank 0's standard output (the one JSON line) is passed through as it is;
+    the other ranks' standard output goes to standard error.  Returns (exit code, lines rank 0 printed, codes of all
+    ranks).  A rank that ends with an error ends the others: they are given 20 s to leave by themselves (every wait of
+    the library is bounded and every collective has a time limit), then terminated by PID."""
+    import subprocess
+    import threading
+    env = dict(os.environ)
+    env.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                "MASTER_PORT": str(_free_port()), "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                "SIH_BENCH_SELF_LAUNCHED": "1"})
+    env.update(extra_env or {})
+    if limit_s is None:
+        limit_s = float(os.environ.get("SIH_BENCH_RANK_LIMIT_S", "1100"))
+    procs, lines0 = [], []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1))
+
+    def relay(p, r):
+        for line in p.stdout:
+            if r == 0:
+                lines0.append(line)
+                sys.stdout.write(line)
+                sys.stdout.flush()
+            else:
+                sys.stderr.write(f"[rank {r}] {line}")
+    threads = [threading.Thread(target=relay, args=(p, r), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+    t0, first_bad = time.time(), None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        codes = [p.poll() for p in procs]
+        if first_bad is None and any(c not in (None, 0) for c in codes):
+            first_bad = time.time()
+        over = time.time() - t0 > limit_s
+        if over or (first_bad is not None and time.time() - first_bad > 20.0):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            time.sleep(5.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            if over:
+                sys.stderr.write(f"bench.py: ranks still running after {limit_s:.0f} s were ended\n")
+    for t in threads:
+        t.join(timeout=5.0)
+    codes = [p.wait() for p in procs]
+    rc = 0
+    for c in codes:
+        if c != 0:
+            rc = c if c > 0 else 128 - c
+            break
+    return rc, lines0, codes
+
+
+def self_launch(args, argv):
+    """The parent of a plain `python bench.py --gpus N`.  One retry, and only after a clean failure: if a rank raised a
+    Python error (exit code 1: a bounded wait of the library's own transport ran out, a check of its results failed)
+    and no rank was ended by a signal or an abort, the run is started once more with the conservative settings --
+    halo messages as torch.distributed all_to_all_single over RCCL, no persistent kernel -- and the line says so."""
+    rc, lines, codes = launch_ranks(args.gpus, argv)
+    if rc == 0 or os.environ.get("SIH_BENCH_NO_RETRY", "0") != "0":
+        return rc
+    clean = all(c in (0, 1) or c == -15 for c in codes) and any(c == 1 for c in codes)
+    if not clean or os.environ.get("SIH_TRANSPORT", "p2p") == "torch" or any(l.lstrip().startswith("{") for l in lines):
+        return rc
+    sys.stderr.write(f"bench.py: the ranks ended with codes {codes}; once more with SIH_TRANSPORT=torch SIH_PERSISTENT=0\n")
+    rc2, _, _ = launch_ranks(args.gpus, argv, extra_env={
+        "SIH_TRANSPORT": "torch", "SIH_PERSISTENT": "0",
+        "SIH_BENCH_RETRY_NOTE": f"second launch: the first one (the library's own transport) ended with exit codes {codes}"})
+    return rc2
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,6 +267,10 @@ def main():
     ap.add_argument("--no-hbm-only", action="store_true", help="skip the QU30 pass (HBM-only rate of the cell kernel)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a plain `python bench.py --gpus N`: this process only starts the ranks and passes on rank 0's line
+        sys.exit(self_launch(args, sys.argv[1:]))
+
     import torch
     from mpas_seaice_amd import cases, mesh as meshmod, velocity_solver as vs
 
@@ -189,9 +281,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the solver has no CPU path")
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    n_dev = max(torch.cuda.device_count(), 1)
+    if world > n_dev:
+        # more ranks than GPUs (a rehearsal on a box with one GPU): the ranks share devices, which RCCL refuses, so
+        # the rendezvous and the scalar reductions go over gloo; the halo messages still travel inside the library
+        os.environ.setdefault("SIH_DIST_BACKEND", "gloo")
     cell_owner = None
     mesh_label = os.path.basename(args.mesh)
     if args.mesh.endswith(".nc"):
@@ -343,6 +437,10 @@ def main():
             "traffic_source": "equivalent rate: the bytes of one iteration of the two-kernel form (cells and vertices) over "
                               "the time an iteration took" + (" (its tables never leave the chip)" if single_form == 1 else "")})
     if world > 1:
+        out["world"] = {"ranks_at_rendezvous": res["world"], "backend": res["rendezvous_backend"],
+                        "devices_visible_per_rank": n_dev, "ranks": res["ranks"],
+                        "launcher": "bench.py itself" if os.environ.get("SIH_BENCH_SELF_LAUNCHED") else "external",
+                        "note": os.environ.get("SIH_BENCH_RETRY_NOTE") or None}
         out["exchange"] = {"transport": res["transport"], "rendezvous_backend": res["rendezvous_backend"],
                            "us_per_exchange_in_a_chain_of_50": res["exchange_us"], "block_cells_with_halo": block_cells,
                            "inside_the_subcycle_kernel": res["exchange_inside_kernel"],

@@ -906,6 +906,15 @@ void sih_persist_destroy(sih_ctx *c)
 {
     sih_persist_state *s = c->persist;
     if (!s) return;
+    if (s->a.state && hipSetDevice(c->device) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess) {
+        unsigned long long w[8];
+        if (hipMemcpy(w, s->a.state, sizeof w, hipMemcpyDeviceToHost) == hipSuccess) {
+            c->persistCarry[0] = w[PS_EPOCH];
+            c->persistCarry[1] = w[PS_LAUNCHES];
+            c->persistCarry[2] = w[PS_XSEQ];
+            c->persistCarry[3] = w[PS_XLAUNCHES];
+        }
+    }
     for (void *q : s->allocs) (void)hipFree(q);
     for (void *q : s->xAllocs) (void)hipFree(q);
     delete s;
@@ -1111,6 +1120,15 @@ int sih_persist_setup(sih_ctx *c)
     s->allocs.push_back(q);
     HIPCHK(hipMemset(q, 0, sizeof(unsigned long long) * PS_WORDS));
     a.state = (unsigned long long *)q;
+    {
+        // go on counting where the tables this call replaces had come to (see persistCarry)
+        unsigned long long w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        w[PS_EPOCH] = c->persistCarry[0];
+        // (not PS_LAUNCHES: the census counters, which start at zero again with these tables, are counted against it)
+        w[PS_XSEQ] = c->persistCarry[2];
+        w[PS_XLAUNCHES] = c->persistCarry[3];
+        HIPCHK(hipMemcpy(a.state, w, sizeof w, hipMemcpyHostToDevice));
+    }
     unsigned long long ticks = 2ULL * 100000000ULL;  // 2 s of the 100 MHz wall clock
     if (const char *e = getenv("SIH_PERSIST_TIMEOUT_MS")) ticks = (unsigned long long)(atof(e) * 100000.0);
     HIPCHK(hipMemcpy(a.state + PS_TICKS, &ticks, sizeof ticks, hipMemcpyHostToDevice));

@@ -616,7 +616,9 @@ extern "C" int sih_comm_status(sih_ctx *c)
         sih_set_error(buf);
         return SIH_ERR_COMM;
     }
-    return SIH_OK;
+    // the exchange inside the persistent subcycle kernel keeps its own status word: a launch that gave up (a
+    // neighbour's words late or overwritten) is an error of the transport as well
+    return sih_persist_status(c);
 }
 
 extern "C" int sih_comm_destroy(sih_ctx *c)

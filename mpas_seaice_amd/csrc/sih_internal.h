@@ -73,6 +73,10 @@ struct sih_ctx {
     struct sih_weak_state *weak = nullptr;                   // weak strain / stress-divergence scheme
     struct sih_upwind_state *upwind = nullptr;               // upwind advection state
     struct sih_persist_state *persist = nullptr;             // persistent subcycle kernel (small blocks)
+    // iterations, launches, exchanges and launches-with-exchange the persistent kernel has counted on the device so
+    // far: kept across a rebuild of its tables (sih_evp_init again, sih_evp_static_changed), because the tags and the
+    // bank parity of the words in the transport's receive region go on counting from them
+    unsigned long long persistCarry[4] = {0, 0, 0, 0};
     struct sih_comm_state *comm = nullptr;                   // halo exchange with blocks of other processes / devices
     std::map<std::string, SihField> fields;
     std::vector<void *> allocs;

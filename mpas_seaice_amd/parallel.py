@@ -543,6 +543,12 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
     rank, world = dist.get_rank(), dist.get_world_size()
     overlap = os.environ.get("SIH_OVERLAP", "0") != "0"
     state = {}
+    # which rank sits on which device, as the ranks themselves see it
+    props = torch.cuda.get_device_properties(local_rank)
+    mine = {"rank": rank, "device": int(local_rank), "name": props.name, "uuid": str(getattr(props, "uuid", "")),
+            "pid": os.getpid()}
+    rank_table = [None] * world
+    dist.all_gather_object(rank_table, mine)
 
     def sync():
         torch.cuda.synchronize()
@@ -579,17 +585,20 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
         if transport == "p2p":
             ok = 1.0
             try:
+                if os.environ.get("SIH_TEST_REFUSE_P2P"):  # tests of the fall-back below
+                    raise RuntimeError("refused by SIH_TEST_REFUSE_P2P")
                 dom.comm = PeerComm(dom, halo, world, rank)
             except Exception as e:  # noqa: BLE001 -- whatever fails, every rank must take the same branch
                 ok, note = 0.0, f"p2p set-up failed on rank {rank}: {e}"
             if reduce_scalar(ok, dist.ReduceOp.MIN) < 1.0:
                 transport = "torch"
             else:
-                bad = link_self_test(dom, halo, dom.comm)
-                try:
+                bad = 0
+                try:  # a message that never arrives ends a bounded wait with an error: that, too, is a failed check
+                    bad = link_self_test(dom, halo, dom.comm)
                     dom.comm.check(dom)
                 except Exception as e:  # noqa: BLE001
-                    bad, note = bad + 1, str(e)
+                    bad, note = bad + 1, f"rank {rank}: {e}"
                 if reduce_scalar(float(bad), dist.ReduceOp.MAX) > 0.0:
                     transport, note = "torch", note or "p2p link check found wrong halo values"
                     dist.barrier()
@@ -747,5 +756,6 @@ def bench_multi_gpu(mesh, name, nsub, steps, warmup, local_rank, renumber=True, 
             "overlap": overlap, "graph": bool(use_graph), "transport": transport, "transport_text": how,
             "transport_note": note, "exchange_us": ex_us, "rendezvous_backend": real_backend,
             "exchange_inside_kernel": bool(inside), "exchange_inside_note": inside_note,
+            "world": int(world), "ranks": rank_table,
             "persistent_kernel": bool(persistent_launches > 0 or (form_same and form_all == 1.0)),
             "fused_kernel": bool(form_same and form_all == 2.0)}

@@ -46,6 +46,9 @@ def main():
     ora.seaice_init_velocity_solver(ref)
     ira.seaice_init_advection(ref)
     ora.seaice_run_velocity_solver(ref)
+    reinit = "reinit" in sys.argv[3:]  # two velocity-solver steps, the device's tables rebuilt between them
+    if reinit:
+        ora.seaice_run_velocity_solver(ref)
     ira.seaice_run_advection(ref)
     upwind = "upwind" in sys.argv[3:]  # one more step with the upwind advection, surface temperature in kelvin
     if upwind:
@@ -76,6 +79,30 @@ def main():
         from mpas_seaice_amd import advection as adv
         vs.seaice_init_velocity_solver(dom)
         adv.seaice_init_advection(dom)
+        if "statusonly" in sys.argv[3:]:
+            # The way the Fortran shim drives a step on several ranks: pre-cycle with its exchanges between launches
+            # (both ranks take part), then the subcycle loop with the exchange inside the kernel, then the transport's
+            # status -- and nothing else that waits for the stream.  Rank 1 never starts its loop: rank 0's launch gives
+            # up within its time limit, and the status call alone must say so.
+            from mpas_seaice_amd import lib as sihlib
+            agreed = dom.comm.agree_on_exchange_inside(dom)
+            for b in dom.blocklist:
+                vs._upload(dom, b)
+            vs.velocity_solver_pre_subcycle(dom)
+            dom.comm.check(dom)
+            dist.barrier()
+            if rank == 0:
+                ctx0 = dom.blocklist[0].ctx
+                ctx0.subcycle_exchange(12, last=False, interval=3, overlap=False, use_graph=False)
+                try:
+                    dom.comm.check(dom)
+                    print(f"rank 0: no error from the status call (agreed {agreed})", flush=True)
+                except sihlib.SeaiceHipError as e:
+                    print(f"rank 0 status call reported: {e}", flush=True)
+            dist.barrier()
+            vs.seaice_mesh_pool_destroy(dom)
+            dist.destroy_process_group()
+            return
         if "silent" in sys.argv[3:]:
             # rank 1 never runs its dynamics: rank 0's kernel must give up within its time limit, end normally and
             # leave an error for the host (the time limit comes from SIH_PERSIST_TIMEOUT_MS)
@@ -95,6 +122,11 @@ def main():
             dist.destroy_process_group()
             return
         vs.seaice_run_velocity_solver(dom)
+        if reinit:
+            # every rank rebuilds the persistent kernel's tables after the first step's exchanges: the tags and the
+            # bank parity of the words in the receive regions must go on from where they were
+            dom.blocklist[0].ctx.static_changed()
+            vs.seaice_run_velocity_solver(dom)
         if os.environ.get("SIH_TEST_DUMP"):
             sv, vv = dom.blocklist[0].structs["velocity_solver"], dom.blocklist[0].structs["velocity_variational"]
             np.savez(os.path.join(os.environ["SIH_TEST_DUMP"], f"rank{rank}.npz"), u=sv["uVelocity"], v=sv["vVelocity"],

@@ -98,7 +98,7 @@ def _run_ranks(mesh, ranks, extra, env_extra, timeout=400):
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
 
 
-@pytest.mark.parametrize("extra", [["p2p", "deep"], ["p2p"], ["p2p", "graph", "deep"]])
+@pytest.mark.parametrize("extra", [["p2p", "deep"], ["p2p"], ["p2p", "graph", "deep"], ["p2p", "reinit"], ["p2p", "deep", "reinit"]])
 def test_exchange_inside_the_kernel_changes_no_bit(tmp_path, extra):
     """the same three-rank run with the exchanges between the launches and inside the one launch (velocities and
     stresses every third iteration with three halo layers; velocities after every iteration, the reference's
@@ -153,6 +153,16 @@ def test_a_silent_neighbour_ends_the_kernel_with_the_exchange_inside():
                      timeout=120)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "rank 0 reported:" in out.stdout and "did not arrive in time" in out.stdout, out.stdout
+
+
+def test_a_launch_that_gave_up_is_reported_by_the_transport_status_alone():
+    """The multi-rank shim asks only the transport's status after the subcycle loop (sih_comm_status): a persistent
+    launch whose neighbour never sent its halo values must surface there, without any other call that reads the
+    kernel's status word."""
+    out = _run_ranks("geo8", 2, ["p2p", "deep", "statusonly"], {"SIH_PERSIST_TIMEOUT_MS": "300", "SIH_HALO_TIMEOUT_MS": "300"},
+                     timeout=120)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "rank 0 status call reported:" in out.stdout and "persistent subcycle kernel" in out.stdout, out.stdout
 
 
 @pytest.mark.parametrize("nblocks,interval,graph", [(2, 1, False), (4, 1, True), (3, 3, False), (4, 4, True)])

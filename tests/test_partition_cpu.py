@@ -91,3 +91,23 @@ def test_the_benchmark_tries_a_thinner_halo_only_where_it_makes_the_blocks_fit()
     assert parallel.thinner_halo_that_fits(mesh, 4, 8, sizes[4] - 1) == 2
     assert parallel.thinner_halo_that_fits(mesh, 4, 8, sizes[2] - 1) == 8      # nothing fits: no change
     assert parallel.thinner_halo_that_fits(mesh, 4, 2, sizes[2] - 1) == 2      # nothing below the asked depth
+
+
+def test_plain_multi_rank_bench_command_ends_promptly_without_a_gpu():
+    """`python bench.py --gpus 2` with no launcher: the parent starts two rank processes by itself; here, without a
+    GPU, both must say so and the command must end with an error code instead of waiting for anything."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["SIH_BENCH_NO_RETRY"] = "1"
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mesh", "QU480", "--steps", "1",
+                          "--warmup", "0"], capture_output=True, text=True, timeout=240, env=env)
+    import torch
+    if torch.cuda.is_available():
+        assert out.returncode == 0, out.stderr[-2000:]
+    else:
+        assert out.returncode != 0 and "needs a GPU" in out.stderr, out.stderr[-2000:]
+        assert time.time() - t0 < 200
