@@ -148,7 +148,7 @@ def advection_timing(dom, mesh, name, reps=7, with_cpu=True):
         else:
             small = "QU240"
             m2 = meshmod.make_named_mesh(small)
-        d2 = cases.make_domain(m2, small if small.startswith("QU") else None, configs={"config_elastic_subcycle_number": 4})
+        d2 = cases.make_domain(m2, small, configs={"config_elastic_subcycle_number": 4})
         ora.seaice_init_velocity_solver(d2)
         ir.seaice_init_advection(d2)
         ora.seaice_run_velocity_solver(d2)
@@ -255,7 +255,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mesh", default="QU60", help="QU480/QU240/QU120/QU60/QU30/QU15, or an MPAS grid file (*.nc)")
+    ap.add_argument("--mesh", default="QU60", help="QU480/QU240/QU120/QU60/QU30/QU15, var<n> (variable resolution, "
+                    "maxEdges 7, 10 n^2 + 2 cells), or an MPAS grid file (*.nc)")
     ap.add_argument("--partition-file", default=None, help="METIS graph.info.part.N for --gpus N (default: "
                     "cut along a space-filling curve)")
     ap.add_argument("--subcycles", type=int, default=120)
@@ -400,6 +401,16 @@ def main():
         except Exception:
             traffic = None
     layout_bytes = b_layout_cell_kernel(M) * cells_per_launch
+    # a mesh with cells of several degrees: the same accounting with every cell's own number of corners in place of
+    # maxEdges (the planes are maxEdges deep, but a corner a cell does not have is never read)
+    degree_note = None
+    if world == 1:
+        ne = np.asarray(mesh.nEdgesOnCell[:mesh.nCells], dtype=np.int64)
+        if ne.min() != ne.max():
+            by_degree = float(sum(b_alg_cell_kernel(int(e)) * int(c) for e, c in zip(*np.unique(ne, return_counts=True))))
+            degree_note = {"cells_by_degree": {int(e): int(c) for e, c in zip(*np.unique(ne, return_counts=True))},
+                           "algorithmic_bytes_per_launch_by_degree": by_degree,
+                           "frac_by_degree": (by_degree / (cell_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if cell_ms > 0 else 0.0}
     out = {
         "metric": "EVP cell-subcycle-updates/sec at " + mesh_label, "value": value, "unit": "cell-subcycle-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -422,6 +433,8 @@ def main():
                          "frac_of_peak": (b_cell + b_vert) * value / 1e9 / HBM_PEAK_GBS},
         "pre_ms": pre_ms, "post_ms": post_ms,
     }
+    if degree_note:
+        out["roofline"]["degrees"] = degree_note
     if world == 1 and single_form != 0:
         it_ms = ms_per_step / nsub
         eq = (b_cell + b_vert) * n_cells_total / (it_ms * 1e-3) / 1e9

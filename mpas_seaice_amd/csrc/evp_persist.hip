@@ -921,7 +921,10 @@ void sih_persist_destroy(sih_ctx *c)
     c->persist = nullptr;
 }
 
-#define PS_SMALL_TILE 42  // cells of the small tile: 42 x 6 corners = 252 threads = four waves, one a SIMD
+#define PS_SMALL_TILE 42  // cells of the small tile, maxEdges 6: 42 x 6 corners = 252 threads = four waves, one a SIMD
+// maxEdges 7: 32 x 7 corners = 224 threads, four waves as well; with the metric rows streamed a tile takes 37.6 KB of
+// LDS, four fit a CU: 32 768 cells a device, against 16 384 with tiles of 64 cells (100 KB of LDS, one a CU)
+#define PS_SMALL_TILE_7 32
 
 template <int M, int TC, bool STREAM>
 static int occupancyFor(int *perCU)
@@ -1084,16 +1087,18 @@ int sih_persist_setup(sih_ctx *c)
     const bool smallTiles = !(smallEnv && atoi(smallEnv) == 0);
     if (t64.nT > s->capacity) {
         bool fits = false;
-        if (M == 6 && smallTiles) {
+        if ((M == 6 || M == 7) && smallTiles) {
             int perCUs = 0;
-            if ((rc = occupancyFor<6, PS_SMALL_TILE, true>(&perCUs))) return rc;
+            const int tcSmall = M == 6 ? PS_SMALL_TILE : PS_SMALL_TILE_7;
+            if ((rc = M == 6 ? occupancyFor<6, PS_SMALL_TILE, true>(&perCUs) : occupancyFor<7, PS_SMALL_TILE_7, true>(&perCUs)))
+                return rc;
             int cap = perCUs * prop.multiProcessorCount;
             if (const char *e = getenv("SIH_PERSIST_CAPACITY_SMALL")) cap = atoi(e);
-            buildTiles(c, PS_SMALL_TILE, cellsOfVertex, tSmall);
+            buildTiles(c, tcSmall, cellsOfVertex, tSmall);
             if (tSmall.ok && tSmall.nT <= cap) {
                 fits = true;
                 use = &tSmall;
-                s->tileCells = PS_SMALL_TILE;
+                s->tileCells = tcSmall;
                 s->perCU = perCUs;
                 s->capacity = cap;
             }
@@ -1185,6 +1190,12 @@ static void launchPersist(sih_ctx *c, int n, int interval)
     if constexpr (M == 6) {
         if (c->persist->tileCells == PS_SMALL_TILE) {
             launchPersistVariant<6, PS_SMALL_TILE, true>(c, n, interval);
+            return;
+        }
+    }
+    if constexpr (M == 7) {
+        if (c->persist->tileCells == PS_SMALL_TILE_7) {
+            launchPersistVariant<7, PS_SMALL_TILE_7, true>(c, n, interval);
             return;
         }
     }

@@ -379,6 +379,10 @@ QU_FREQ = {"QU480": 16, "QU240": 32, "QU120": 64, "QU60": 128, "QU30": 256, "QU1
 
 
 def make_named_mesh(name: str, **kw) -> Mesh:
+    """QU480 ... QU15: the quasi-uniform geodesic meshes; var<n>: the variable-resolution mesh with 5-, 6- and
+    7-sided cells (maxEdges 7) on 10 n^2 + 2 generators (var128: 163 842 cells, var256: 655 362)."""
+    if name.startswith("var"):
+        return make_variable_sphere_mesh(int(name[3:]), **kw)
     return make_sphere_mesh(QU_FREQ[name], **kw)
 
 

@@ -234,3 +234,47 @@ def test_variable_resolution_mesh_in_eight_blocks_960_subcycles_matches_oracle(o
             assert e <= 1e-10, (name, e, extra)
             worst = max(worst, e)
         print("var48 in 8 blocks, 960 subcycles", extra, "worst rel Linf", worst)
+
+
+def test_large_variable_resolution_mesh_properties():
+    """Irregular degrees at a size where a block is bound by HBM alone: the variable-resolution mesh on 10 x 256^2 + 2
+    generators (655 362 cells with 4 to 8 sides, maxEdges 8; the oracle stays at the 23 042-cell mesh of the test
+    above).  Size-independent properties: one block = eight blocks bit for bit on every owned entity (velocity solver
+    with 120 subcycles, an exchange after each as in the reference, then the incremental remap of all tracers), the
+    remap's own conservation (1e-11) and monotonicity checks pass on the device, areas stay in [0, 1], volumes >= 0."""
+    mesh = get_mesh("var256")
+    assert int(mesh.maxEdges) >= 7 and mesh.nCells == 655362
+    cfg = {"config_elastic_subcycle_number": 120, "config_conservation_check": True, "config_monotonicity_check": True}
+    one = cases.make_domain(mesh, "var256", configs=cfg)
+    vs.seaice_mesh_pool_create(one)
+    try:
+        vs.seaice_init_velocity_solver(one)
+        adv.seaice_init_advection(one)
+        vs.seaice_run_velocity_solver(one)
+        adv.seaice_run_advection(one)
+    finally:
+        vs.seaice_mesh_pool_destroy(one)
+    b0 = one.blocklist[0]
+    for n in TRACERS:
+        s0, s1 = one.solver_state["ir_sums"][n]
+        big = np.abs(s0) > 1e-11
+        assert np.abs((s1 - s0)[big] / s0[big]).max() <= 1e-11, n
+        assert np.isfinite(b0.structs["tracers"][n]).all(), n
+    a = b0.structs["tracers"]["iceAreaCategory"][0, :, :-1]
+    assert a.min() >= 0.0 and a.sum(axis=0).max() <= 1.0 + 1e-9
+    assert b0.structs["tracers"]["iceVolumeCategory"].min() >= 0.0 and b0.structs["tracers"]["snowVolumeCategory"].min() >= 0.0
+    assert np.abs(b0.structs["velocity_solver"]["uVelocity"]).max() > 1e-3
+
+    dom, halos, _ = parallel.make_partitioned_domain(mesh, "var256", 8, configs=cfg)
+    vs.seaice_mesh_pool_create(dom, device=0)
+    try:
+        dom.comm = parallel.LocalComm(dom, halos, 8)
+        vs.seaice_init_velocity_solver(dom)
+        adv.seaice_init_advection(dom)
+        vs.seaice_run_velocity_solver(dom)
+        adv.seaice_run_advection(dom)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+    fields = STATE + [("tracers", t) for t in TRACERS]
+    for (pool, name), g in _gathered(dom, halos, mesh, fields).items():
+        assert np.array_equal(g, b0.structs[pool][name][..., :g.shape[-1]]), name

@@ -93,3 +93,95 @@ def test_seaice_init_mesh_rescales_and_sets_coriolis():
     import pytest
     with pytest.raises(RuntimeError, match="inconsistent radii"):
         mesh_init.seaice_init_mesh(dom2)
+
+
+def test_files_are_checked_by_a_reader_and_writer_that_share_no_code_with_mesh_io(tmp_path):
+    """mesh_io goes through scipy's NetCDF module both ways, so a round trip proves little about the bytes.  Here
+    tests/cdf_raw.py -- written from the file format's layout alone -- reads what mesh_io wrote (entity dimension
+    first, 0 for a missing neighbour, the leading pool index last in restart fields) and writes files mesh_io has
+    never seen (a grid with other dimension order in the header, 0 and out-of-range neighbour marks, classic format;
+    a restart with two records of which the first counts), which mesh_io must read into the pools' layout: Fortran
+    order, n + 1 sentinels."""
+    import cdf_raw
+    mesh = get_mesh("hex_8_6")  # a planar mesh with a boundary: missing neighbours exist
+    nC, nV, nE, M = mesh.nCells, mesh.nVertices, mesh.nEdges, int(mesh.maxEdges)
+    p = str(tmp_path / "grid.nc")
+    mesh_io.write_mpas_mesh(mesh, p)
+    dims, gatts, var = cdf_raw.read(p)
+    assert dims["nCells"] == nC and dims["nVertices"] == nV and dims["maxEdges"] == M and dims["TWO"] == 2
+    assert gatts["on_a_sphere"].strip() == "NO"
+    names, a = var["verticesOnCell"]
+    assert names == ("nCells", "maxEdges") and a.shape == (nC, M) and a.dtype == np.int32
+    pool = np.asarray(mesh["verticesOnCell"])  # (maxEdges, nCells), n + 1 = none
+    assert np.array_equal(np.where(pool.T > nV, 0, pool.T), a)
+    names, a = var["cellsOnVertex"]
+    assert names == ("nVertices", "vertexDegree") and (a == 0).any() and a.max() <= nC
+    assert np.array_equal(np.where(np.asarray(mesh["cellsOnVertex"]).T > nC, 0, np.asarray(mesh["cellsOnVertex"]).T), a)
+    assert var["xCell"][0] == ("nCells",) and np.array_equal(var["xCell"][1], np.asarray(mesh["xCell"]))
+    assert np.array_equal(var["dvEdge"][1], np.asarray(mesh["dvEdge"]))
+
+    # ---- a grid file mesh_io did not write
+    def conn(k, target):
+        a = np.asarray(mesh[k]).T.astype(np.int32).copy()
+        a[a > target] = 0
+        return a
+    voc = conn("verticesOnCell", nV)
+    voc[3, int(mesh["nEdgesOnCell"][3]):] = nV + 7  # junk past nEdgesOnCell, as real grid files have
+    variables = [("xCell", ("nCells",), np.asarray(mesh["xCell"], dtype=np.float64))]
+    for k in ("yCell", "zCell", "areaCell"):
+        variables.append((k, ("nCells",), np.asarray(mesh[k], dtype=np.float64)))
+    for k in ("xVertex", "yVertex", "zVertex", "areaTriangle"):
+        variables.append((k, ("nVertices",), np.asarray(mesh[k], dtype=np.float64)))
+    for k in ("xEdge", "yEdge", "zEdge", "dcEdge", "dvEdge"):
+        variables.append((k, ("nEdges",), np.asarray(mesh[k], dtype=np.float64)))
+    variables += [("nEdgesOnCell", ("nCells",), np.asarray(mesh["nEdgesOnCell"], dtype=np.int32)),
+                  ("verticesOnCell", ("nCells", "maxEdges"), voc),
+                  ("edgesOnCell", ("nCells", "maxEdges"), conn("edgesOnCell", nE)),
+                  ("cellsOnCell", ("nCells", "maxEdges"), conn("cellsOnCell", nC)),
+                  ("cellsOnVertex", ("nVertices", "vertexDegree"), conn("cellsOnVertex", nC)),
+                  ("cellsOnEdge", ("nEdges", "TWO"), conn("cellsOnEdge", nC)),
+                  ("verticesOnEdge", ("nEdges", "TWO"), conn("verticesOnEdge", nV))]
+    q = str(tmp_path / "foreign.grid.nc")
+    cdf_raw.write(q, [("TWO", 2), ("vertexDegree", 3), ("maxEdges", M), ("nEdges", nE), ("nVertices", nV),
+                      ("nCells", nC)], {"on_a_sphere": "NO", "sphere_radius": 1.0}, variables, version=1)
+    back = mesh_io.read_mpas_mesh(q)
+    for k in ("nEdgesOnCell", "verticesOnCell", "edgesOnCell", "cellsOnCell", "cellsOnVertex", "cellsOnEdge",
+              "verticesOnEdge", "xCell", "zVertex", "areaCell", "areaTriangle", "dcEdge", "dvEdge", "edgesOnVertex"):
+        assert np.array_equal(np.asarray(back[k]), np.asarray(mesh[k])), k
+    assert back["verticesOnCell"].flags["F_CONTIGUOUS"] and back["verticesOnCell"].shape == (M, nC)
+    assert not back["on_a_sphere"]
+
+    # ---- restart files both ways
+    dom = cases.make_domain(mesh, None, configs={"config_dt": 600.0})
+    b = dom.blocklist[0]
+    rng = np.random.Generator(np.random.PCG64(20241020))
+    b.structs["velocity_solver"]["uVelocity"][:nV] = rng.standard_normal(nV)
+    b.structs["velocity_variational"]["stress12"][:, :nC] = rng.standard_normal((M, nC))
+    b.structs["tracers"]["iceEnthalpy"][..., :nC] = rng.standard_normal(b.structs["tracers"]["iceEnthalpy"][..., :nC].shape)
+    b.structs["velocity_solver"]["solveVelocityPrevious"][:nV] = rng.integers(0, 2, nV)
+    r = str(tmp_path / "restart.nc")
+    mesh_io.write_restart(dom, r)
+    dims, _, var = cdf_raw.read(r)
+    assert dims["Time"] is None
+    names, a = var["stress12"]
+    assert names == ("Time", "nCells", "maxEdges") and a.shape == (1, nC, M)
+    assert np.array_equal(a[0], b.structs["velocity_variational"]["stress12"][:, :nC].T)
+    names, a = var["iceEnthalpy"]
+    assert names == ("Time", "nCells", "nCategories", "nIceLayers")
+    assert np.array_equal(a[0], np.transpose(b.structs["tracers"]["iceEnthalpy"][..., :nC]))
+    assert var["solveVelocityPrevious"][1].dtype == np.int32
+    # the same fields written by the raw writer (two records; the restart's is the first), read by mesh_io
+    variables = []
+    for k, (names, a) in var.items():
+        two = np.concatenate([a, a * 0 - 3], axis=0)
+        variables.append((k, names, two.astype(np.int32) if a.dtype.kind == "i" else two.astype(np.float64)))
+    dl = [("Time", None)] + [(k, v) for k, v in dims.items() if k != "Time"]
+    r2 = str(tmp_path / "foreign.restart.nc")
+    cdf_raw.write(r2, dl, {}, variables, version=2)
+    other = cases.make_domain(mesh, None, configs={"config_dt": 600.0})
+    mesh_io.read_restart(other, r2)
+    for pool, name, ent, _ in mesh_io.RESTART_FIELDS:
+        n = nV if ent == "nVertices" else nC
+        assert np.array_equal(other.blocklist[0].structs[pool][name][..., :n], b.structs[pool][name][..., :n]), name
+    for t in ("iceAreaCategory", "iceEnthalpy", "snowEnthalpy"):
+        assert np.array_equal(other.blocklist[0].structs["tracers"][t][..., :nC], b.structs["tracers"][t][..., :nC]), t

@@ -131,3 +131,32 @@ def test_small_tiles_hold_a_block_that_tiles_of_64_cells_cannot():
     for k in res[0]:
         assert np.isfinite(res[1][k]).all(), k
         assert np.array_equal(res[0][k], res[1][k]), (k, np.abs(res[0][k] - res[1][k]).max())
+
+
+def test_small_tiles_for_seven_sided_meshes():
+    """A variable-resolution mesh with 5-, 6- and 7-sided cells (maxEdges 7), 31 362 cells: tiles of 64 cells need
+    100 KB of LDS, one to a CU, and 491 of them are more than a device holds; tiles of 32 cells x 7 corners (four waves)
+    with the metric rows streamed fit four to a CU.  Same bits as the two-kernel form."""
+    mesh = get_mesh("var56")
+    assert int(mesh.maxEdges) == 7
+    res = []
+    for persistent in (False, True):
+        dom, b = _prepared(mesh, None, configs={"config_dt": 900.0}, open_water_band=(-0.2, 0.3))
+        try:
+            if persistent:
+                assert b.ctx.info("persistentKernel") == 1.0, b.ctx.info("persistentReason")
+                assert b.ctx.info("persistentTileCells") == 32.0 and b.ctx.info("persistentTiles") == 981.0
+            for n in (7, 1, 12):
+                if persistent:
+                    b.ctx.subcycle_persistent(n)
+                else:
+                    b.ctx.subcycle(n, last=False)
+                b.ctx.subcycle(2, last=False)
+            b.ctx.sync()
+            res.append(_state(b))
+        finally:
+            vs.seaice_mesh_pool_destroy(dom)
+    assert np.abs(res[0]["uVelocity"]).max() > 1e-4
+    for k in res[0]:
+        assert np.isfinite(res[1][k]).all(), k
+        assert np.array_equal(res[0][k], res[1][k]), (k, np.abs(res[0][k] - res[1][k]).max())

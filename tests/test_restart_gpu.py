@@ -1,0 +1,107 @@
+"""Restartability as the reference's own harness tests it (testing_and_setup/testing/tests/restartability.py: a
+straight run against a run restarted half way, every restart variable compared bit for bit): two dynamics steps
+(velocity solver + incremental remap) straight, against one step -> restart file -> every device context destroyed ->
+fresh domain and contexts -> restart file read -> one step.  Only what the restart stream holds (Registry.xml:1910-2000:
+uVelocity, vVelocity, stress11/22/12, solveVelocityPrevious, oceanStressCellU/V, the tracers) crosses the file; masks,
+strains, forcing terms and basis arrays are recomputed, as in the reference."""
+import numpy as np
+import pytest
+
+from mpas_seaice_amd import advection as adv, cases, mesh_io, parallel, velocity_solver as vs
+from util import get_mesh
+
+pytestmark = pytest.mark.gpu
+
+TRACERS = ["iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory", "surfaceTemperature", "iceEnthalpy",
+           "iceSalinity", "snowEnthalpy"]
+RESTART = [(p, n) for p, n, _, _ in mesh_io.RESTART_FIELDS] + [("tracers", t) for t in TRACERS]
+CFG = {"config_elastic_subcycle_number": 60}
+
+
+def _make(mesh, nblocks):
+    if nblocks == 1:
+        return cases.make_domain(mesh, "QU240", configs=CFG, open_water_band=(-0.2, 0.3)), None
+    dom, halos, _ = parallel.make_partitioned_domain(mesh, "QU240", nblocks, configs=CFG, open_water_band=(-0.2, 0.3))
+    return dom, halos
+
+
+def _start(dom, halos):
+    vs.seaice_mesh_pool_create(dom, device=0)
+    if halos is not None:
+        dom.comm = parallel.LocalComm(dom, halos, len(halos))
+    vs.seaice_init_velocity_solver(dom)
+    adv.seaice_init_advection(dom)
+
+
+def _step(dom):
+    vs.seaice_run_velocity_solver(dom)
+    adv.seaice_run_advection(dom)
+
+
+def _global(mesh, dom, halos):
+    """the restart fields of the whole mesh, from the owned entities of the blocks"""
+    out = {}
+    for pool, name in RESTART:
+        loc = parallel.field_loc(name)
+        n = mesh.nVertices if loc == "vertex" else mesh.nCells
+        if halos is None:
+            out[name] = dom.blocklist[0].structs[pool][name][..., :n].copy()
+        else:
+            out[name] = parallel.gather_global(dom.blocklist, halos, pool, name, n, loc)
+    return out
+
+
+@pytest.mark.parametrize("nblocks", [1, 2])
+def test_restarted_run_equals_straight_run_bit_for_bit(tmp_path, nblocks):
+    mesh = get_mesh("QU240")
+    # ---- straight: two steps
+    dom, halos = _make(mesh, nblocks)
+    _start(dom, halos)
+    try:
+        _step(dom)
+        _step(dom)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+    straight = _global(mesh, dom, halos)
+
+    # ---- one step, restart file, everything torn down
+    dom, halos = _make(mesh, nblocks)
+    _start(dom, halos)
+    try:
+        _step(dom)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+    half = _global(mesh, dom, halos)
+    whole = cases.make_domain(mesh, "QU240", configs=CFG, open_water_band=(-0.2, 0.3))
+    for pool, name in RESTART:
+        a = whole.blocklist[0].structs[pool][name]
+        a[..., :half[name].shape[-1]] = half[name]
+    rst = str(tmp_path / "restart.nc")
+    mesh_io.write_restart(whole, rst)
+    del dom, whole
+
+    # ---- fresh domain and contexts, state from the file only
+    again = cases.make_domain(mesh, "QU240", configs=CFG, open_water_band=(-0.2, 0.3))
+    mesh_io.read_restart(again, rst)
+    dom, halos = _make(mesh, nblocks)
+    if halos is None:
+        for pool, name in RESTART:
+            dom.blocklist[0].structs[pool][name][...] = again.blocklist[0].structs[pool][name]
+    else:
+        for b, h in zip(dom.blocklist, halos):
+            for pool, name in RESTART:
+                loc = parallel.field_loc(name)
+                g = h.globalID[loc]
+                b.structs[pool][name][..., :len(g)] = again.blocklist[0].structs[pool][name][..., g]
+    _start(dom, halos)
+    try:
+        _step(dom)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+    restarted = _global(mesh, dom, halos)
+
+    assert np.abs(straight["uVelocity"]).max() > 1e-3
+    assert not np.array_equal(straight["iceAreaCategory"], half["iceAreaCategory"])  # the second step did something
+    for name, a in straight.items():
+        assert np.isfinite(a).all(), name
+        assert np.array_equal(a, restarted[name]), (name, float(np.abs(a - restarted[name]).max()))
