@@ -50,13 +50,30 @@ def b_layout_cell_kernel(M):
     return 48 * M + 24 * M * M + 48 * M + 16 * M + (4 * M + 8) + 8 + 24 * 2
 
 
-def kernel_source_hash():
+def kernel_source_hash(files=("evp_step.hip", "sih_internal.h")):
+    """Of the sources of the subcycle kernels; ir_source_hash() is the same for the incremental remap's.  The counter
+    figures kept under profiles/ carry both, and a figure taken with other sources is not reported."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("evp_step.hip", "sih_internal.h"):
+    for f in files:
         with open(os.path.join(ROOT, "mpas_seaice_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def ir_source_hash():
+    return kernel_source_hash(("ir_advect.hip", "sih_internal.h"))
+
+
+def committed_profile():
+    """profiles/traffic_latest.json: HBM bytes per launch from the PMC counters and rocprofv3's average kernel
+    durations, both from EARLIER profile runs of bench.py at QU60 (scripts/profile_round.sh; counters cannot be
+    collected inside a timed run), or {} when the file is missing or unreadable."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as fh:
+            return json.load(fh)
+    except Exception:  # noqa: BLE001
+        return {}
 
 
 def hbm_only_pass(local_rank, nsub=24, steps=5):
@@ -128,14 +145,28 @@ def advection_timing(dom, mesh, name, reps=7, with_cpu=True):
     nCat = b.dimensions["nCategories"]
     ns = sum(t.nLayers for t in dom.solver_state["tracersHead"]) * nCat
     ms = float(np.median(tot))
-    # nominal compulsory traffic per scalar per cell: value read + written, centre/gradient/product written
-    # and read back, three edge fluxes per cell written once and read twice
-    bytes_per_scalar_cell = 8 + 8 + 4 * 8 * 2 + 3 * 8 * 3
+    # Two accountings of the compulsory traffic, both against the same time.  (1) The nominal figure of the hot-path
+    # scope: per advected scalar and cell 20 B (value read, mask, value written) + 40 B of reconstruction scratch, and
+    # 300 B of geometry per cell.  (2) This layout's own: value read + written, centre / gradient / product written
+    # and read back, three edge fluxes per cell written once and read twice = 152 B per scalar and cell.  (3) What the
+    # counters saw, when the committed profile was taken with these kernel sources.
+    nominal_bytes = mesh.nCells * (ns * (20 + 40) + 300)
+    layout_bytes = mesh.nCells * ns * (8 + 8 + 4 * 8 * 2 + 3 * 8 * 3)
+    prof = committed_profile()
+    counted = None
+    if name == "QU60" and prof.get("ir_source_hash") == ir_source_hash():
+        counted = float(sum(v for k, v in prof.get("advection_hbm_bytes_per_step", {}).items() if "_init_" not in k))
+
+    def rate(b):
+        return {"bytes_per_step": b, "GBps": b / (ms * 1e-3) / 1e9, "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     out = {"workload": f"incremental remap, {ns} scalars per cell on {name}", "ms_per_step": ms,
            "tracer_cell_updates_per_s": mesh.nCells * ns / (ms * 1e-3),
            "phase_ms": dict(zip(["convert+masks", "reconstruct", "departure_triangles", "fluxes", "update+zap"],
                                 [round(float(x), 4) for x in np.median(np.array(ph), axis=0)])),
-           "nominal_GBps": mesh.nCells * ns * bytes_per_scalar_cell / (ms * 1e-3) / 1e9}
+           "traffic": {"nominal_60B_per_scalar_plus_300B_per_cell": rate(nominal_bytes),
+                       "layout_152B_per_scalar": rate(layout_bytes),
+                       "counted_in_an_earlier_profile": rate(counted) if counted else None},
+           "nominal_GBps": layout_bytes / (ms * 1e-3) / 1e9}
     a = np.zeros_like(b.structs["tracers"]["iceAreaCategory"])
     b.ctx.get("iceAreaCategory", a)
     if not np.isfinite(a).all():
@@ -388,18 +419,19 @@ def main():
     # HBM bytes per launch from the PMC counters: they are collected in passes of their own (rocprofv3 --pmc,
     # scripts/refresh_traffic.py) and kept under profiles/ with a hash of the kernel source they were taken with;
     # a figure taken with other kernels is not reported
-    traffic, traffic_note = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if world == 1 and mesh_label == "QU60" and os.path.exists(tpath):  # the counters were collected on this workload
-        try:
-            tj = json.load(open(tpath))
-            if tj.get("kernel_source_hash") == kernel_source_hash():
-                traffic = tj.get("cell_kernel_hbm_bytes_per_launch")
-                traffic_note = tj.get("source")
-            else:
-                traffic_note = "profiles/traffic_latest.json was taken with other kernel sources: not reported"
-        except Exception:
-            traffic = None
+    traffic, traffic_note, rocprof_ms = None, None, None
+    tj = committed_profile()
+    if world == 1 and mesh_label == "QU60" and tj:  # the counters were collected on this workload
+        if tj.get("kernel_source_hash") == kernel_source_hash():
+            traffic = tj.get("cell_kernel_hbm_bytes_per_launch")
+            traffic_note = ("NOT measured in this run: profiles/traffic_latest.json, an earlier profile of the same "
+                            "kernel sources; " + str(tj.get("source")))
+            if tj.get("cell_kernel_avg_ns_rocprof"):
+                rocprof_ms = {"cell_kernel": tj["cell_kernel_avg_ns_rocprof"] * 1e-6,
+                              "vertex_kernel": (tj.get("vertex_kernel_avg_ns_rocprof") or 0.0) * 1e-6,
+                              "from": tj.get("kernel_stats_file")}
+        else:
+            traffic_note = "profiles/traffic_latest.json was taken with other kernel sources: not reported"
     layout_bytes = b_layout_cell_kernel(M) * cells_per_launch
     # a mesh with cells of several degrees: the same accounting with every cell's own number of corners in place of
     # maxEdges (the planes are maxEdges deep, but a corner a cell does not have is never read)
@@ -422,6 +454,9 @@ def main():
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_launch": roof_bytes,
                      "kernel_ms": cell_ms, "vertex_kernel_ms": vert_ms,
+                     # rocprofv3's average durations of the same kernels in the committed kernel trace (an earlier
+                     # run): frac can be recomputed from algorithmic_bytes_per_launch and either duration
+                     "kernel_ms_rocprof": rocprof_ms,
                      # the same kernel time against the bytes this layout really has to move (compact gradients)
                      # and, when the counters are current, against the bytes they counted
                      "layout_bytes_per_launch": layout_bytes,

@@ -397,6 +397,8 @@ contains
     call system_clock(t1)
     msLazy = real(t1 - t0, c_double) / real(rate, c_double) * 1.0e3_c_double / nRep
 
+    call time_overlapped()
+
     write(*,'(a,i0,a,f8.1,a,f8.1,a)') "host step, ", nCells, " cells: ", mbIn, " MB up, ", mbOut, " MB down"
     write(*,'(a,f10.3)') "host step ms, one blocking call per field, ordinary memory: ", msPerField
     write(*,'(a,f10.3)') "host step ms, batched calls, page-locked memory: ", msBatched
@@ -407,6 +409,173 @@ contains
     deallocate(arena)
 
   end subroutine time_host_step
+
+  !> The same step with the downloads behind the computation (sih_fields_get_start / _finish), page-locked memory:
+  !> what the pre-cycle leaves for good (masks, ice strength, forcing terms, aggregates) travels while the subcycle
+  !> loop runs; at the end of the solver only what the next stage of the time step and a restart need comes back
+  !> before the call returns (velocities, stresses, solveVelocityPrevious, oceanStressCellU/V, ridging rates); the
+  !> other diagnostics (strains, replacement pressure, principal stresses, stress divergence, ...) drain while the
+  !> incremental remap of seaice_run_advection computes and are complete when that call ends.  Every array is
+  !> compared with the plain batched download afterwards.
+  subroutine time_overlapped()
+
+    integer, parameter :: nPre = 21, nCrit = 10, nRest = 13, nAll = nPre + nCrit + nRest, nRep = 5
+    character(len=32), dimension(nAll), parameter :: names = [character(len=32) :: &
+         "uVelocityInitial", "vVelocityInitial", "icePressure", "airStressCellU", "airStressCellV", &
+         "airStressVertexU", "airStressVertexV", "uOceanVelocityVertex", "vOceanVelocityVertex", &
+         "surfaceTiltForceU", "surfaceTiltForceV", "totalMassVertexfVertex", "iceAreaVertex", "totalMassVertex", &
+         "iceAreaCellInitial", "totalMassCell", "iceAreaCell", "iceVolumeCell", "snowVolumeCell", "solveStress", &
+         "solveVelocity", &
+         "uVelocity", "vVelocity", "stress11", "stress22", "stress12", "solveVelocityPrevious", &
+         "oceanStressCellU", "oceanStressCellV", "ridgeConvergence", "ridgeShear", &
+         "stressDivergenceU", "stressDivergenceV", "oceanStressU", "oceanStressV", "oceanStressCoeff", &
+         "divergence", "shear", "strain11", "strain22", "strain12", "replacementPressure", &
+         "principalStress1", "principalStress2"]
+    integer, parameter :: nIn = 20
+    ! the inputs of a step: first what the host model changes between two steps (tracers, forcing, masks), then the
+    ! solver's own state, which is on the device already when nothing but the solver has touched it
+    integer, parameter :: nInFresh = 10
+    character(len=32), dimension(nIn), parameter :: inNames = [character(len=32) :: &
+         "iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory", "uOceanVelocity", "vOceanVelocity", &
+         "uAirVelocity", "vAirVelocity", "airDensity", "landIceMask", "landIceMaskVertex", &
+         "uVelocity", "vVelocity", "stressDivergenceU", "stressDivergenceV", "oceanStressU", "oceanStressV", &
+         "solveVelocityPrevious", "stress11", "stress22", "stress12"]
+    integer, parameter :: nTr = 7
+    character(len=32), dimension(nTr), parameter :: trNames = [character(len=32) :: &
+         "iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory", "surfaceTemperature", "iceEnthalpy", &
+         "iceSalinity", "snowEnthalpy"]
+    integer, parameter :: nTot = nAll + nIn + nTr
+    character(len=33, kind=c_char), dimension(nTot), target :: cNames
+    type(c_ptr), dimension(nTot) :: namePtrs, hostA, hostB, hostC
+    integer(c_size_t), dimension(nTot) :: counts, offsets
+    integer(c_int), dimension(nTot) :: es
+    integer(c_size_t) :: total, j
+    integer(c_int8_t), dimension(:), pointer :: arenaA, arenaB, arenaC
+    type(c_ptr) :: baseA, baseB, baseC
+    integer(kind=8) :: t0, t1, t2, t3, rate
+    real(c_double) :: msSolverPlain, msStepPlain, msSolverOver, msStepOver, msSolverKeep, msStepKeep
+    integer :: i, rep, nDiff, variant
+    integer(c_int) :: e1
+
+    total = 0
+    do i = 1, nTot
+       if (i <= nAll) then
+          cNames(i) = trim(names(i)) // c_null_char
+       else if (i <= nAll + nIn) then
+          cNames(i) = trim(inNames(i - nAll)) // c_null_char
+       else
+          cNames(i) = trim(trNames(i - nAll - nIn)) // c_null_char
+       endif
+       namePtrs(i) = c_loc(cNames(i))
+       counts(i) = sih_field_count(ctx, cNames(i), e1)
+       es(i) = e1
+       if (counts(i) == 0) then
+          write(*,*) "time_overlapped: unknown field ", trim(cNames(i))
+          stop 1
+       endif
+       offsets(i) = total
+       total = total + ((counts(i) * e1 + 255_c_size_t) / 256_c_size_t) * 256_c_size_t
+    enddo
+    call check(sih_host_alloc(baseA, total), "sih_host_alloc")
+    call check(sih_host_alloc(baseB, total), "sih_host_alloc")
+    call check(sih_host_alloc(baseC, total), "sih_host_alloc")   ! the state every timed step starts from
+    call c_f_pointer(baseA, arenaA, [total])
+    call c_f_pointer(baseB, arenaB, [total])
+    call c_f_pointer(baseC, arenaC, [total])
+    arenaC = 0_c_int8_t
+    arenaA = 0_c_int8_t
+    arenaB = 0_c_int8_t
+    do i = 1, nTot
+       hostA(i) = c_loc(arenaA(offsets(i) + 1))
+       hostB(i) = c_loc(arenaB(offsets(i) + 1))
+       hostC(i) = c_loc(arenaC(offsets(i) + 1))
+    enddo
+    ! the inputs of a step and the tracers as they are on the device now, once, into both sets
+    call check(sih_fields_get(ctx, int(nIn + nTr, c_int), namePtrs(nAll+1:), hostA(nAll+1:), counts(nAll+1:)), "get inputs")
+    call check(sih_fields_get(ctx, int(nIn + nTr, c_int), namePtrs(nAll+1:), hostB(nAll+1:), counts(nAll+1:)), "get inputs")
+    call check(sih_fields_get(ctx, int(nIn + nTr, c_int), namePtrs(nAll+1:), hostC(nAll+1:), counts(nAll+1:)), "get inputs")
+
+    call system_clock(count_rate=rate)
+    msSolverPlain = 0; msStepPlain = 0; msSolverOver = 0; msStepOver = 0; msSolverKeep = 0; msStepKeep = 0
+    do rep = 0, nRep   ! rep 0 warms up
+       ! ---- plain: everything up, solver, everything down; then the advection
+       call check(sih_fields_put(ctx, int(nIn + nTr, c_int), namePtrs(nAll+1:), hostC(nAll+1:), counts(nAll+1:)), "put")
+       call system_clock(t0)
+       call check(sih_fields_put(ctx, int(nIn, c_int), namePtrs(nAll+1:), hostA(nAll+1:), counts(nAll+1:)), "put")
+       call check(sih_evp_run(ctx), "sih_evp_run")
+       call check(sih_fields_get(ctx, int(nAll, c_int), namePtrs, hostA, counts), "get")
+       call system_clock(t1)
+       call check(sih_ir_run(ctx, config_dt, 0_c_int), "sih_ir_run")
+       call check(sih_fields_get(ctx, int(nTr, c_int), namePtrs(nAll+nIn+1:), hostA(nAll+nIn+1:), counts(nAll+nIn+1:)), "get")
+       call system_clock(t2)
+       if (rep > 0) then
+          msSolverPlain = msSolverPlain + real(t1 - t0, c_double)
+          msStepPlain = msStepPlain + real(t2 - t0, c_double)
+       endif
+       ! ---- the same step from the same state with the downloads behind the computation: first with every input
+       !      uploaded, then with the solver's own state left where the step before put it (here: the untimed upload)
+       do variant = 1, 2
+          call check(sih_fields_put(ctx, int(nIn + nTr, c_int), namePtrs(nAll+1:), hostC(nAll+1:), counts(nAll+1:)), "put")
+          call system_clock(t0)
+          call check(sih_fields_put(ctx, int(merge(nIn, nInFresh, variant == 1), c_int), namePtrs(nAll+1:), &
+               hostB(nAll+1:), counts(nAll+1:)), "put")
+          call check(sih_evp_run_early_outputs(ctx, int(nPre, c_int), namePtrs, hostB, counts), "sih_evp_run_early_outputs")
+          call check(sih_fields_get(ctx, int(nCrit, c_int), namePtrs(nPre+1:), hostB(nPre+1:), counts(nPre+1:)), "get critical")
+          call check(sih_fields_get_start(ctx, int(nRest, c_int), namePtrs(nPre+nCrit+1:), hostB(nPre+nCrit+1:), &
+               counts(nPre+nCrit+1:)), "get_start rest")
+          call system_clock(t1)   ! seaice_run_velocity_solver would return here
+          call check(sih_ir_run(ctx, config_dt, 0_c_int), "sih_ir_run")
+          call check(sih_fields_get(ctx, int(nTr, c_int), namePtrs(nAll+nIn+1:), hostB(nAll+nIn+1:), &
+               counts(nAll+nIn+1:)), "get")
+          call check(sih_fields_get_finish(ctx), "sih_fields_get_finish")
+          call system_clock(t3)
+          if (rep > 0 .and. variant == 1) then
+             msSolverOver = msSolverOver + real(t1 - t0, c_double)
+             msStepOver = msStepOver + real(t3 - t0, c_double)
+          else if (rep > 0) then
+             msSolverKeep = msSolverKeep + real(t1 - t0, c_double)
+             msStepKeep = msStepKeep + real(t3 - t0, c_double)
+          endif
+       enddo
+    enddo
+    nDiff = 0
+    do i = 1, nAll
+       do j = 1, counts(i) * es(i)
+          if (arenaA(offsets(i) + j) /= arenaB(offsets(i) + j)) then
+             nDiff = nDiff + 1
+             write(*,*) "overlapped download differs in ", trim(names(i))
+             exit
+          endif
+       enddo
+    enddo
+    do i = nAll + nIn + 1, nTot
+       do j = 1, counts(i) * es(i)
+          if (arenaA(offsets(i) + j) /= arenaB(offsets(i) + j)) then
+             nDiff = nDiff + 1
+             write(*,*) "overlapped run differs in tracer ", trim(trNames(i - nAll - nIn))
+             exit
+          endif
+       enddo
+    enddo
+    write(*,'(a,i0)') "overlapped downloads: fields that differ from the plain ones: ", nDiff
+    write(*,'(a,f10.3)') "host step ms, velocity solver, batched, page-locked, all outputs before it returns: ", &
+         msSolverPlain / real(rate, c_double) * 1.0e3_c_double / nRep
+    write(*,'(a,f10.3)') "host step ms, velocity solver + advection, plain: ", &
+         msStepPlain / real(rate, c_double) * 1.0e3_c_double / nRep
+    write(*,'(a,f10.3)') "host step ms, velocity solver, downloads behind the computation, until it returns: ", &
+         msSolverOver / real(rate, c_double) * 1.0e3_c_double / nRep
+    write(*,'(a,f10.3)') "host step ms, velocity solver + advection, downloads behind the computation, all outputs delivered: ", &
+         msStepOver / real(rate, c_double) * 1.0e3_c_double / nRep
+    write(*,'(a,f10.3)') "host step ms, velocity solver, downloads behind the computation, solver state kept on the device, until it returns: ", &
+         msSolverKeep / real(rate, c_double) * 1.0e3_c_double / nRep
+    write(*,'(a,f10.3)') "host step ms, velocity solver + advection, downloads behind the computation, solver state kept on the device, all outputs delivered: ", &
+         msStepKeep / real(rate, c_double) * 1.0e3_c_double / nRep
+    call check(sih_host_free(baseA), "sih_host_free")
+    call check(sih_host_free(baseB), "sih_host_free")
+    call check(sih_host_free(baseC), "sih_host_free")
+    if (nDiff /= 0) stop 1
+
+  end subroutine time_overlapped
 
   subroutine check(ierr, what)
     integer(c_int), intent(in) :: ierr

@@ -192,6 +192,36 @@ module seaice_hip_interface
        integer(c_int) :: ierr
      end function sih_fields_get
 
+     ! the same download, draining behind whatever the host starts next; the arrays are the library's until
+     ! sih_fields_get_finish has returned
+     function sih_fields_get_start(ctx, nFields, names, hosts, counts) bind(C, name="sih_fields_get_start") result(ierr)
+       import :: c_int, c_ptr, c_size_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nFields
+       type(c_ptr), dimension(*), intent(in) :: names
+       type(c_ptr), dimension(*), intent(in) :: hosts
+       integer(c_size_t), dimension(*), intent(in) :: counts
+       integer(c_int) :: ierr
+     end function sih_fields_get_start
+
+     ! sih_evp_run with the download of the listed fields (final after the pre-cycle) behind the iterations
+     function sih_evp_run_early_outputs(ctx, nFields, names, hosts, counts) &
+          bind(C, name="sih_evp_run_early_outputs") result(ierr)
+       import :: c_int, c_ptr, c_size_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nFields
+       type(c_ptr), dimension(*), intent(in) :: names
+       type(c_ptr), dimension(*), intent(in) :: hosts
+       integer(c_size_t), dimension(*), intent(in) :: counts
+       integer(c_int) :: ierr
+     end function sih_evp_run_early_outputs
+
+     function sih_fields_get_finish(ctx) bind(C, name="sih_fields_get_finish") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int) :: ierr
+     end function sih_fields_get_finish
+
      function sih_field_count(ctx, name, elemSize) bind(C, name="sih_field_count") result(n)
        import :: c_int, c_ptr, c_char, c_size_t
        type(c_ptr), value :: ctx

@@ -211,6 +211,25 @@ int sih_field_get(sih_ctx *ctx, const char *name, void *host, size_t count);
 int sih_fields_put(sih_ctx *ctx, int nFields, const char *const *names, const void *const *hosts,
                    const size_t *counts);
 int sih_fields_get(sih_ctx *ctx, int nFields, const char *const *names, void *const *hosts, const size_t *counts);
+/* A download that drains behind whatever the host starts next.  No counterpart in the reference (its pools live in
+ * host memory); it serves the order of seaice_timestep (mpas_seaice_time_integration.F:147-153): the fields of the
+ * velocity solver that nothing reads before the end of the step (strains, replacement pressure, principal stresses,
+ * masks, forcing terms: what the analysis members and output streams take from the pools) travel while
+ * seaice_run_advection computes.  sih_fields_get_start queues the read of the fields behind the work queued on the
+ * context's stream so far and returns; work queued afterwards waits for that read (a few layout kernels), not for the
+ * copies to the host.  The host arrays must stay allocated and untouched until sih_fields_get_finish has returned; one
+ * such download at a time (a second start first waits for the one before).  Page-locked arrays (sih_host_alloc) make
+ * the copies asynchronous; from ordinary memory the call may take as long as sih_fields_get. */
+int sih_fields_get_start(sih_ctx *ctx, int nFields, const char *const *names, void *const *hosts, const size_t *counts);
+int sih_fields_get_finish(sih_ctx *ctx);
+/* sih_evp_run (below) with such a download started between the pre-cycle and the iterations, for the fields that
+ * velocity_solver_pre_subcycle (mpas_seaice_velocity_solver.F:613-671) computes and nothing later in the step changes:
+ * solveStress solveVelocity icePressure airStressCellU/V airStressVertexU/V uOceanVelocityVertex vOceanVelocityVertex
+ * surfaceTiltForceU/V totalMassVertexfVertex iceAreaVertex totalMassVertex iceAreaCellInitial totalMassCell
+ * iceAreaCell iceVolumeCell snowVolumeCell uVelocityInitial vVelocityInitial.  They reach the host while the subcycle
+ * loop runs. */
+int sih_evp_run_early_outputs(sih_ctx *ctx, int nFields, const char *const *names, void *const *hosts,
+                              const size_t *counts);
 /* Hand-off to the column package between advection and ridging (seaice_column_dynamics_time_integration,
  * mpas_seaice_time_integration.F:158 -> column_ridging, mpas_seaice_column.F:3391-3560), which works cell by cell
  * on the owned cells and takes, per cell, ridgeConvergence / ridgeShear (written by the velocity solver's

@@ -1399,11 +1399,16 @@ extern "C" int sih_evp_post_subcycle(sih_ctx *c, int stage)
     return SIH_OK;
 }
 
-extern "C" int sih_evp_run(sih_ctx *c)
+extern "C" int sih_fields_get_start(sih_ctx *c, int nf, const char *const *names, void *const *hosts, const size_t *counts);
+extern "C" int sih_fields_get_finish(sih_ctx *c);
+
+static int evpRun(sih_ctx *c, int nEarly, const char *const *names, void *const *hosts, const size_t *counts)
 {
     int rc = checkInit(c, "sih_evp_run");
     if (rc) return rc;
     if ((rc = sih_evp_pre_subcycle(c, -1))) return rc;
+    // what the pre-cycle leaves for good starts its way to the host now and travels while the iterations run
+    if (nEarly > 0 && (rc = sih_fields_get_start(c, nEarly, names, hosts, counts))) return rc;
     // All iterations but the last are the same pair (or few) of launches: replayed from a graph captured at the
     // first call, which takes the launch gaps out (2 % of the loop at 164 k cells, 25 % at 10 k).  The last
     // iteration stores more and runs as it is.  SIH_EVP_GRAPH=0 keeps every launch separate.
@@ -1418,8 +1423,23 @@ extern "C" int sih_evp_run(sih_ctx *c)
     } else if ((rc = sih_evp_subcycle(c, n, 1)))
         return rc;
     if ((rc = sih_evp_post_subcycle(c, -1))) return rc;
+    // everything is queued: the early outputs are finished (their last hop into ordinary host memory is made by this
+    // thread) while the device still runs the iterations
+    if (nEarly > 0 && (rc = sih_fields_get_finish(c))) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     return sih_persist_status(c);
+}
+
+extern "C" int sih_evp_run(sih_ctx *c) { return evpRun(c, 0, nullptr, nullptr, nullptr); }
+
+// sih_evp_run with a download inside it: the listed fields, which must be among those the pre-cycle computes and the
+// iterations and the post-cycle leave alone (masks, ice strength, forcing terms, aggregated mass and area, the
+// velocities at the start of the step), are read right after the pre-cycle and copied to the host while the
+// iterations run (sih_fields_get_start; complete at sih_fields_get_finish or at the next sih_fields_get_start).
+extern "C" int sih_evp_run_early_outputs(sih_ctx *c, int nFields, const char *const *names, void *const *hosts,
+                                         const size_t *counts)
+{
+    return evpRun(c, nFields, names, hosts, counts);
 }
 
 static int ensureEvents(sih_ctx *c, size_t n)

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 #include "sih_internal.h"
 
@@ -457,6 +458,16 @@ extern "C" int sih_block_destroy(sih_ctx *c)
             for (int b = 0; b < 2; b++)
                 if (kv.second.d_base[a][b]) (void)hipFree(kv.second.d_base[a][b]);
     }
+    if (c->copyStream) {
+        (void)hipStreamSynchronize(c->copyStream);
+        (void)hipStreamDestroy(c->copyStream);
+    }
+    if (c->evCopyFrom) (void)hipEventDestroy(c->evCopyFrom);
+    if (c->evCopyGot) (void)hipEventDestroy(c->evCopyGot);
+    if (c->d_stageCopy) (void)hipFree(c->d_stageCopy);
+    if (c->h_stageCopy) (void)hipHostFree(c->h_stageCopy);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (hipEvent_t e : c->stageEvents) (void)hipEventDestroy(e);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     if (c->counted) g_liveCtx[c->device]--;
     delete c;
@@ -524,6 +535,134 @@ extern "C" size_t sih_field_count(sih_ctx *c, const char *name, int *elemSize)
     return (size_t)f->lead * locCount(c, f->loc);
 }
 
+// whether the runtime knows the host address as page-locked memory (hipHostMalloc, hipHostRegister)
+static bool isPageLocked(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // an address the runtime has never seen is no error here
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+// dst[k] <- base + off[k] (toUser) or the other way, len[k] bytes each, in pieces of 2 MiB dealt to up to eight
+// threads (one core moves about 10 GB/s, the DMA beside it 50)
+static void hostCopyParallel(const std::vector<void *> &dst, const char *base, const std::vector<size_t> &off,
+                             const std::vector<size_t> &len, bool toUser = true)
+{
+    struct Piece { char *d; const char *s; size_t n; };
+    std::vector<Piece> pieces;
+    const size_t chunk = (size_t)2 << 20;
+    for (size_t k = 0; k < dst.size(); k++)
+        for (size_t o = 0; o < len[k]; o += chunk) {
+            char *u = (char *)dst[k] + o, *l = const_cast<char *>(base) + off[k] + o;
+            pieces.push_back({toUser ? u : l, toUser ? l : u, std::min(chunk, len[k] - o)});
+        }
+    unsigned nThreads = std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char *e = getenv("SIH_COPY_THREADS")) nThreads = (unsigned)std::max(1, atoi(e));
+    nThreads = (unsigned)std::min<size_t>(nThreads, std::max<size_t>(pieces.size(), 1));
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (size_t i = next.fetch_add(1); i < pieces.size(); i = next.fetch_add(1)) memcpy(pieces[i].d, pieces[i].s, pieces[i].n);
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nThreads; t++) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+}
+
+// true if host array k begins off[k] bytes after host array 0 for every k: the batch is one piece of host memory laid
+// out like the staging buffer (the padding between two fields then belongs to the host's arena as well)
+static bool hostsFollowStageLayout(int nf, void *const *hosts, const std::vector<size_t> &off)
+{
+    if (nf < 2) return false;
+    for (int k = 1; k < nf; k++)
+        if ((const char *)hosts[k] != (const char *)hosts[0] + off[k]) return false;
+    return true;
+}
+
+static void launchLayout(sih_ctx *c, SihField *f, char *stage, bool put, hipStream_t st)
+{
+    const int n = locCount(c, f->loc), pad = locPad(c, f->loc), L = f->lead;
+    const int *perm = c->renumber ? locPerm(c, f->loc) : nullptr;
+    const long total = (long)n * L;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (put) {
+        if (f->isInt)
+            hipLaunchKernelGGL(k_put<int>, grid, block, 0, st, (int *)f->d, (const int *)stage, perm, n, L, pad);
+        else
+            hipLaunchKernelGGL(k_put<double>, grid, block, 0, st, (double *)f->d, (const double *)stage, perm, n, L, pad);
+    } else {
+        if (f->isInt)
+            hipLaunchKernelGGL(k_get<int>, grid, block, 0, st, (int *)stage, (const int *)f->d, perm, n, L, pad);
+        else
+            hipLaunchKernelGGL(k_get<double>, grid, block, 0, st, (double *)stage, (const double *)f->d, perm, n, L, pad);
+    }
+}
+
+// putgetMany for host arrays that are not page-locked (see there)
+static int putgetStaged(sih_ctx *c, int nf, const std::vector<SihField *> &fs, void *const *hosts, const size_t *counts,
+                        const std::vector<size_t> &off, bool put)
+{
+    if (c->hStageBytes < off[nf]) {
+        if (c->h_stage) HIPCHK(hipHostFree(c->h_stage));
+        c->h_stage = nullptr;
+        c->hStageBytes = 0;
+        HIPCHK(hipHostMalloc(&c->h_stage, off[nf], hipHostMallocPortable));
+        c->hStageBytes = off[nf];
+    }
+    // groups of consecutive fields of about 16 MiB
+    std::vector<int> first{0};
+    for (int k = 0; k < nf; k++)
+        if (off[k + 1] - off[first.back()] >= ((size_t)16 << 20) && k + 1 < nf) first.push_back(k + 1);
+    first.push_back(nf);
+    const int nG = (int)first.size() - 1;
+    while ((int)c->stageEvents.size() < nG) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->stageEvents.push_back(e);
+    }
+    auto group = [&](int g, std::vector<void *> &dst, std::vector<size_t> &o, std::vector<size_t> &len) {
+        dst.clear();
+        o.clear();
+        len.clear();
+        for (int k = first[g]; k < first[g + 1]; k++) {
+            dst.push_back(hosts[k]);
+            o.push_back(off[k]);
+            len.push_back(counts[k] * (fs[k]->isInt ? 4 : 8));
+        }
+    };
+    std::vector<void *> dst;
+    std::vector<size_t> o, len;
+    if (put) {
+        for (int g = 0; g < nG; g++) {
+            group(g, dst, o, len);
+            hostCopyParallel(dst, (const char *)c->h_stage, o, len, false);  // host arrays -> page-locked buffer
+            const size_t b0 = off[first[g]], b1 = off[first[g + 1]];
+            HIPCHK(hipMemcpyAsync((char *)c->d_stage + b0, (char *)c->h_stage + b0, b1 - b0, hipMemcpyHostToDevice, c->stream));
+            for (int k = first[g]; k < first[g + 1]; k++) launchLayout(c, fs[k], (char *)c->d_stage + off[k], true, c->stream);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return SIH_OK;
+    }
+    for (int g = 0; g < nG; g++) {
+        for (int k = first[g]; k < first[g + 1]; k++) launchLayout(c, fs[k], (char *)c->d_stage + off[k], false, c->stream);
+        HIPCHK(hipGetLastError());
+        const size_t b0 = off[first[g]], b1 = off[first[g + 1]];
+        HIPCHK(hipMemcpyAsync((char *)c->h_stage + b0, (char *)c->d_stage + b0, b1 - b0, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipEventRecord(c->stageEvents[g], c->stream));
+    }
+    for (int g = 0; g < nG; g++) {
+        HIPCHK(hipEventSynchronize(c->stageEvents[g]));
+        group(g, dst, o, len);
+        hostCopyParallel(dst, (const char *)c->h_stage, o, len, true);  // page-locked buffer -> host arrays
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SIH_OK;
+}
+
 // One or many fields between host arrays and the device planes.  Every field gets its own 256-byte
 // aligned region of the staging buffer, so all copies and all layout kernels of a batch are queued
 // back to back and the stream is waited for once at the end.
@@ -557,6 +696,25 @@ static int putgetMany(sih_ctx *c, int nf, const char *const *names, void *const 
     HIPCHK(hipSetDevice(c->device));
     int rc = ensureStage(c, off[nf]);
     if (rc) return rc;
+    {
+        // Ordinary (pageable) host arrays, as a host model's framework allocates them: the runtime would stage every copy
+        // itself, at a third of the link's rate on the way down.  A batch of some size goes through the library's own
+        // page-locked buffer instead, in groups of fields, with the DMA of one group beside the threads that move the
+        // group before (down) or after (up) it between that buffer and the host arrays.
+        static const bool staged = [] {
+            const char *e = getenv("SIH_STAGE_PAGEABLE");
+            return !(e && atoi(e) == 0);
+        }();
+        bool pageable = false;
+        for (int k = 0; k < nf && !pageable; k++) pageable = !isPageLocked(hosts[k]);
+        if (staged && pageable && off[nf] >= ((size_t)4 << 20)) return putgetStaged(c, nf, fs, hosts, counts, off, put);
+    }
+    // A host that keeps the fields of a batch in one arena, each at the next multiple of 256 bytes -- the layout of
+    // the staging buffer -- gets one copy for the whole batch instead of one per field (a copy costs 10-20 us before
+    // its first byte moves).
+    const bool oneCopy = hostsFollowStageLayout(nf, hosts, off);
+    if (put && oneCopy) HIPCHK(hipMemcpyAsync(c->d_stage, hosts[0], off[nf - 1] + counts[nf - 1] * (fs[nf - 1]->isInt ? 4 : 8),
+                                              hipMemcpyHostToDevice, c->stream));
     for (int k = 0; k < nf; k++) {
         SihField *f = fs[k];
         int n = locCount(c, f->loc), pad = locPad(c, f->loc), L = f->lead;
@@ -566,7 +724,7 @@ static int putgetMany(sih_ctx *c, int nf, const char *const *names, void *const 
         long total = (long)n * L;
         dim3 grid((unsigned)((total + 255) / 256)), block(256);
         if (put) {
-            HIPCHK(hipMemcpyAsync(stage, hosts[k], bytes, hipMemcpyHostToDevice, c->stream));
+            if (!oneCopy) HIPCHK(hipMemcpyAsync(stage, hosts[k], bytes, hipMemcpyHostToDevice, c->stream));
             if (f->isInt)
                 hipLaunchKernelGGL(k_put<int>, grid, block, 0, c->stream, (int *)f->d, (const int *)stage, perm, n, L, pad);
             else
@@ -581,12 +739,131 @@ static int putgetMany(sih_ctx *c, int nf, const char *const *names, void *const 
         }
         HIPCHK(hipGetLastError());
     }
-    if (!put)
-        for (int k = 0; k < nf; k++)
-            HIPCHK(hipMemcpyAsync(hosts[k], (char *)c->d_stage + off[k], counts[k] * (fs[k]->isInt ? 4 : 8),
+    if (!put) {
+        if (oneCopy)
+            HIPCHK(hipMemcpyAsync(hosts[0], c->d_stage, off[nf - 1] + counts[nf - 1] * (fs[nf - 1]->isInt ? 4 : 8),
                                   hipMemcpyDeviceToHost, c->stream));
+        else
+            for (int k = 0; k < nf; k++)
+                HIPCHK(hipMemcpyAsync(hosts[k], (char *)c->d_stage + off[k], counts[k] * (fs[k]->isInt ? 4 : 8),
+                                      hipMemcpyDeviceToHost, c->stream));
+    }
     // the staging buffer is reused by the next call, and the caller owns the host arrays again
     HIPCHK(hipStreamSynchronize(c->stream));
+    return SIH_OK;
+}
+
+// A download that drains behind the work the host queues next (the advection after the velocity solver, the next
+// step's uploads).  The fields are read by layout kernels on a second stream once everything queued on the context's
+// stream so far is done; the context's stream then waits only for those short kernels, not for the copies to the
+// host, which run by DMA beside whatever is launched next.  The host arrays belong to the library until
+// sih_fields_get_finish returns.  Page-locked host arrays (sih_host_alloc) make the copies truly asynchronous; with
+// ordinary memory the runtime stages them and this call may return only when they are done (still correct).
+extern "C" int sih_fields_get_start(sih_ctx *c, int nf, const char *const *names, void *const *hosts, const size_t *counts)
+{
+    if (!c || nf < 0 || (nf > 0 && (!names || !hosts || !counts))) {
+        sih_set_error("sih_fields_get_start: null argument");
+        return SIH_ERR_ARG;
+    }
+    std::vector<SihField *> fs(nf);
+    std::vector<size_t> off(nf + 1, 0);
+    for (int k = 0; k < nf; k++) {
+        SihField *f = (names[k] && hosts[k]) ? sih_find_field(c, names[k]) : nullptr;
+        if (!f) {
+            sih_set_error(std::string("sih_fields_get_start: unknown field or null array: ") + (names[k] ? names[k] : "(null)"));
+            return SIH_ERR_ARG;
+        }
+        if (counts[k] != (size_t)locCount(c, f->loc) * f->lead) {
+            sih_set_error(std::string("field ") + names[k] + ": element count mismatch");
+            return SIH_ERR_ARG;
+        }
+        fs[k] = f;
+        off[k + 1] = off[k] + ((counts[k] * (f->isInt ? 4 : 8) + 255) & ~(size_t)255);
+    }
+    if (nf == 0) return SIH_OK;
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->copyStream) {
+        HIPCHK(hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->evCopyFrom, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->evCopyGot, hipEventDisableTiming));
+    }
+    // one download at a time: the staging buffer and the host arrays of the previous one must be free
+    HIPCHK(hipStreamSynchronize(c->copyStream));
+    c->copyPending = false;
+    if (c->stageCopyBytes < off[nf]) {
+        if (c->d_stageCopy) HIPCHK(hipFree(c->d_stageCopy));
+        c->d_stageCopy = nullptr;
+        c->stageCopyBytes = 0;
+        HIPCHK(hipMalloc(&c->d_stageCopy, off[nf]));
+        c->stageCopyBytes = off[nf];
+    }
+    HIPCHK(hipEventRecord(c->evCopyFrom, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->copyStream, c->evCopyFrom, 0));
+    for (int k = 0; k < nf; k++) {
+        SihField *f = fs[k];
+        const int n = locCount(c, f->loc), pad = locPad(c, f->loc), L = f->lead;
+        char *stage = (char *)c->d_stageCopy + off[k];
+        const int *perm = c->renumber ? locPerm(c, f->loc) : nullptr;
+        const long total = (long)n * L;
+        dim3 grid((unsigned)((total + 255) / 256)), block(256);
+        if (f->isInt)
+            hipLaunchKernelGGL(k_get<int>, grid, block, 0, c->copyStream, (int *)stage, (const int *)f->d, perm, n, L, pad);
+        else
+            hipLaunchKernelGGL(k_get<double>, grid, block, 0, c->copyStream, (double *)stage, (const double *)f->d, perm, n, L,
+                               pad);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(c->evCopyGot, c->copyStream));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->evCopyGot, 0));  // later work may overwrite the fields: not before they are read
+    c->copyPending = true;
+    c->copyDst.clear();
+    c->copyOff.clear();
+    c->copyLen.clear();
+    bool pageable = false;
+    for (int k = 0; k < nf && !pageable; k++) pageable = !isPageLocked(hosts[k]);
+    if (pageable) {
+        // ordinary host memory: a copy into it is staged by the runtime and holds up the caller.  One DMA into the
+        // library's own page-locked buffer instead; the last hop is made by sih_fields_get_finish.
+        if (c->hStageCopyBytes < off[nf]) {
+            if (c->h_stageCopy) HIPCHK(hipHostFree(c->h_stageCopy));
+            c->h_stageCopy = nullptr;
+            c->hStageCopyBytes = 0;
+            HIPCHK(hipHostMalloc(&c->h_stageCopy, off[nf], hipHostMallocPortable));
+            c->hStageCopyBytes = off[nf];
+        }
+        HIPCHK(hipMemcpyAsync(c->h_stageCopy, c->d_stageCopy, off[nf - 1] + counts[nf - 1] * (fs[nf - 1]->isInt ? 4 : 8),
+                              hipMemcpyDeviceToHost, c->copyStream));
+        for (int k = 0; k < nf; k++) {
+            c->copyDst.push_back(hosts[k]);
+            c->copyOff.push_back(off[k]);
+            c->copyLen.push_back(counts[k] * (fs[k]->isInt ? 4 : 8));
+        }
+        return SIH_OK;
+    }
+    if (hostsFollowStageLayout(nf, hosts, off))
+        HIPCHK(hipMemcpyAsync(hosts[0], c->d_stageCopy, off[nf - 1] + counts[nf - 1] * (fs[nf - 1]->isInt ? 4 : 8),
+                              hipMemcpyDeviceToHost, c->copyStream));
+    else
+        for (int k = 0; k < nf; k++)
+            HIPCHK(hipMemcpyAsync(hosts[k], (char *)c->d_stageCopy + off[k], counts[k] * (fs[k]->isInt ? 4 : 8),
+                                  hipMemcpyDeviceToHost, c->copyStream));
+    return SIH_OK;
+}
+
+// waits for the download sih_fields_get_start began; the host arrays are the caller's again.  No-op without one.
+extern "C" int sih_fields_get_finish(sih_ctx *c)
+{
+    if (!c) return SIH_ERR_ARG;
+    if (!c->copyStream || !c->copyPending) return SIH_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->copyStream));
+    c->copyPending = false;
+    if (!c->copyDst.empty()) {
+        hostCopyParallel(c->copyDst, (const char *)c->h_stageCopy, c->copyOff, c->copyLen);
+        c->copyDst.clear();
+        c->copyOff.clear();
+        c->copyLen.clear();
+    }
     return SIH_OK;
 }
 

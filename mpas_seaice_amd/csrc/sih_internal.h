@@ -92,6 +92,24 @@ struct sih_ctx {
     double *d_rule = nullptr;  // integration rule of the Wachspress integrals
     void *d_stage = nullptr;
     size_t stageBytes = 0;
+    // sih_fields_get_start: a second stream with a staging buffer of its own, so that a download can drain while the
+    // context's stream computes.  evCopyFrom: what the download has to wait for (recorded on the context's stream);
+    // evCopyGot: the layout kernels have read the fields (the context's stream waits for it before it goes on, so
+    // nothing overwrites a field that is still being read); copyPending: copies are in flight into host arrays.
+    hipStream_t copyStream = nullptr;
+    hipEvent_t evCopyFrom = nullptr, evCopyGot = nullptr;
+    void *d_stageCopy = nullptr;
+    size_t stageCopyBytes = 0;
+    bool copyPending = false;
+    // host arrays that are not page-locked: the download goes by DMA into this page-locked buffer of the library and
+    // sih_fields_get_finish copies it on into the host arrays (copyDst, copyOff, copyLen) with a few threads
+    void *h_stage = nullptr;  // the same for the synchronous batched transfers (sih_fields_put / sih_fields_get)
+    size_t hStageBytes = 0;
+    std::vector<hipEvent_t> stageEvents;
+    void *h_stageCopy = nullptr;
+    size_t hStageCopyBytes = 0;
+    std::vector<void *> copyDst;
+    std::vector<size_t> copyOff, copyLen;
     int nSend[2] = {0, 0}, nRecv[2] = {0, 0};
     int *d_send[2] = {nullptr, nullptr}, *d_recv[2] = {nullptr, nullptr};
     // per entry: start offset and length of the neighbour segment it belongs to (send: [0], recv: [1])

@@ -83,6 +83,7 @@ EXPORTS = [
     "sih_comm_handle_size", "sih_comm_create", "sih_comm_get_handle", "sih_comm_connect", "sih_comm_destroy",
     "sih_halo_exchange", "sih_halo_exchange_start", "sih_halo_exchange_finish", "sih_comm_set_timeout",
     "sih_comm_status", "sih_evp_subcycle_exchange", "sih_field_get_noalloc", "sih_device_count", "sih_evp_subcycle_persistent", "sih_evp_subcycle_fused", "sih_column_get", "sih_column_put", "sih_evp_set_persistent",
+    "sih_fields_get_start", "sih_fields_get_finish", "sih_evp_run_early_outputs",
 ]
 
 
@@ -120,7 +121,8 @@ def load():
     lib.sih_field_put.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t]
     lib.sih_field_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t]
     lib.sih_field_get_noalloc.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t]
-    for fn in (lib.sih_fields_put, lib.sih_fields_get):
+    lib.sih_fields_get_finish.argtypes = [ctypes.c_void_p]
+    for fn in (lib.sih_fields_put, lib.sih_fields_get, lib.sih_fields_get_start, lib.sih_evp_run_early_outputs):
         fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
                        ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
     lib.sih_evp_pre_subcycle.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -301,6 +303,20 @@ class BlockContext:
 
     def get_many(self, items):
         self._many(self._lib.sih_fields_get, "sih_fields_get", items)
+
+    def get_many_start(self, items):
+        """the download drains behind whatever is launched next; the arrays are the library's until get_many_finish()"""
+        self._pending_get = [a for _, a in items]  # keep the arrays alive
+        self._many(self._lib.sih_fields_get_start, "sih_fields_get_start", items)
+
+    def evp_run_early_outputs(self, items):
+        """sih_evp_run with the download of `items` (fields final after the pre-cycle) behind the iterations"""
+        self._pending_get = [a for _, a in items]
+        self._many(self._lib.sih_evp_run_early_outputs, "sih_evp_run_early_outputs", items)
+
+    def get_many_finish(self):
+        check(self._lib.sih_fields_get_finish(self.handle), "sih_fields_get_finish")
+        self._pending_get = None
 
     def pre_subcycle(self, stage=-1):
         check(self._lib.sih_evp_pre_subcycle(self.handle, stage), "sih_evp_pre_subcycle")

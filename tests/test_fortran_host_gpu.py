@@ -85,3 +85,13 @@ def test_fortran_host_step_with_transfers_at_qu60(tmp_path):
     lazy = ms["batched calls, page-locked memory, strains and stresses left on the device"]
     assert alone < lazy < batched < per_field
     assert batched <= 14.0, ms  # 7 ms of solver + 69 MB up + 137 MB down over the host link
+    # the downloads behind the computation (sih_evp_run's early outputs, sih_fields_get_start): the same bits in every
+    # array, the solver's call returns sooner, and the whole step (solver + advection, everything delivered) is shorter
+    assert "fields that differ from the plain ones: 0" in out.stdout
+    ret = ms["velocity solver, downloads behind the computation, until it returns"]
+    plain = ms["velocity solver, batched, page-locked, all outputs before it returns"]
+    step_over = ms["velocity solver + advection, downloads behind the computation, all outputs delivered"]
+    step_plain = ms["velocity solver + advection, plain"]
+    keep = ms["velocity solver, downloads behind the computation, solver state kept on the device, until it returns"]
+    assert keep < ret < plain and step_over < step_plain, ms
+    assert ret <= 10.0 and keep <= 9.2, ms

@@ -57,8 +57,9 @@ def _compare(got, ref_block, pairs, worst):
         assert e <= TOL, (pool, name, e)
 
 
-@pytest.mark.parametrize("steps,lazy", [(1, False), (2, False), (2, True)])
-def test_shim_modules_run_velocity_solver_and_incremental_remap(oracle, tmp_path, steps, lazy):
+@pytest.mark.parametrize("steps,lazy,deferred", [(1, False, False), (2, False, False), (2, True, False), (2, False, True),
+                                                 (2, True, True), (3, "keep", True)])
+def test_shim_modules_run_velocity_solver_and_incremental_remap(oracle, tmp_path, steps, lazy, deferred):
     from oracle import ir_flow
     mesh = get_mesh("QU480")
     cfg = {"config_elastic_subcycle_number": 120, "config_conservation_check": True,
@@ -71,7 +72,16 @@ def test_shim_modules_run_velocity_solver_and_incremental_remap(oracle, tmp_path
     for _ in range(steps):
         oracle.seaice_run_velocity_solver(ref)
         ir_flow.seaice_run_advection(ref)
-    out = _harness(case, res, steps, {"SIH_SHIM_LAZY_DIAGNOSTICS": "1"} if lazy else None)
+    # lazy: strains, stresses and replacement pressure stay on the device between steps; deferred: the diagnostics
+    # travel to the pools while the advection computes.  Either way the pools hold everything at the end.
+    env = {}
+    if lazy == "keep":  # the solver's own state (velocities, stresses, ...) is not uploaded again after the first step
+        env["SIH_SHIM_KEEP_STATE"] = "1"
+    elif lazy:
+        env["SIH_SHIM_LAZY_DIAGNOSTICS"] = "1"
+    if deferred:
+        env["SIH_SHIM_DEFERRED_DIAGNOSTICS"] = "1"
+    out = _harness(case, res, steps, env)
     got = fortran_case.read_pools(res)
     worst = {}
     rb = ref.blocklist[0]
