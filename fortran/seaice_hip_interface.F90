@@ -58,7 +58,31 @@ module seaice_hip_interface
      integer(c_int32_t) :: nCategories, rotateCartesianGrid
   end type sih_ir_desc
 
+  ! sih_ridge_config of seaice_hip.h: the arguments of colpkg_step_ridge that are not fields
+  type, bind(C) :: sih_ridge_config
+     real(c_double)     :: dt
+     integer(c_int32_t) :: dynamicsSubcycleNumber
+     integer(c_int32_t) :: participation, redistribution   ! 0 Thorndike75 / Hibler80, 1 exponential
+     real(c_double)     :: efoldingScale
+     integer(c_int32_t) :: nCategories
+     type(c_ptr)        :: categoryThicknessLimits        ! nCategories + 1 doubles
+  end type sih_ridge_config
+
   interface
+
+     function sih_column_ridge_init(ctx, nCategories) bind(C, name="sih_column_ridge_init") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nCategories
+       integer(c_int) :: ierr
+     end function sih_column_ridge_init
+
+     function sih_column_ridge(ctx, cfg) bind(C, name="sih_column_ridge") result(ierr)
+       import :: c_int, c_ptr, sih_ridge_config
+       type(c_ptr), value :: ctx
+       type(sih_ridge_config), intent(in) :: cfg
+       integer(c_int) :: ierr
+     end function sih_column_ridge
 
      function sih_block_create(mesh, device, ctx) bind(C, name="sih_block_create") result(ierr)
        import :: sih_mesh_desc, c_int, c_ptr

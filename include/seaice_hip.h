@@ -46,7 +46,8 @@ enum {
     SIH_ERR_STATE = 3,      /* call out of order (e.g. run before init) */
     SIH_ERR_UNSUPPORTED = 4, /* option of the reference that is outside this library's scope */
     SIH_ERR_IR = 5,         /* a run-time abort of the advection (negative mass / area, degenerate geometry) */
-    SIH_ERR_COMM = 6        /* a neighbour's halo message did not arrive within the time limit */
+    SIH_ERR_COMM = 6,       /* a neighbour's halo message did not arrive within the time limit */
+    SIH_ERR_COLUMN = 7      /* a run-time abort of the column package's ridging (its l_stop with stop_label) */
 };
 
 /* Mesh description of one block: the `mesh` pool fields the dynamics read
@@ -250,6 +251,38 @@ int sih_column_get(sih_ctx *ctx, int nFields, const char *const *names, int nCat
                    double *host, size_t count);
 int sih_column_put(sih_ctx *ctx, int nFields, const char *const *names, int nCategories, int firstCell, int nCells,
                    const double *host, size_t count);
+/* The ridging itself on the device: ridge_ice (src/column/ice_mechred.F90:80-597, with ridge_prep :640, ridge_itd
+ * :741, ridge_shift :1030 and colpkg_compute_tracers, src/column/ice_colpkg_tracers.F90:163) for every owned cell, as
+ * column_ridging runs it through colpkg_step_ridge (src/shared/mpas_seaice_column.F:3468-3530,
+ * src/column/ice_colpkg.F90:3296-3325).  Works on the device fields of the advected tracers (sih_ir_set_tracers must
+ * have been called: iceAreaCategory, iceVolumeCategory, snowVolumeCategory and every tracer carried on one of them --
+ * surfaceTemperature, iceEnthalpy, iceSalinity, snowEnthalpy of the standard physics; a tracer carried on another
+ * tracer returns SIH_ERR_UNSUPPORTED) and on these cell fields, which the call creates if they do not exist yet:
+ *   in:     ridgeConvergence ridgeShear (left by the velocity solver with config_use_column_package)
+ *           seaFreezingTemperature (ocean_coupling pool)
+ *   in/out: openWaterArea (icestate)  oceanFreshWaterFlux oceanHeatFlux (ocean_fluxes)
+ *           fractionNewRidgeArea fractionNewRidgeVolume (nCategories,nCells; ridging pool)
+ *   out:    areaLossRidge areaGainRidge iceVolumeRidged openingRateRidge (nCells), ridgeParticipationFunction
+ *           ratioRidgeThicknessToIce areaLossRidgeCategory areaGainRidgeCategory iceVolumeRidgedCategory raftingIceArea
+ *           raftingIceVolume (nCategories,nCells)
+ * so that velocity solver -> advection -> ridging -> next velocity solver runs without a copy to the host.  Where the
+ * reference sets l_stop the call returns SIH_ERR_COLUMN with the reference's stop_label as the message
+ * ("Ridging error: aice0 < 0", "Ridging error: ardg > aicen", "ridge_ice: Exceeded max number of ridging iterations",
+ * "ridge_ice: total area > 1").  Not included: the ITD clean-up that colpkg_step_ridge runs afterwards (cleanup_itd,
+ * src/column/ice_itd.F90:754), which stays with the host's column package. */
+typedef struct {
+    double dt;                  /* dynamicsTimeStep */
+    int32_t dynamicsSubcycleNumber; /* config_dynamics_subcycle_number (ndtd: the fluxes are averaged over the thermodynamic step) */
+    int32_t participation;      /* config_ridging_participation_function: 0 Thorndike75, 1 exponential */
+    int32_t redistribution;     /* config_ridging_redistribution_function: 0 Hibler80, 1 exponential */
+    double efoldingScale;       /* config_ridiging_efolding_scale (mu_rdg) */
+    int32_t nCategories;
+    const double *categoryThicknessLimits; /* hin_max(0:nCategories) of the `initial` pool, host memory */
+} sih_ridge_config;
+int sih_column_ridge(sih_ctx *ctx, const sih_ridge_config *cfg);
+/* creates the cell fields listed above (zero-filled) without running anything, so that a host can put its ocean state
+ * and accumulated fluxes before the first sih_column_ridge */
+int sih_column_ridge_init(sih_ctx *ctx, int nCategories);
 /* sih_field_get for callers that cannot allocate: code under HIP graph capture elsewhere in the process, tight
  * serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  The layout conversion is
  * staged in a 16 MiB array that is part of the library's code object on every GPU, so the call makes no

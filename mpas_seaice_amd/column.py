@@ -1,0 +1,66 @@
+"""Host mirror of the column package's part of the dynamics step, for what this library runs on the device:
+``seaice_column_dynamics_time_integration`` (/root/reference/src/shared/mpas_seaice_column.F:1139-1194) ->
+``column_ridging`` (:3283-3556) -> ``colpkg_step_ridge`` -> ``ridge_ice``
+(/root/reference/src/column/ice_mechred.F90:80-597).
+
+The ridging works on the device fields of the advected tracers, so that between the advection and the next velocity
+solve nothing has to visit the host.  Scope and limits: see ``sih_column_ridge`` in include/seaice_hip.h (standard
+physics tracers, no strata; the ITD clean-up of colpkg_step_ridge is not included)."""
+from __future__ import annotations
+
+from . import pools
+from .lib import SeaiceHipError
+
+PARTICIPATION = {"Thorndike75": 0, "exponential": 1}
+REDISTRIBUTION = {"Hibler80": 0, "exponential": 1}
+INPUT_FIELDS = (("ridging", "ridgeConvergence"), ("ridging", "ridgeShear"), ("icestate", "openWaterArea"),
+                ("ocean_coupling", "seaFreezingTemperature"), ("ocean_fluxes", "oceanFreshWaterFlux"),
+                ("ocean_fluxes", "oceanHeatFlux"), ("ridging", "fractionNewRidgeArea"),
+                ("ridging", "fractionNewRidgeVolume"))
+OUTPUT_FIELDS = (("icestate", "openWaterArea"), ("ocean_fluxes", "oceanFreshWaterFlux"), ("ocean_fluxes", "oceanHeatFlux")) \
+    + tuple(("ridging", k) for k in pools.RIDGING_CELL_FIELDS + pools.RIDGING_CATEGORY_FIELDS)
+
+
+def column_ridging(domain, upload=True, download=True):
+    """:3283-3556.  ``upload``: True, the tracers and every cell field the ridging reads go from the pools to the device
+    first; "cells", only the cell fields that no device routine computes (ocean state, accumulated fluxes, open water,
+    the fractions of the last ridging): for a host that has just run velocity solver and advection on the device;
+    False, nothing: the device holds what the ridging before this one left (open water, fluxes accumulated so far).
+    ``download``: tracers, open water, fluxes and diagnostics come back."""
+    cfg = domain.configs
+    for key, table in (("config_ridging_participation_function", PARTICIPATION),
+                       ("config_ridging_redistribution_function", REDISTRIBUTION)):
+        if cfg[key] not in table:
+            raise SeaiceHipError(f"{key} unknown: {cfg[key]}")
+    names = [t.tracerName for t in domain.solver_state["tracersHead"]]
+    for b in domain.blocklist:
+        pools.allocate_ridging_pools(b)
+        tp = b.structs["tracers"]
+        dt = float(b.structs["velocity_solver"]["dynamicsTimeStep"][0])
+        limits = b.structs["initial"]["categoryThicknessLimits"]
+        # the fields only the host knows (ocean state, accumulated fluxes, open water); the rates of the velocity
+        # solver and the tracers are on the device already unless the caller says otherwise
+        b.ctx.ridge_prepare_fields(b.dimensions["nCategories"])
+        items = []
+        if upload is True:
+            items = [(n, b.structs[p][n]) for p, n in INPUT_FIELDS] + [(n, tp[n]) for n in names]
+        elif upload == "cells":
+            items = [(n, b.structs[p][n]) for p, n in INPUT_FIELDS if n not in ("ridgeConvergence", "ridgeShear")]
+        if items:
+            b.ctx.put_many(items)
+        b.ctx.column_ridge(dt, int(cfg["config_dynamics_subcycle_number"]),
+                           PARTICIPATION[cfg["config_ridging_participation_function"]],
+                           REDISTRIBUTION[cfg["config_ridging_redistribution_function"]],
+                           float(cfg["config_ridiging_efolding_scale"]), limits)
+        limits[-1] = 1.0e8  # ridge_prep writes it into the host's array (ice_mechred.F90:675)
+        domain.solver_state["ridge_iterations"] = int(b.ctx.info("ridgeIterations"))
+        if download:
+            b.ctx.get_many([(n, tp[n]) for n in names] + [(n, b.structs[p][n]) for p, n in OUTPUT_FIELDS])
+
+
+def seaice_column_dynamics_time_integration(domain, upload=True, download=True):
+    """:1139-1194, the ridging part (column_combine_snow_ice_tracers and seaice_column_update_state belong to column
+    physics options outside this library)"""
+    cfg = domain.configs
+    if cfg["config_use_column_package"] and cfg.get("config_use_column_ridging", True):
+        column_ridging(domain, upload=upload, download=download)

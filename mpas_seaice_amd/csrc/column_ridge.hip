@@ -1,0 +1,563 @@
+// Mechanical redistribution (ridging) of the column package on the device: ridge_ice of
+// src/column/ice_mechred.F90:80-597 with asum_ridging :609, ridge_prep :640, ridge_itd :741, ridge_shift :1030 and
+// colpkg_compute_tracers (src/column/ice_colpkg_tracers.F90:163-254), run for every owned cell as column_ridging does
+// (src/shared/mpas_seaice_column.F:3468-3530 -> colpkg_step_ridge, src/column/ice_colpkg.F90:3296-3325).
+//
+// One thread per owned cell.  The category arrays of a cell (areas, volumes, participation, ridge thicknesses) live
+// in the thread; the tracers stay where the advection left them, in the planes of the device fields (plane =
+// category * layers + layer, the cell index fastest), so a wave reads and writes every plane as one coalesced
+// stream, and nothing is gathered into per-cell records.  The products area*tracer / volume*tracer that ridge_shift
+// keeps while it moves ice between categories (atrcrn, :1151) are a scratch field of the same shape.
+//
+// Scope: tracers without strata (n_trcr_strata = 0): every advected tracer other than the ice area and the two
+// volumes must have the ice area, the ice volume or the snow volume as its parent -- the standard physics set
+// (surface temperature, ice enthalpy, ice salinity, snow enthalpy).  Tracers carried on other tracers (ponds, brine,
+// level ice, aerosols: the strata branches :1206-1211, :1389-1394, :1508-1517) are refused.  The module's
+// l_conservation_check is .false. (:64).  The ITD clean-up that colpkg_step_ridge runs after ridge_ice (cleanup_itd,
+// src/column/ice_itd.F90:754) is not here.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sih_internal.h"
+
+#define RIDGE_MAXCAT 10
+#define RIDGE_MAXTR 48
+
+struct RidgeTracer {
+    double *val;  // plane 0 of the field
+    int L, layer, depend;
+};
+
+struct RidgeDev {
+    int nCellsSolve, padC, ncat, ntrcr, nslyr, ntTsfc, ntQsno, krdgPartic, krdgRedist, ndtd;
+    double dt, muRdg;
+    double hinMax[RIDGE_MAXCAT + 1];
+    double *aicen, *vicen, *vsnon, *aice0, *atrcrn;
+    const double *rdgConv, *rdgShear, *Tf;
+    double *dardg1dt, *dardg2dt, *dvirdgdt, *opening, *fresh, *fhocn;
+    double *aparticn, *krdgn, *aredistn, *vredistn, *dardg1ndt, *dardg2ndt, *dvirdgndt, *araftn, *vraftn;
+    int *flag;  // [0] highest stop code of any cell, [1] most iterations of any cell
+    RidgeTracer tr[RIDGE_MAXTR];
+};
+
+struct sih_ridge_state {
+    double *atrcrn = nullptr;
+    int planes = 0;
+    int *d_flag = nullptr;
+    int lastIterations = 0;
+};
+
+void sih_ridge_destroy(sih_ctx *c)
+{
+    if (!c->ridge) return;
+    if (c->ridge->d_flag) (void)hipFree(c->ridge->d_flag);
+    delete c->ridge;
+    c->ridge = nullptr;
+}
+
+#define PUNY 1.0e-11
+// ice_mechred.F90:51-61, ice_constants_colpkg.F90:24
+#define RDG_CS 0.25
+#define RDG_FSNOW 0.5
+#define RDG_GSTAR 0.15
+#define RDG_ASTAR 0.05
+#define RDG_MAXRAFT 1.0
+#define RDG_HSTAR 25.0
+#define RDG_RHOS 330.0
+
+// category arrays are 1-based (index 0 of apartic is the open water), as in the reference
+template <int NC>
+struct RidgeCell {
+    double aicen[NC + 1], vicen[NC + 1], vsnon[NC + 1];
+    double apartic[NC + 1], hrmin[NC + 1], hrmax[NC + 1], hrexp[NC + 1], krdg[NC + 1];
+    double ardg1n[NC + 1], ardg2n[NC + 1], virdgn[NC + 1], mraftn[NC + 1], aredistn[NC + 1], vredistn[NC + 1];
+};
+
+// ridge_itd :741-1012
+template <int NC>
+__device__ void ridgeItd(const RidgeDev &d, int ncat, double aice0, RidgeCell<NC> &s, double &aksum)
+{
+    const double Gstari = 1.0 / RDG_GSTAR, astari = 1.0 / RDG_ASTAR;
+    double GsumA[NC + 2];
+    double *Gsum = GsumA + 1;
+    Gsum[-1] = 0.0;
+    Gsum[0] = aice0 > PUNY ? aice0 : Gsum[-1];
+    s.apartic[0] = 0.0;
+    for (int n = 1; n <= ncat; n++) {
+        Gsum[n] = 1.0;
+        s.apartic[n] = 0.0;
+        s.hrmin[n] = 0.0;
+        s.hrmax[n] = 0.0;
+        s.hrexp[n] = 0.0;
+        s.krdg[n] = 1.0;
+        if (s.aicen[n] > PUNY)
+            Gsum[n] = Gsum[n - 1] + s.aicen[n];
+        else
+            Gsum[n] = Gsum[n - 1];
+    }
+    const double work = 1.0 / Gsum[ncat];
+    for (int n = 0; n <= ncat; n++) Gsum[n] = Gsum[n] * work;
+    if (d.krdgPartic == 0) {
+        for (int n = 0; n <= ncat; n++) {
+            if (Gsum[n] < RDG_GSTAR)
+                s.apartic[n] = Gstari * (Gsum[n] - Gsum[n - 1]) * (2.0 - Gstari * (Gsum[n - 1] + Gsum[n]));
+            else if (Gsum[n - 1] < RDG_GSTAR)
+                s.apartic[n] = Gstari * (RDG_GSTAR - Gsum[n - 1]) * (2.0 - Gstari * (RDG_GSTAR + Gsum[n - 1]));
+        }
+    } else {
+        const double xtmp = 1.0 / (1.0 - exp(-astari));
+        Gsum[-1] = exp(-Gsum[-1] * astari) * xtmp;
+        for (int n = 0; n <= ncat; n++) {
+            Gsum[n] = exp(-Gsum[n] * astari) * xtmp;
+            s.apartic[n] = Gsum[n - 1] - Gsum[n];
+        }
+    }
+    if (d.krdgRedist == 0) {
+        for (int n = 1; n <= ncat; n++)
+            if (s.aicen[n] > PUNY) {
+                const double hi = s.vicen[n] / s.aicen[n];
+                s.hrmin[n] = fmin(2.0 * hi, hi + RDG_MAXRAFT);
+                s.hrmax[n] = 2.0 * sqrt(RDG_HSTAR * hi);
+                s.hrmax[n] = fmax(s.hrmax[n], s.hrmin[n] + PUNY);
+                const double hrmean = 0.5 * (s.hrmin[n] + s.hrmax[n]);
+                s.krdg[n] = hrmean / hi;
+            }
+    } else {
+        for (int n = 1; n <= ncat; n++)
+            if (s.aicen[n] > PUNY) {
+                double hi = s.vicen[n] / s.aicen[n];
+                hi = fmax(hi, PUNY);
+                s.hrmin[n] = fmin(2.0 * hi, hi + RDG_MAXRAFT);
+                s.hrexp[n] = d.muRdg * sqrt(hi);
+                s.krdg[n] = (s.hrmin[n] + s.hrexp[n]) / hi;
+                s.mraftn[n] = fmax(0.0, copysign(1.0, hi + RDG_MAXRAFT - s.hrmin[n]));  // :976-980
+                const double xtmp = s.mraftn[n] * ((2.0 * hi + s.hrexp[n]) / hi - s.krdg[n]);
+                s.mraftn[n] = fmax(0.0, copysign(1.0, PUNY - fabs(xtmp)));
+            }
+    }
+    aksum = s.apartic[0];
+    for (int n = 1; n <= ncat; n++) aksum = aksum + s.apartic[n] * (1.0 - 1.0 / s.krdg[n]);
+}
+
+__device__ inline double &trc(const RidgeDev &d, int it, int n, int cell)  // trcrn(it, n), n = 1 .. ncat
+{
+    const RidgeTracer &t = d.tr[it];
+    return t.val[((size_t)(n - 1) * t.L + t.layer) * d.padC + cell];
+}
+__device__ inline double &atr(const RidgeDev &d, int it, int n, int cell)  // atrcrn(it, n)
+{
+    return d.atrcrn[((size_t)it * d.ncat + (n - 1)) * d.padC + cell];
+}
+
+// ridge_shift :1030-1541; returns the number of the reference's stop (1 'aice0 < 0', 2 'ardg > aicen') or 0
+template <int NC>
+__device__ int ridgeShift(const RidgeDev &d, int ncat, int cell, RidgeCell<NC> &s, double &aice0, double aksum,
+                          double closing_net, double &opning, double &ardg1, double &ardg2, double &virdg, double &aopen,
+                          double &msnow_mlt, double &esnow_mlt, double Tf)
+{
+    double aicen_init[NC + 1], vicen_init[NC + 1], vsnon_init[NC + 1];
+    const int ntrcr = d.ntrcr;
+    const double dt = d.dt;
+    for (int n = 1; n <= ncat; n++) {
+        aicen_init[n] = s.aicen[n];
+        vicen_init[n] = s.vicen[n];
+        vsnon_init[n] = s.vsnon[n];
+        for (int it = 0; it < ntrcr; it++) {
+            const int dep = d.tr[it].depend;
+            const double b1 = dep == 0, b2 = dep == 1, b3 = dep == 2;
+            atr(d, it, n, cell) = trc(d, it, n, cell) * (b1 * s.aicen[n] + b2 * s.vicen[n] + b3 * s.vsnon[n]);
+        }
+    }
+    double closing_gross = closing_net / aksum;
+    if (s.apartic[0] > 0.0) {
+        const double wk1 = s.apartic[0] * closing_gross * dt;
+        if (wk1 > aice0) {
+            const double tmpfac = aice0 / wk1;
+            closing_gross = closing_gross * tmpfac;
+            opning = opning * tmpfac;
+        }
+    }
+    for (int n = 1; n <= ncat; n++)
+        if (s.aicen[n] > PUNY && s.apartic[n] > 0.0) {
+            const double wk1 = s.apartic[n] * closing_gross * dt;
+            if (wk1 > s.aicen[n]) {
+                const double tmpfac = s.aicen[n] / wk1;
+                closing_gross = closing_gross * tmpfac;
+                opning = opning * tmpfac;
+            }
+        }
+    aice0 = aice0 - s.apartic[0] * closing_gross * dt + opning * dt;
+    if (aice0 < -PUNY)
+        return 1;
+    else if (aice0 < 0.0)
+        aice0 = 0.0;
+    aopen = opning * dt;
+
+    for (int n = 1; n <= ncat; n++) {
+        if (aicen_init[n] > PUNY && s.apartic[n] > 0.0 && closing_gross > 0.0) {
+            double ardg1n = s.apartic[n] * closing_gross * dt;
+            if (ardg1n > aicen_init[n] + PUNY)
+                return 2;
+            else
+                ardg1n = fmin(aicen_init[n], ardg1n);
+            const double ardg2n = ardg1n / s.krdg[n];
+            const double afrac = ardg1n / aicen_init[n];
+            const double virdgn = vicen_init[n] * afrac;
+            const double vsrdgn = vsnon_init[n] * afrac;
+            s.aicen[n] = s.aicen[n] - ardg1n;
+            s.vicen[n] = s.vicen[n] - virdgn;
+            s.vsnon[n] = s.vsnon[n] - vsrdgn;
+            ardg1 = ardg1 + ardg1n;
+            ardg2 = ardg2 + ardg2n;
+            virdg = virdg + virdgn;
+            s.ardg1n[n] = ardg1n;
+            s.ardg2n[n] = ardg2n;
+            s.virdgn[n] = virdgn;
+            msnow_mlt = msnow_mlt + RDG_RHOS * vsrdgn * (1.0 - RDG_FSNOW);
+            const double dhr = s.hrmax[n] - s.hrmin[n];
+            const double dhr2 = s.hrmax[n] * s.hrmax[n] - s.hrmin[n] * s.hrmin[n];
+            if (d.ntQsno >= 0)
+                for (int k = 1; k <= d.nslyr; k++) {
+                    const double esrdgn = vsrdgn * trc(d, d.ntQsno + k - 1, n, cell) / (double)d.nslyr;
+                    esnow_mlt = esnow_mlt + esrdgn * (1.0 - RDG_FSNOW);
+                }
+            for (int it = 0; it < ntrcr; it++) {
+                const int dep = d.tr[it].depend;
+                const double f1 = (dep == 0 ? 1.0 : 0.0) * ardg1n, f2 = (dep == 1 ? 1.0 : 0.0) * virdgn,
+                             f3 = (dep == 2 ? 1.0 : 0.0) * vsrdgn;
+                const double tv = trc(d, it, n, cell);
+                double work = 0.0;
+                work = work + f1 * tv;
+                work = work + f2 * tv;
+                work = work + f3 * tv;
+                atr(d, it, n, cell) = atr(d, it, n, cell) - work;
+            }
+            for (int nr = 1; nr <= ncat; nr++) {
+                double farea, fvol, hL, hR;
+                if (d.krdgRedist == 0) {
+                    if (s.hrmin[n] >= d.hinMax[nr] || s.hrmax[n] <= d.hinMax[nr - 1]) {
+                        hL = 0.0;
+                        hR = 0.0;
+                    } else {
+                        hL = fmax(s.hrmin[n], d.hinMax[nr - 1]);
+                        hR = fmin(s.hrmax[n], d.hinMax[nr]);
+                    }
+                    farea = (hR - hL) / dhr;
+                    fvol = (hR * hR - hL * hL) / dhr2;
+                } else {
+                    const double hi1 = s.hrmin[n], hexp = s.hrexp[n];
+                    if (nr < ncat) {
+                        if (hi1 >= d.hinMax[nr]) {
+                            farea = 0.0;
+                            fvol = 0.0;
+                        } else {
+                            hL = fmax(hi1, d.hinMax[nr - 1]);
+                            hR = d.hinMax[nr];
+                            const double expL = exp(-(hL - hi1) / hexp);
+                            const double expR = exp(-(hR - hi1) / hexp);
+                            farea = expL - expR;
+                            fvol = ((hL + hexp) * expL - (hR + hexp) * expR) / (hi1 + hexp);
+                        }
+                    } else {
+                        hL = fmax(hi1, d.hinMax[nr - 1]);
+                        const double expL = exp(-(hL - hi1) / hexp);
+                        farea = expL;
+                        fvol = (hL + hexp) * expL / (hi1 + hexp);
+                    }
+                    if (n == 1) {  // diagnostics of the thinnest ridging ice :1462-1469
+                        s.aredistn[nr] = farea * ardg2n;
+                        s.vredistn[nr] = fvol * virdgn;
+                    }
+                }
+                s.aicen[nr] = s.aicen[nr] + farea * ardg2n;
+                s.vicen[nr] = s.vicen[nr] + fvol * virdgn;
+                s.vsnon[nr] = s.vsnon[nr] + fvol * vsrdgn * RDG_FSNOW;
+                for (int it = 0; it < ntrcr; it++) {
+                    const int dep = d.tr[it].depend;
+                    const double f1 = (dep == 0 ? 1.0 : 0.0) * ardg2n * farea, f2 = (dep == 1 ? 1.0 : 0.0) * virdgn * fvol,
+                                 f3 = (dep == 2 ? 1.0 : 0.0) * vsrdgn * fvol * RDG_FSNOW;
+                    const double tv = trc(d, it, n, cell);
+                    double work = 0.0;
+                    work = work + f1 * tv;
+                    work = work + f2 * tv;
+                    work = work + f3 * tv;
+                    atr(d, it, nr, cell) = atr(d, it, nr, cell) + work;
+                }
+            }
+        }
+    }
+    // colpkg_compute_tracers, ice_colpkg_tracers.F90:216-252 (no strata; the loop over the three divisors keeps the last
+    // positive one, which with a unit trcr_base is the tracer's own base quantity)
+    for (int n = 1; n <= ncat; n++)
+        for (int it = 0; it < ntrcr; it++) {
+            const int dep = d.tr[it].depend;
+            const double a = atr(d, it, n, cell);
+            double v;
+            if (dep == 0) {
+                if (s.aicen[n] > PUNY)
+                    v = a / s.aicen[n];
+                else
+                    v = it == d.ntTsfc ? Tf : 0.0;
+            } else {
+                const double div = dep == 1 ? s.vicen[n] : s.vsnon[n];
+                v = div > 0.0 ? a / div : 0.0;
+            }
+            trc(d, it, n, cell) = v;
+        }
+    return 0;
+}
+
+template <int NC>
+__global__ void __launch_bounds__(128) k_ridge_ice(RidgeDev d)
+{
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= d.nCellsSolve) return;
+    const int ncat = d.ncat, P = d.padC;
+    RidgeCell<NC> s;
+    for (int n = 1; n <= ncat; n++) {
+        s.aicen[n] = d.aicen[(size_t)(n - 1) * P + cell];
+        s.vicen[n] = d.vicen[(size_t)(n - 1) * P + cell];
+        s.vsnon[n] = d.vsnon[(size_t)(n - 1) * P + cell];
+        s.ardg1n[n] = s.ardg2n[n] = s.virdgn[n] = s.mraftn[n] = 0.0;
+        s.aredistn[n] = d.aredistn[(size_t)(n - 1) * P + cell];  // intent(inout): kept where nothing ridges
+        s.vredistn[n] = d.vredistn[(size_t)(n - 1) * P + cell];
+    }
+    double aice0 = d.aice0[cell];
+    const double Tf = d.Tf[cell], dt = d.dt;
+    double msnow_mlt = 0.0, esnow_mlt = 0.0, ardg1 = 0.0, ardg2 = 0.0, virdg = 0.0, aopen = 0.0;
+    // asum_ridging :609-632, ridge_prep :640-722
+    double asum = aice0;
+    for (int n = 1; n <= ncat; n++) asum = asum + s.aicen[n];
+    double closing_net = RDG_CS * d.rdgShear[cell] + d.rdgConv[cell];
+    double divu_adv = (1.0 - asum) / dt;
+    if (divu_adv < 0.0) closing_net = fmax(closing_net, -divu_adv);
+    double opning = closing_net + divu_adv;
+    const int nitermax = 20;
+    int stop = 0, niter;
+    for (niter = 1; niter <= nitermax; niter++) {
+        double aksum;
+        ridgeItd<NC>(d, ncat, aice0, s, aksum);
+        stop = ridgeShift<NC>(d, ncat, cell, s, aice0, aksum, closing_net, opning, ardg1, ardg2, virdg, aopen, msnow_mlt,
+                              esnow_mlt, Tf);
+        if (stop) break;
+        asum = aice0;
+        for (int n = 1; n <= ncat; n++) asum = asum + s.aicen[n];
+        bool iterate;
+        if (fabs(asum - 1.0) < PUNY) {
+            iterate = false;
+            closing_net = 0.0;
+            opning = 0.0;
+        } else {
+            iterate = true;
+            divu_adv = (1.0 - asum) / dt;
+            closing_net = fmax(0.0, -divu_adv);
+            opning = fmax(0.0, divu_adv);
+        }
+        if (!iterate) break;
+        if (niter == nitermax) {
+            stop = 3;
+            break;
+        }
+    }
+    atomicMax(&d.flag[1], niter > nitermax ? nitermax : niter);
+    for (int n = 1; n <= ncat; n++) {
+        const size_t k = (size_t)(n - 1) * P + cell;
+        d.aicen[k] = s.aicen[n];
+        d.vicen[k] = s.vicen[n];
+        d.vsnon[k] = s.vsnon[n];
+        d.aparticn[k] = s.apartic[n];
+        d.krdgn[k] = s.krdg[n];
+        d.aredistn[k] = s.aredistn[n];
+        d.vredistn[k] = s.vredistn[n];
+    }
+    d.aice0[cell] = aice0;
+    if (!stop && fabs(asum - 1.0) > PUNY) stop = 5;  // :576 (after the diagnostics in the reference; they are set below)
+    if (stop && stop != 5) {
+        atomicMax(&d.flag[0], stop);
+        return;
+    }
+    double dti = 1.0 / dt;  // :509-548
+    d.dardg1dt[cell] = ardg1 * dti;
+    d.dardg2dt[cell] = ardg2 * dti;
+    d.dvirdgdt[cell] = virdg * dti;
+    d.opening[cell] = aopen * dti;
+    for (int n = 1; n <= ncat; n++) {
+        const size_t k = (size_t)(n - 1) * P + cell;
+        d.dardg1ndt[k] = s.ardg1n[n] * dti;
+        d.dardg2ndt[k] = s.ardg2n[n] * dti;
+        d.dvirdgndt[k] = s.virdgn[n] * dti;
+        d.araftn[k] = s.mraftn[n] * s.ardg2n[n];
+        d.vraftn[k] = s.mraftn[n] * s.virdgn[n];
+    }
+    dti = 1.0 / (d.ndtd * dt);  // :555-562
+    d.fresh[cell] = d.fresh[cell] + msnow_mlt * dti;
+    d.fhocn[cell] = d.fhocn[cell] + esnow_mlt * dti;
+    if (stop) atomicMax(&d.flag[0], stop);
+}
+
+__global__ void k_ridge_zero_flags(int *f)
+{
+    if (threadIdx.x < 2) f[threadIdx.x] = 0;
+}
+
+static int fieldPtr(sih_ctx *c, const char *name, SihLoc loc, int lead, double **out)
+{
+    int rc = sih_add_field(c, name, loc, lead, false);  // an existing field of that name is kept
+    if (rc) return rc;
+    SihField *f = sih_find_field(c, name);
+    if (!f || f->lead != lead || f->isInt) {
+        sih_set_error(std::string("sih_column_ridge: field ") + name + " exists with another shape");
+        return SIH_ERR_ARG;
+    }
+    *out = (double *)f->d;
+    return SIH_OK;
+}
+
+// the cell fields of the ridging beyond the tracers, created on first use
+static int ridgeFields(sih_ctx *c, int nCat, RidgeDev &d)
+{
+    int rc;
+    double *p = nullptr;
+    if ((rc = fieldPtr(c, "openWaterArea", LOC_CELL, 1, &d.aice0))) return rc;
+    if ((rc = fieldPtr(c, "ridgeConvergence", LOC_CELL, 1, &p))) return rc;
+    d.rdgConv = p;
+    if ((rc = fieldPtr(c, "ridgeShear", LOC_CELL, 1, &p))) return rc;
+    d.rdgShear = p;
+    if ((rc = fieldPtr(c, "seaFreezingTemperature", LOC_CELL, 1, &p))) return rc;
+    d.Tf = p;
+    if ((rc = fieldPtr(c, "areaLossRidge", LOC_CELL, 1, &d.dardg1dt))) return rc;
+    if ((rc = fieldPtr(c, "areaGainRidge", LOC_CELL, 1, &d.dardg2dt))) return rc;
+    if ((rc = fieldPtr(c, "iceVolumeRidged", LOC_CELL, 1, &d.dvirdgdt))) return rc;
+    if ((rc = fieldPtr(c, "openingRateRidge", LOC_CELL, 1, &d.opening))) return rc;
+    if ((rc = fieldPtr(c, "oceanFreshWaterFlux", LOC_CELL, 1, &d.fresh))) return rc;
+    if ((rc = fieldPtr(c, "oceanHeatFlux", LOC_CELL, 1, &d.fhocn))) return rc;
+    if ((rc = fieldPtr(c, "ridgeParticipationFunction", LOC_CELL, nCat, &d.aparticn))) return rc;
+    if ((rc = fieldPtr(c, "ratioRidgeThicknessToIce", LOC_CELL, nCat, &d.krdgn))) return rc;
+    if ((rc = fieldPtr(c, "fractionNewRidgeArea", LOC_CELL, nCat, &d.aredistn))) return rc;
+    if ((rc = fieldPtr(c, "fractionNewRidgeVolume", LOC_CELL, nCat, &d.vredistn))) return rc;
+    if ((rc = fieldPtr(c, "areaLossRidgeCategory", LOC_CELL, nCat, &d.dardg1ndt))) return rc;
+    if ((rc = fieldPtr(c, "areaGainRidgeCategory", LOC_CELL, nCat, &d.dardg2ndt))) return rc;
+    if ((rc = fieldPtr(c, "iceVolumeRidgedCategory", LOC_CELL, nCat, &d.dvirdgndt))) return rc;
+    if ((rc = fieldPtr(c, "raftingIceArea", LOC_CELL, nCat, &d.araftn))) return rc;
+    if ((rc = fieldPtr(c, "raftingIceVolume", LOC_CELL, nCat, &d.vraftn))) return rc;
+    return SIH_OK;
+}
+
+extern "C" int sih_column_ridge_init(sih_ctx *c, int nCategories)
+{
+    if (!c || nCategories < 1 || nCategories > RIDGE_MAXCAT) {
+        sih_set_error("sih_column_ridge_init: bad argument");
+        return SIH_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    RidgeDev d{};
+    return ridgeFields(c, nCategories, d);
+}
+
+extern "C" int sih_column_ridge(sih_ctx *c, const sih_ridge_config *cfg)
+{
+    if (!c || !cfg || !cfg->categoryThicknessLimits) {
+        sih_set_error("sih_column_ridge: null argument");
+        return SIH_ERR_ARG;
+    }
+    std::vector<SihTracerInfo> tr;
+    int nCat = 0;
+    if (!sih_ir_tracer_table(c, tr, &nCat)) {
+        sih_set_error("sih_column_ridge: the tracer list is not set (sih_ir_init, sih_ir_set_tracers)");
+        return SIH_ERR_STATE;
+    }
+    if (cfg->nCategories != nCat || nCat < 1 || nCat > RIDGE_MAXCAT) {
+        sih_set_error("sih_column_ridge: nCategories must be that of the tracers, at most 10");
+        return SIH_ERR_ARG;
+    }
+    if (!(cfg->dt > 0.0) || cfg->dynamicsSubcycleNumber < 1 || cfg->participation < 0 || cfg->participation > 1 ||
+        cfg->redistribution < 0 || cfg->redistribution > 1) {
+        sih_set_error("sih_column_ridge: bad time step or option");
+        return SIH_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    RidgeDev d{};
+    int iVol = -1, iSnow = -1;
+    for (size_t i = 0; i < tr.size(); i++) {
+        if (tr[i].name == "iceVolumeCategory") iVol = (int)i;
+        if (tr[i].name == "snowVolumeCategory") iSnow = (int)i;
+    }
+    if (iVol < 0 || iSnow < 0 || tr[0].L != 1 || tr[iVol].L != 1 || tr[iSnow].L != 1 || tr[iVol].parent != 0 ||
+        tr[iSnow].parent != 0) {
+        sih_set_error("sih_column_ridge: the tracer list must hold iceVolumeCategory and snowVolumeCategory on the ice area");
+        return SIH_ERR_ARG;
+    }
+    d.ntTsfc = -1;
+    d.ntQsno = -1;
+    d.nslyr = 0;
+    int nt = 0;
+    for (size_t i = 1; i < tr.size(); i++) {
+        if ((int)i == iVol || (int)i == iSnow) continue;
+        const int dep = tr[i].parent == 0 ? 0 : tr[i].parent == iVol ? 1 : tr[i].parent == iSnow ? 2 : -1;
+        if (dep < 0) {
+            sih_set_error("sih_column_ridge: tracer " + tr[i].name +
+                          " is carried on another tracer (strata: ponds, brine, level ice, aerosols): not supported");
+            return SIH_ERR_UNSUPPORTED;
+        }
+        if (nt + tr[i].L > RIDGE_MAXTR) {
+            sih_set_error("sih_column_ridge: too many tracer layers");
+            return SIH_ERR_UNSUPPORTED;
+        }
+        if (tr[i].name == "surfaceTemperature") d.ntTsfc = nt;
+        if (tr[i].name == "snowEnthalpy") {
+            d.ntQsno = nt;
+            d.nslyr = tr[i].L;
+        }
+        for (int l = 0; l < tr[i].L; l++) d.tr[nt++] = RidgeTracer{tr[i].val, tr[i].L, l, dep};
+    }
+    d.ntrcr = nt;
+    d.ncat = nCat;
+    d.nCellsSolve = c->nCellsSolve;
+    d.padC = c->padC;
+    d.dt = cfg->dt;
+    d.ndtd = cfg->dynamicsSubcycleNumber;
+    d.krdgPartic = cfg->participation;
+    d.krdgRedist = cfg->redistribution;
+    d.muRdg = cfg->efoldingScale;
+    for (int n = 0; n <= nCat; n++) d.hinMax[n] = cfg->categoryThicknessLimits[n];
+    d.hinMax[nCat] = 1.0e+8;  // ridge_prep :675 (the reference writes it into the host's array as well)
+    d.aicen = tr[0].val;
+    d.vicen = tr[iVol].val;
+    d.vsnon = tr[iSnow].val;
+    int rc;
+    if ((rc = ridgeFields(c, nCat, d))) return rc;
+    if (!c->ridge) c->ridge = new sih_ridge_state();
+    sih_ridge_state *rs = c->ridge;
+    if (!rs->d_flag) HIPCHK(hipMalloc(&rs->d_flag, 2 * sizeof(int)));
+    if (rs->planes != nt * nCat) {
+        const std::string name = "_ridgeProducts" + std::to_string(nt * nCat);
+        if ((rc = fieldPtr(c, name.c_str(), LOC_CELL, nt * nCat, &rs->atrcrn))) return rc;
+        rs->planes = nt * nCat;
+    }
+    d.atrcrn = rs->atrcrn;
+    d.flag = rs->d_flag;
+    hipLaunchKernelGGL(k_ridge_zero_flags, dim3(1), dim3(64), 0, c->stream, d.flag);
+    const dim3 grid((unsigned)((d.nCellsSolve + 127) / 128)), block(128);
+    if (nCat <= 5)
+        hipLaunchKernelGGL(k_ridge_ice<5>, grid, block, 0, c->stream, d);
+    else
+        hipLaunchKernelGGL(k_ridge_ice<RIDGE_MAXCAT>, grid, block, 0, c->stream, d);
+    HIPCHK(hipGetLastError());
+    int flags[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(flags, d.flag, sizeof flags, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    rs->lastIterations = flags[1];
+    if (flags[0]) {
+        sih_set_error(flags[0] == 1   ? "Ridging error: aice0 < 0"
+                      : flags[0] == 2 ? "Ridging error: ardg > aicen"
+                      : flags[0] == 3 ? "ridge_ice: Exceeded max number of ridging iterations"
+                                      : "ridge_ice: total area > 1");
+        return SIH_ERR_COLUMN;
+    }
+    return SIH_OK;
+}
+
+double sih_ridge_info(sih_ctx *c) { return c->ridge ? (double)c->ridge->lastIterations : 0.0; }

@@ -125,6 +125,15 @@ void sih_ir_destroy(sih_ctx *c)
     c->ir = nullptr;
 }
 
+bool sih_ir_tracer_table(sih_ctx *c, std::vector<SihTracerInfo> &out, int *nCategories)
+{
+    out.clear();
+    if (!c->ir || c->ir->tracers.empty()) return false;
+    for (const IrTracer &t : c->ir->tracers) out.push_back({t.name, t.parent, t.L, t.val});
+    if (nCategories) *nCategories = c->ir->nCat;
+    return true;
+}
+
 // Blocks are dealt round-robin over the 8 XCDs, each with its own L2, so blocks b and b + 8 share one.
 // A launch over (tile, part) pairs whose `nPart` parts re-read the tile's geometry puts all parts of a tile
 // on one XCD, back to back: linear block id -> (tile, part).  Affinity only; any placement is correct.

@@ -432,6 +432,7 @@ extern "C" int sih_block_destroy(sih_ctx *c)
     if (c->graphExec) (void)hipGraphExecDestroy(c->graphExec);
     sih_comm_free(c);
     sih_persist_destroy(c);
+    sih_ridge_destroy(c);
     sih_ir_destroy(c);
     sih_weak_destroy(c);
     sih_upwind_destroy(c);
@@ -1431,6 +1432,7 @@ extern "C" int sih_get_info(sih_ctx *c, const char *key, double *value)
     else if (k == "minDvEdge") *value = c->minDvEdge;
     else if (k == "irCflWarnings") *value = sih_ir_cfl_warnings(c);
     else if (k == "irRecoverMeansWarnings") *value = sih_ir_recover_warnings(c);
+    else if (k == "ridgeIterations") *value = sih_ridge_info(c);  // most iterations of ridge_ice in any cell, last call
     else if (k == "irFluxWalk") *value = sih_ir_flux_walk(c);
     else if (k == "splitCellKernel") *value = c->splitCells ? 1.0 : 0.0;
     else if (k == "persistentKernel") *value = sih_persist_usable(c) ? 1.0 : 0.0;

@@ -77,6 +77,7 @@ struct sih_ctx {
     // far: kept across a rebuild of its tables (sih_evp_init again, sih_evp_static_changed), because the tags and the
     // bank parity of the words in the transport's receive region go on counting from them
     unsigned long long persistCarry[4] = {0, 0, 0, 0};
+    struct sih_ridge_state *ridge = nullptr;                 // ridging of the column package (column_ridge.hip)
     struct sih_comm_state *comm = nullptr;                   // halo exchange with blocks of other processes / devices
     std::map<std::string, SihField> fields;
     std::vector<void *> allocs;
@@ -157,6 +158,16 @@ SihField *sih_find_field(sih_ctx *c, const char *name);
 int sih_add_field(sih_ctx *c, const char *name, SihLoc loc, int lead, bool isInt);
 int sih_dev_alloc(sih_ctx *c, void **p, size_t bytes);
 void sih_ir_destroy(sih_ctx *c);
+// the advected tracers as sih_ir_set_tracers registered them (list order: parents before children), for the column
+// package's ridging, which works on the same device fields
+struct SihTracerInfo {
+    std::string name;
+    int parent, L;
+    double *val;
+};
+bool sih_ir_tracer_table(sih_ctx *c, std::vector<SihTracerInfo> &out, int *nCategories);
+void sih_ridge_destroy(sih_ctx *c);
+double sih_ridge_info(sih_ctx *c);
 void sih_weak_destroy(sih_ctx *c);
 void sih_upwind_destroy(sih_ctx *c);
 void sih_comm_free(sih_ctx *c);

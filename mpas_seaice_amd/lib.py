@@ -69,6 +69,14 @@ class IrDesc(ctypes.Structure):
     ]
 
 
+class RidgeConfig(ctypes.Structure):
+    _fields_ = [
+        ("dt", ctypes.c_double), ("dynamicsSubcycleNumber", ctypes.c_int32), ("participation", ctypes.c_int32),
+        ("redistribution", ctypes.c_int32), ("efoldingScale", ctypes.c_double), ("nCategories", ctypes.c_int32),
+        ("categoryThicknessLimits", ctypes.c_void_p),
+    ]
+
+
 EXPORTS = [
     "sih_block_create", "sih_block_destroy", "sih_last_error", "sih_set_stream", "sih_sync",
     "sih_evp_init", "sih_evp_static_changed", "sih_field_put", "sih_field_get", "sih_field_count",
@@ -84,6 +92,7 @@ EXPORTS = [
     "sih_halo_exchange", "sih_halo_exchange_start", "sih_halo_exchange_finish", "sih_comm_set_timeout",
     "sih_comm_status", "sih_evp_subcycle_exchange", "sih_field_get_noalloc", "sih_device_count", "sih_evp_subcycle_persistent", "sih_evp_subcycle_fused", "sih_column_get", "sih_column_put", "sih_evp_set_persistent",
     "sih_fields_get_start", "sih_fields_get_finish", "sih_evp_run_early_outputs",
+    "sih_column_ridge", "sih_column_ridge_init",
 ]
 
 
@@ -122,6 +131,8 @@ def load():
     lib.sih_field_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t]
     lib.sih_field_get_noalloc.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t]
     lib.sih_fields_get_finish.argtypes = [ctypes.c_void_p]
+    lib.sih_column_ridge.argtypes = [ctypes.c_void_p, ctypes.POINTER(RidgeConfig)]
+    lib.sih_column_ridge_init.argtypes = [ctypes.c_void_p, ctypes.c_int]
     for fn in (lib.sih_fields_put, lib.sih_fields_get, lib.sih_fields_get_start, lib.sih_evp_run_early_outputs):
         fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
                        ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
@@ -507,6 +518,16 @@ class BlockContext:
         checks = ((1 if check_conservation else 0) | (2 if check_monotonicity else 0)
                   | (4 if check_recover_means else 0))
         check(self._lib.sih_ir_run(self.handle, float(dt), checks), "sih_ir_run")
+
+    def ridge_prepare_fields(self, nCategories):
+        check(self._lib.sih_column_ridge_init(self.handle, int(nCategories)), "sih_column_ridge_init")
+
+    def column_ridge(self, dt, ndtd, participation, redistribution, efolding_scale, thickness_limits):
+        """sih_column_ridge: ridge_ice for every owned cell on the device fields"""
+        lim = np.ascontiguousarray(thickness_limits, dtype=np.float64)
+        cfg = RidgeConfig(float(dt), int(ndtd), int(participation), int(redistribution), float(efolding_scale),
+                          int(lim.size - 1), lim.ctypes.data)
+        check(self._lib.sih_column_ridge(self.handle, ctypes.byref(cfg)), "sih_column_ridge")
 
     def ir_unpack_reconstruction(self):
         check(self._lib.sih_ir_unpack_reconstruction(self.handle), "sih_ir_unpack_reconstruction")

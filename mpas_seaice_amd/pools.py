@@ -47,6 +47,8 @@ DEFAULT_CONFIGS = {
     "config_ridging_redistribution_function": "exponential",
     "config_ridiging_efolding_scale": 3.0,
     "config_ratio_ridging_work_to_PE": 17.0,
+    # ridging of the column package (Registry.xml:1685-1708; column_ridging runs when both are set)
+    "config_use_column_ridging": True,
     "config_use_special_boundaries_velocity": False,
     "config_use_special_boundaries_velocity_masks": False,
     "config_use_special_boundaries_tracers": False,
@@ -206,6 +208,44 @@ class Block:
                                           "landIceMask": ic(), "landIceMaskVertex": iv()}
         self.structs["atmos_coupling"] = {"uAirVelocity": rc(), "vAirVelocity": rc(), "airDensity": rc()}
         self.structs["ridging"] = {"ridgeConvergence": rc(), "ridgeShear": rc()}
+
+
+RIDGING_CELL_FIELDS = ("areaLossRidge", "areaGainRidge", "iceVolumeRidged", "openingRateRidge")
+RIDGING_CATEGORY_FIELDS = ("ridgeParticipationFunction", "ratioRidgeThicknessToIce", "fractionNewRidgeArea",
+                           "fractionNewRidgeVolume", "areaLossRidgeCategory", "areaGainRidgeCategory",
+                           "iceVolumeRidgedCategory", "raftingIceArea", "raftingIceVolume")
+
+
+def category_thickness_limits(nCategories):
+    """hin_max(0:ncat) of the original category scheme (kcatbound = 0 with the linear-remapping ITD,
+    colpkg_init_itd, /root/reference/src/column/ice_colpkg.F90:175-202): for five categories 0, 0.645, 1.391, 2.470,
+    4.567, 9.334 m."""
+    r = float(nCategories)
+    cc1, cc3 = 3.0 / r, 3.0
+    cc2 = 15.0 * cc1
+    h = np.zeros(nCategories + 1)
+    for n in range(1, nCategories + 1):
+        x1 = (n - 1) / r
+        h[n] = h[n - 1] + cc1 + cc2 * (1.0 + np.tanh(cc3 * (x1 - 1.0)))
+    return h
+
+
+def allocate_ridging_pools(block):
+    """What column_ridging reaches beyond the tracers (/root/reference/src/shared/mpas_seaice_column.F:3418-3456): the
+    diagnostics of the `ridging` pool (Registry dims nCells or nCategories x nCells), the ocean fluxes the ridging adds
+    to, the freezing temperature of the ocean and the category limits of the `initial` pool."""
+    if "ocean_fluxes" in block.structs:
+        return
+    d = block.dimensions
+    nC, nCat = d["nCells"], d["nCategories"]
+    rg = block.structs["ridging"]
+    for k in RIDGING_CELL_FIELDS:
+        rg[k] = np.zeros(nC + 1)
+    for k in RIDGING_CATEGORY_FIELDS:
+        rg[k] = np.zeros((nCat, nC + 1), order="F")
+    block.structs["ocean_fluxes"] = {"oceanFreshWaterFlux": np.zeros(nC + 1), "oceanHeatFlux": np.zeros(nC + 1)}
+    block.structs["ocean_coupling"]["seaFreezingTemperature"] = np.full(nC + 1, -1.8)
+    block.structs["initial"] = {"categoryThicknessLimits": category_thickness_limits(nCat)}
 
 
 class Domain:

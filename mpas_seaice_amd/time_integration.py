@@ -17,8 +17,14 @@ from . import velocity_solver as vs
 
 
 def seaice_timestep_dynamics(domain, column_dynamics=None):
-    """:131-173 without the column physics before and after the dynamics"""
+    """:131-173 without the column physics before and after the dynamics.  ``column_dynamics="device"``: the ridging
+    runs on the device (column.seaice_column_dynamics_time_integration), and from the first velocity solve to the last
+    ridging of the step the tracers never visit the host: every velocity solve after the first takes ice area and
+    volumes from the device, every advection and ridging works on what the stage before left there, and the pools
+    get tracers and ridging diagnostics once, at the end."""
     cfg = domain.configs
+    if column_dynamics == "device":
+        return _timestep_dynamics_on_device(domain)
     if cfg.get("config_use_dynamics", True):
         n = int(cfg["config_dynamics_subcycle_number"])
         for i in range(n):                                    # :138-162
@@ -32,3 +38,19 @@ def seaice_timestep_dynamics(domain, column_dynamics=None):
             if column_dynamics is not None:
                 column_dynamics(domain)                       # :158
     sb.seaice_set_special_boundaries_tracers(domain)          # :173
+
+
+def _timestep_dynamics_on_device(domain):
+    from . import column
+    cfg = domain.configs
+    if cfg.get("config_use_dynamics", True):
+        n = int(cfg["config_dynamics_subcycle_number"])
+        for i in range(n):
+            last = i == n - 1
+            vs.seaice_run_velocity_solver(domain, tracers_on_device=(i > 0))
+            if cfg.get("config_use_advection", True):
+                adv.seaice_run_advection(domain, upload=(i == 0), download=False)
+            # the first ridging of the step brings the host's cell fields (ocean state, fluxes, open water); later ones
+            # go on from what the one before left on the device; the tracers are on the device either way
+            column.seaice_column_dynamics_time_integration(domain, upload=("cells" if i == 0 else False), download=last)
+    sb.seaice_set_special_boundaries_tracers(domain)

@@ -228,9 +228,9 @@ def seaice_init_velocity_solver(domain):
                 b.ctx.overlap_setup()
 
 
-def _upload(domain, b):
+def _upload(domain, b, skip=()):
     cfg = domain.configs
-    items = list(RUN_INPUTS)
+    items = [(p, n) for p, n in RUN_INPUTS if n not in skip]
     if cfg["config_use_surface_tilt"] and not cfg["config_geostrophic_surface_tilt"]:
         items += [("ocean_coupling", "seaSurfaceTiltU"), ("ocean_coupling", "seaSurfaceTiltV")]
     if not cfg["config_calc_velocity_masks"]:
@@ -366,11 +366,13 @@ def velocity_solver_post_subcycle(domain):
         b.ctx.post_subcycle(1)
 
 
-def seaice_run_velocity_solver(domain, clock=None):
+def seaice_run_velocity_solver(domain, clock=None, tracers_on_device=False):
+    """``tracers_on_device``: ice area, ice volume and snow volume per category are on the device as the advection
+    and the ridging left them (a step whose column physics ran on the device): they are not taken from the pools."""
     if not domain.configs["config_use_velocity_solver"]:
         return
     for b in domain.blocklist:
-        _upload(domain, b)
+        _upload(domain, b, skip=("iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory") if tracers_on_device else ())
     velocity_solver_pre_subcycle(domain)
     subcycle_velocity_solver(domain, clock)
     velocity_solver_post_subcycle(domain)

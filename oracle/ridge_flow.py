@@ -1,0 +1,94 @@
+"""TEST INFRASTRUCTURE ONLY: column_ridging (/root/reference/src/shared/mpas_seaice_column.F:3283-3556) executed with
+the CPU oracle: for every owned cell the category tracer array is set from the pools (set_cice_tracer_array_category
+:6534-6575 for the standard physics tracers: surface temperature, ice enthalpy and salinity per ice layer, snow
+enthalpy per snow layer), ridge_ice runs (ridge_oracle.c), and the array goes back (get_cice_tracer_array_category).
+The ITD clean-up that follows ridge_ice inside colpkg_step_ridge is not part of this flow (see ridge_oracle.c).
+Parity status: "parity unpinned" (header of ridge_oracle.c)."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from mpas_seaice_amd import pools
+from . import evp_flow
+
+STOP_LABELS = {1: "Ridging error: aice0 < 0", 2: "Ridging error: ardg > aicen",
+               3: "ridge_ice: Exceeded max number of ridging iterations", 5: "ridge_ice: total area > 1"}
+PARTICIPATION = {"Thorndike75": 0, "exponential": 1}
+REDISTRIBUTION = {"Hibler80": 0, "exponential": 1}
+
+
+def tracer_layout(block):
+    """(field, layer) of every entry of the category tracer array, its base quantity (trcr_depend: 0 ice area, 1 ice
+    volume, 2 snow volume) and the indices the ridging needs (nt_Tsfc, nt_qsno), 0-based."""
+    d = block.dimensions
+    entries = [("surfaceTemperature", 0, 0)]
+    entries += [("iceEnthalpy", l, 1) for l in range(d["nIceLayers"])]
+    entries += [("iceSalinity", l, 1) for l in range(d["nIceLayers"])]
+    nt_qsno = len(entries)
+    entries += [("snowEnthalpy", l, 2) for l in range(d["nSnowLayers"])]
+    return entries, 0, nt_qsno
+
+
+def column_ridging(domain):
+    cfg = domain.configs
+    lib = evp_flow.lib()
+    for b in domain.blocklist:
+        pools.allocate_ridging_pools(b)
+        d = b.dimensions
+        nCS, nCat = d["nCellsSolve"], d["nCategories"]
+        tr, rg = b.structs["tracers"], b.structs["ridging"]
+        entries, nt_Tsfc, nt_qsno = tracer_layout(b)
+        ntrcr = len(entries)
+        depend = np.array([e[2] for e in entries], dtype=np.int32)
+        # set_cice_tracer_array_category: records (cell, category, tracer), tracer fastest
+        trcrn = np.zeros((nCS, nCat, ntrcr))
+        for it, (name, layer, _) in enumerate(entries):
+            trcrn[:, :, it] = tr[name][layer, :, :nCS].T
+        aicen = np.ascontiguousarray(tr["iceAreaCategory"][0, :, :nCS].T)
+        vicen = np.ascontiguousarray(tr["iceVolumeCategory"][0, :, :nCS].T)
+        vsnon = np.ascontiguousarray(tr["snowVolumeCategory"][0, :, :nCS].T)
+        aice0 = b.structs["icestate"]["openWaterArea"][:nCS].copy()
+        dt = float(b.structs["velocity_solver"]["dynamicsTimeStep"][0])
+        cell = {k: rg[k][:nCS].copy() for k in pools.RIDGING_CELL_FIELDS}
+        cat = {k: np.ascontiguousarray(rg[k][:, :nCS].T) for k in pools.RIDGING_CATEGORY_FIELDS}
+        fresh = b.structs["ocean_fluxes"]["oceanFreshWaterFlux"][:nCS].copy()
+        fhocn = b.structs["ocean_fluxes"]["oceanHeatFlux"][:nCS].copy()
+        stop = np.zeros(nCS, dtype=np.int32)
+        iters = np.zeros(nCS, dtype=np.int32)
+        fn = lib.ora_ridge_cells
+        fn.restype = ctypes.c_int
+
+        def P(a):
+            return ctypes.c_void_p(a.ctypes.data)
+        rc = fn(ctypes.c_int(nCS), ctypes.c_double(dt), ctypes.c_int(int(cfg["config_dynamics_subcycle_number"])),
+                ctypes.c_int(nCat), ctypes.c_int(d["nSnowLayers"]), ctypes.c_int(ntrcr),
+                P(b.structs["initial"]["categoryThicknessLimits"]), P(np.ascontiguousarray(rg["ridgeConvergence"][:nCS])),
+                P(np.ascontiguousarray(rg["ridgeShear"][:nCS])),
+                P(np.ascontiguousarray(b.structs["ocean_coupling"]["seaFreezingTemperature"][:nCS])),
+                P(aicen), P(trcrn), P(vicen), P(vsnon), P(aice0), P(depend), ctypes.c_int(nt_Tsfc), ctypes.c_int(nt_qsno),
+                ctypes.c_int(PARTICIPATION[cfg["config_ridging_participation_function"]]),
+                ctypes.c_int(REDISTRIBUTION[cfg["config_ridging_redistribution_function"]]),
+                ctypes.c_double(float(cfg["config_ridiging_efolding_scale"])),
+                P(cell["areaLossRidge"]), P(cell["areaGainRidge"]), P(cell["iceVolumeRidged"]), P(cell["openingRateRidge"]),
+                P(fresh), P(fhocn), P(cat["ridgeParticipationFunction"]), P(cat["ratioRidgeThicknessToIce"]),
+                P(cat["fractionNewRidgeArea"]), P(cat["fractionNewRidgeVolume"]), P(cat["areaLossRidgeCategory"]),
+                P(cat["areaGainRidgeCategory"]), P(cat["iceVolumeRidgedCategory"]), P(cat["raftingIceArea"]),
+                P(cat["raftingIceVolume"]), P(stop), P(iters))
+        domain.solver_state["ridge_iterations"] = iters
+        if rc:
+            raise RuntimeError("column_ridging: " + STOP_LABELS.get(int(rc), f"code {rc}"))
+        # get_cice_tracer_array_category and the rest of the state
+        for it, (name, layer, _) in enumerate(entries):
+            tr[name][layer, :, :nCS] = trcrn[:, :, it].T
+        tr["iceAreaCategory"][0, :, :nCS] = aicen.T
+        tr["iceVolumeCategory"][0, :, :nCS] = vicen.T
+        tr["snowVolumeCategory"][0, :, :nCS] = vsnon.T
+        b.structs["icestate"]["openWaterArea"][:nCS] = aice0
+        for k in pools.RIDGING_CELL_FIELDS:
+            rg[k][:nCS] = cell[k]
+        for k in pools.RIDGING_CATEGORY_FIELDS:
+            rg[k][:, :nCS] = cat[k].T
+        b.structs["ocean_fluxes"]["oceanFreshWaterFlux"][:nCS] = fresh
+        b.structs["ocean_fluxes"]["oceanHeatFlux"][:nCS] = fhocn
