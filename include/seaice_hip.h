@@ -464,7 +464,9 @@ int sih_comm_status(sih_ctx *ctx);
 /* ---- incremental-remap advection ---------------------------------------------------------------
  * Replaces, for one block, seaice_init_advection_incremental_remap and the per-block part of
  * seaice_run_advection_incremental_remap (src/shared/mpas_seaice_advection_incremental_remap.F:165,
- * :2338) with incremental_remap_block (:2740).  Hexagonal meshes (vertexDegree 3) only. */
+ * :2338) with incremental_remap_block (:2740).  Hexagonal meshes (vertexDegree 3) and quadrilateral meshes
+ * (vertexDegree 4: six side edges and cells per edge, :1133-1172, and the split of side triangles, :5807-5958); the
+ * velocity solver and the upwind advection take vertexDegree 3 only and refuse a quadrilateral block at their set-up. */
 
 /* mesh-pool fields the advection reads beyond sih_mesh_desc, and the options it reads
  * (incremental_remap.F:257-340, :2899-2901).  Pointers are borrowed for the duration of the call. */

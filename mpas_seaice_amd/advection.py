@@ -29,8 +29,9 @@ def seaice_init_advection(domain):
     if cfg["config_advection_type"] != "incremental_remap":
         raise SeaiceHipError("config_advection_type: unknown option " + str(cfg["config_advection_type"]))
     # check_halo_layer_number, incremental_remap.F:829-874
-    if getattr(domain, "comm", None) is not None and int(cfg.get("config_num_halos", 2)) < 2:
-        raise SeaiceHipError("IR requires at least two halo layers (config_num_halos)")
+    need = 3 if int(domain.blocklist[0].dimensions["vertexDegree"]) == 4 else 2   # SCVT meshes 2, quadrilateral ones 3
+    if getattr(domain, "comm", None) is not None and int(cfg.get("config_num_halos", need)) < need:
+        raise SeaiceHipError("MPAS-seaice: IR too few halo layers for incremental remapping (config_num_halos)")
     tracersHead = trc.seaice_add_tracers_to_linked_list(domain)
     if cfg["config_monotonicity_check"]:
         # the reference's tracer_monotonicity pool (incremental_remap_tracers.F:1045-1110)

@@ -605,6 +605,10 @@ extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
         sih_set_error("sih_evp_init: null argument");
         return SIH_ERR_ARG;
     }
+    if (c->D != 3) {
+        sih_set_error("velocity solver: only vertexDegree = 3 (hexagonal meshes) is implemented");
+        return SIH_ERR_UNSUPPORTED;
+    }
     if (cfg->constitutiveRelation < 1 || cfg->constitutiveRelation > 3) {
         sih_set_error("config_constitutive_relation_type unknown");
         return SIH_ERR_ARG;

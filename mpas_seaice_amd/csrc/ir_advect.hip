@@ -1,7 +1,8 @@
 // Incremental-remap (IR) tracer advection on the device.
 //
 // Follows src/shared/mpas_seaice_advection_incremental_remap.F of the reference (routine : line cited
-// at each kernel) for hexagonal meshes (vertexDegree = 3).  Arithmetic is written statement by statement
+// at each kernel) for hexagonal (vertexDegree = 3) and quadrilateral (vertexDegree = 4) meshes.  Arithmetic is written
+// statement by statement
 // in the reference's evaluation order and compiled with -ffp-contract=off.
 //
 // Data layout: structure-of-arrays like the rest of the library.  A tracer with L layers and nCat
@@ -47,6 +48,7 @@
 
 struct IrDev {
     int nCells, nCellsSolve, nVertices, nEdges, M, nCat, padC, padV, padE, onSphere, rotate;
+    int vdeg, nRemap;  // vertexDegree; side edges and cells around an edge: 4 on hexagonal meshes, 6 on quadrilateral ones
     const int *nEdgesOnCell, *voc, *coc;
     int *eoc, *coe, *voe, *eov, *remapEdge, *eoer, *coer;
     double *g2c, *xVOC, *yVOC, *xVOE, *yVOE, *geom, *minLen;
@@ -56,7 +58,7 @@ struct IrDev {
     int *triCount, *triCell;
     double *xTri, *yTri, *triArea;
     int *maskCell, *flag;
-    int *triSlot;       // per (remap cell 0..3, edge vertex 0..1, edge): where that vertex sits in that cell (emitTriangle)
+    int *triSlot;       // per (remap cell 0..nRemap-1, edge vertex 0..1, edge): where that vertex sits in that cell (emitTriangle)
     const int *updWin;  // per block of 256 owned cells: first edge of the window of fluxes its update stages in LDS
 };
 
@@ -320,7 +322,7 @@ __global__ void k_ir_init_edges(IrDev d, IrInitArgs a)
         d.xVOE[(size_t)d.padE + e] = p2[0] - pe[0];
         d.yVOE[(size_t)d.padE + e] = p2[1] - pe[1];
     }
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < d.nRemap; k++) {
         d.eoer[(size_t)k * d.padE + e] = nE;
         d.coer[(size_t)k * d.padE + e] = nC;
     }
@@ -351,7 +353,7 @@ __global__ void k_ir_init_edges(IrDev d, IrInitArgs a)
     }
     d.coer[e] = c1;
     d.coer[(size_t)d.padE + e] = c2;
-    int eo[4] = {nE, nE, nE, nE};
+    int eo[6] = {nE, nE, nE, nE, nE, nE};
     for (int k = 0; k < 2; k++) {
         int c = k == 0 ? c1 : c2;
         int n = d.nEdgesOnCell[c], iMain = 0;
@@ -370,27 +372,62 @@ __global__ void k_ir_init_edges(IrDev d, IrInitArgs a)
             eo[3] = d.eoc[(size_t)im * d.padC + c];
         }
     }
-    for (int k = 0; k < 4; k++) d.eoer[(size_t)k * d.padE + e] = eo[k];
-    for (int k = 0; k < 2; k++) {  // C3 and C4, :1513-1539
-        int en = eo[k];
-        if (en >= nE) en = eo[k + 2];
-        int found = nC;
-        for (int j = 0; j < 2; j++) {
-            int cn = d.coe[(size_t)j * d.padE + en];
-            if (cn < nC && cn != c1 && cn != c2) found = cn;
+    if (d.vdeg == 4) {  // E5 and E6: the edge at V1 / V2 that is neither the main edge nor one of E1..E4, :1479-1507
+        for (int k = 0; k < 2; k++) {
+            const int v = k == 0 ? v1 : v2;
+            for (int j = 0; j < 4; j++) {
+                const int en = d.eov[(size_t)j * d.padV + v];
+                if (en >= nE) continue;
+                bool isNew = en != e;
+                for (int q = 0; q < 4; q++)
+                    if (en == eo[q]) isNew = false;
+                if (isNew) {
+                    eo[4 + k] = en;
+                    break;
+                }
+            }
         }
-        d.coer[(size_t)(k + 2) * d.padE + e] = found;
+    }
+    for (int k = 0; k < d.nRemap; k++) d.eoer[(size_t)k * d.padE + e] = eo[k];
+    if (d.vdeg == 3) {
+        for (int k = 0; k < 2; k++) {  // C3 and C4, :1513-1539
+            int en = eo[k];
+            if (en >= nE) en = eo[k + 2];
+            int found = nC;
+            for (int j = 0; j < 2; j++) {
+                int cn = d.coe[(size_t)j * d.padE + en];
+                if (cn < nC && cn != c1 && cn != c2) found = cn;
+            }
+            d.coer[(size_t)(k + 2) * d.padE + e] = found;
+        }
+    } else {
+        for (int k = 0; k < 2; k++) {  // C3, C4 across E1, E2 from C1; C5, C6 across E3, E4 from C2, :1541-1578
+            int found = nC;
+            if (eo[k] < nE)
+                for (int j = 0; j < 2; j++) {
+                    int cn = d.coe[(size_t)j * d.padE + eo[k]];
+                    if (cn < nC && cn != c1) found = cn;
+                }
+            d.coer[(size_t)(k + 2) * d.padE + e] = found;
+            found = nC;
+            if (eo[k + 2] < nE)
+                for (int j = 0; j < 2; j++) {
+                    int cn = d.coe[(size_t)j * d.padE + eo[k + 2]];
+                    if (cn < nC && cn != c2) found = cn;
+                }
+            d.coer[(size_t)(k + 4) * d.padE + e] = found;
+        }
     }
 }
 
-// per remap edge: coordinates of the distant vertices V3..V6, second loop of :1650-1699 / planar :1703-1760
+// per remap edge: coordinates of the distant vertices V3..V6 (V3..V8 on quadrilateral meshes), second loop of :1650-1699 / planar :1703-1760
 __global__ void k_ir_init_edge_vertices(IrDev d, IrInitArgs a)
 {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= d.nEdges || d.remapEdge[e] != 1) return;
     const int nE = d.nEdges;
     int count = 2;
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < d.nRemap; k++) {
         int en = d.eoer[(size_t)k * d.padE + e];
         if (en >= nE) continue;
         int n1 = 0, m1 = 0, m2 = 0;
@@ -422,7 +459,7 @@ __global__ void k_ir_init_vertices(IrDev d, IrInitArgs a)
     int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= d.nVertices) return;
     double mn = HUGE_R;
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < d.vdeg; k++) {
         int e = d.eov[(size_t)k * d.padV + v];
         if (e < d.nEdges) {
             int v1 = d.voe[e], v2 = d.voe[(size_t)d.padE + e];
@@ -855,7 +892,7 @@ __global__ void k_ir_departure_points(IrDev d, double dt)
 }
 
 // shift_vertices_of_departure_triangle :6270-6500 followed by the signed area (:6231), then stored
-// Set-up: for each of an edge's four remap cells and each of its two vertices, the place of that vertex among the
+// Set-up: for each of an edge's four (six) remap cells and each of its two vertices, the place of that vertex among the
 // cell's vertices (0 when it is not one of them, as the search of shift_vertices_of_departure_triangle :6270 leaves
 // it) and the places before and after it, packed place | before << 8 | after << 16.
 __global__ void k_ir_init_tri_slots(IrDev d)
@@ -863,7 +900,7 @@ __global__ void k_ir_init_tri_slots(IrDev d)
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= d.nEdges) return;
     const size_t pe = d.padE, pc = d.padC;
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < d.nRemap; j++) {
         const int cell = d.coer[(size_t)j * pe + e];
         for (int tvoe = 0; tvoe < 2; tvoe++) {
             int packed = 0;
@@ -931,8 +968,10 @@ __device__ inline void emitTriangle(const IrDev &d, int e, int t, double xt[3], 
     d.triArea[(size_t)t * pe + e] = area;
 }
 
+template <int VDEG>
 __global__ void __launch_bounds__(128) k_ir_triangles(IrDev d)
 {
+    constexpr int NR = VDEG == 4 ? 6 : 4;  // side edges / remap cells of an edge
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= d.nEdges) return;
     const size_t pe = d.padE, pv = d.padV;
@@ -950,17 +989,17 @@ __global__ void __launch_bounds__(128) k_ir_triangles(IrDev d)
     // everything the branches below may read of this edge is requested here, in one go: read where it is needed,
     // each of these loads was a memory round trip of its own behind a branch (the kernel spent 84 % of its
     // wave-cycles waiting)
-    double xo[6], yo[6];  // the edge's two vertices, then the far vertices of E1..E4
-    int en4[4], cell4[4], slot8[8];
+    double xo[NR + 2], yo[NR + 2];  // the edge's two vertices, then the far vertices of E1..E4 (E1..E6)
+    int en4[NR], cell4[NR], slot8[2 * NR];
 #pragma unroll
-    for (int j = 0; j < 8; j++) slot8[j] = d.triSlot[(size_t)j * pe + e];
+    for (int j = 0; j < 2 * NR; j++) slot8[j] = d.triSlot[(size_t)j * pe + e];
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
+    for (int j = 0; j < NR + 2; j++) {
         xo[j] = d.xVOE[(size_t)j * pe + e];
         yo[j] = d.yVOE[(size_t)j * pe + e];
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < NR; j++) {
         en4[j] = d.eoer[(size_t)j * pe + e];
         cell4[j] = d.coer[(size_t)j * pe + e];
     }
@@ -990,14 +1029,57 @@ __global__ void __launch_bounds__(128) k_ir_triangles(IrDev d)
             }
             if (hit) {
                 double xt[3] = {ev[k][0], dp[k][0], ix}, yt[3] = {ev[k][1], dp[k][1], iy};
-                int cell = cell4[k + 2];
-                int other = ieoe + 2;
-                if (other > 3) other = other - 4;
-                double ox = xo[other + 2], oy = yo[other + 2];
-                if (tc < NTRI)
-                    emitTriangle(d, e, tc, xt, yt, slot8[(k + 2) * 2 + k], ev[k][0], ev[k][1], cell, nx - ev[k][0], ny - ev[k][1],
-                                 ox - ev[k][0], oy - ev[k][1], side == 0 ? 1 : -1);
-                tc = tc + 1;
+                const int sign = side == 0 ? 1 : -1;
+                if (VDEG == 3) {
+                    int cell = cell4[k + 2];
+                    int other = ieoe + 2;
+                    if (other > 3) other = other - 4;
+                    double ox = xo[other + 2], oy = yo[other + 2];
+                    if (tc < NTRI)
+                        emitTriangle(d, e, tc, xt, yt, slot8[(k + 2) * 2 + k], ev[k][0], ev[k][1], cell, nx - ev[k][0],
+                                     ny - ev[k][1], ox - ev[k][0], oy - ev[k][1], sign);
+                    tc = tc + 1;
+                } else {
+                    // quadrilateral mesh, :5785-5958: the second basis vector runs along E5 / E6; where the line D1-D2
+                    // also crosses E5 / E6 the side triangle is cut in two, one part on each side of the main edge's line
+                    const double e2x = xo[NR + k] - ev[k][0], e2y = yo[NR + k] - ev[k][1];  // towards V7 / V8
+                    double e1x = nx - ev[k][0], e1y = ny - ev[k][1];
+                    int cIdx = k + 2;  // C3 / C4
+                    bool hit56 = false;
+                    double jx = 0.0, jy = 0.0;
+                    if (en4[NR - 2 + k] < d.nEdges)
+                        hit56 = lineIntersect(dp[0][0], dp[0][1], dp[1][0], dp[1][1], ev[k][0], ev[k][1], xo[NR + k], yo[NR + k], jx,
+                                              jy);
+                    if (hit56) {
+                        xt[2] = jx;
+                        yt[2] = jy;
+                        double f1x, f1y;
+                        if (side == 0) {  // IP on the left, this part on the right: C5 / C6, first basis vector along E3 / E4
+                            cIdx = k + 4;
+                            f1x = xo[ieoe + 4] - ev[k][0];
+                            f1y = yo[ieoe + 4] - ev[k][1];
+                        } else {  // IP on the right, this part on the left: C3 / C4, first basis vector along E1 / E2
+                            f1x = xo[ieoe] - ev[k][0];
+                            f1y = yo[ieoe] - ev[k][1];
+                        }
+                        if (tc < NTRI)
+                            emitTriangle(d, e, tc, xt, yt, slot8[cIdx * 2 + k], ev[k][0], ev[k][1], cell4[cIdx], f1x, f1y, e2x, e2y,
+                                         sign);
+                        tc = tc + 1;
+                        // V1 / V2, IP0, IP: the part on the side where IP lies
+                        double xs[3] = {ev[k][0], jx, ix}, ys[3] = {ev[k][1], jy, iy};
+                        const int c2 = side == 0 ? k + 2 : k + 4;
+                        if (tc < NTRI)
+                            emitTriangle(d, e, tc, xs, ys, slot8[c2 * 2 + k], ev[k][0], ev[k][1], cell4[c2], e1x, e1y, e2x, e2y, sign);
+                        tc = tc + 1;
+                    } else {
+                        if (side == 1) cIdx = k + 4;  // IP and triangle in the right half-plane: C5 / C6
+                        if (tc < NTRI)
+                            emitTriangle(d, e, tc, xt, yt, slot8[cIdx * 2 + k], ev[k][0], ev[k][1], cell4[cIdx], e1x, e1y, e2x, e2y,
+                                         sign);
+                        tc = tc + 1;
+                    }
+                }
                 dp[k][0] = ix;
                 dp[k][1] = iy;
             }
@@ -1621,7 +1703,7 @@ static int uploadPlaneInts(sih_ctx *c, int *dst, const std::vector<int> &v)
 int sih_setup_edges(sih_ctx *c, const sih_ir_desc *m, const char *who)
 {
     HIPCHK(hipSetDevice(c->device));
-    const int nC = c->nCells, nV = c->nVertices, nE = c->nEdges, M = c->M;
+    const int nC = c->nCells, nV = c->nVertices, nE = c->nEdges, M = c->M, D = c->D;
     // validate connectivity before the device dereferences it
     for (int e = 0; e < nE; e++)
         for (int k = 0; k < 2; k++) {
@@ -1639,7 +1721,7 @@ int sih_setup_edges(sih_ctx *c, const sih_ir_desc *m, const char *who)
                 return SIH_ERR_ARG;
             }
         }
-    for (size_t k = 0; k < (size_t)nV * 3; k++)
+    for (size_t k = 0; k < (size_t)nV * D; k++)
         if (m->edgesOnVertex[k] < 0 || m->edgesOnVertex[k] > nE + 1) {
             sih_set_error(std::string(who) + ": edgesOnVertex index out of range");
             return SIH_ERR_ARG;
@@ -1670,7 +1752,7 @@ int sih_setup_edges(sih_ctx *c, const sih_ir_desc *m, const char *who)
         bool isInt;
     } specs[] = {
         {"_eoc", LOC_CELL, M, true}, {"_coe", LOC_EDGE, 2, true}, {"_voe", LOC_EDGE, 2, true},
-        {"_eov", LOC_VERTEX, 3, true}, {"xEdge", LOC_EDGE, 1, false}, {"yEdge", LOC_EDGE, 1, false},
+        {"_eov", LOC_VERTEX, D, true}, {"xEdge", LOC_EDGE, 1, false}, {"yEdge", LOC_EDGE, 1, false},
         {"zEdge", LOC_EDGE, 1, false}, {"dcEdge", LOC_EDGE, 1, false}, {"dvEdge", LOC_EDGE, 1, false},
     };
     for (const auto &s : specs)
@@ -1679,7 +1761,7 @@ int sih_setup_edges(sih_ctx *c, const sih_ir_desc *m, const char *who)
     // connectivity in internal numbering
     {
         std::vector<int> eoc((size_t)M * c->padC, nE), coe((size_t)2 * c->padE, nC), voe((size_t)2 * c->padE, nV),
-            eov((size_t)3 * c->padV, nE);
+            eov((size_t)D * c->padV, nE);
         for (int i = 0; i < nC; i++) {
             int h = c->cellPerm[i];
             for (int s = 0; s < M; s++) {
@@ -1697,8 +1779,8 @@ int sih_setup_edges(sih_ctx *c, const sih_ir_desc *m, const char *who)
         }
         for (int i = 0; i < nV; i++) {
             int h = c->vertPerm[i];
-            for (int k = 0; k < 3; k++) {
-                int e = m->edgesOnVertex[(size_t)h * 3 + k];
+            for (int k = 0; k < D; k++) {
+                int e = m->edgesOnVertex[(size_t)h * D + k];
                 eov[(size_t)k * c->padV + i] = (e >= 1 && e <= nE) ? c->edgeInv[e - 1] : nE;
             }
         }
@@ -1726,12 +1808,13 @@ extern "C" int sih_ir_init(sih_ctx *c, const sih_ir_desc *m)
         sih_set_error("sih_ir_init: incomplete edge description of the mesh");
         return SIH_ERR_ARG;
     }
-    if (c->D != 3) {
-        sih_set_error("incremental remap: only vertexDegree = 3 (hexagonal meshes) is implemented");
+    if (c->D != 3 && c->D != 4) {
+        sih_set_error("incremental remap: vertexDegree must be 3 (hexagonal meshes) or 4 (quadrilateral meshes)");
         return SIH_ERR_UNSUPPORTED;
     }
     HIPCHK(hipSetDevice(c->device));
-    const int nC = c->nCells, nV = c->nVertices, nE = c->nEdges, M = c->M;
+    const int nC = c->nCells, nV = c->nVertices, nE = c->nEdges, M = c->M, D = c->D;
+    const int NR = D == 4 ? 6 : 4;  // side edges / cells around an edge, :1587-1591
     int rc;
     if ((rc = sih_setup_edges(c, m, "sih_ir_init"))) return rc;
     if (c->ir) sih_ir_destroy(c);
@@ -1775,10 +1858,10 @@ extern "C" int sih_ir_init(sih_ctx *c, const sih_ir_desc *m)
     };
     const Spec specs[] = {
         {"_eoc", LOC_CELL, M, true}, {"_coe", LOC_EDGE, 2, true}, {"_voe", LOC_EDGE, 2, true},
-        {"_eov", LOC_VERTEX, 3, true}, {"remapEdge", LOC_EDGE, 1, true}, {"_eoer", LOC_EDGE, 4, true},
-        {"_coer", LOC_EDGE, 4, true}, {"_triSlot", LOC_EDGE, 8, true}, {"_g2c", LOC_CELL, 6, false},
+        {"_eov", LOC_VERTEX, D, true}, {"remapEdge", LOC_EDGE, 1, true}, {"_eoer", LOC_EDGE, NR, true},
+        {"_coer", LOC_EDGE, NR, true}, {"_triSlot", LOC_EDGE, 2 * NR, true}, {"_g2c", LOC_CELL, 6, false},
         {"xVertexOnCell", LOC_CELL, M, false}, {"yVertexOnCell", LOC_CELL, M, false},
-        {"xVertexOnEdge", LOC_EDGE, 6, false}, {"yVertexOnEdge", LOC_EDGE, 6, false},
+        {"xVertexOnEdge", LOC_EDGE, NR + 2, false}, {"yVertexOnEdge", LOC_EDGE, NR + 2, false},
         {"geomAvgCell", LOC_CELL, 14, false}, {"minLengthEdgesOnVertex", LOC_VERTEX, 1, false},
         {"xEdge", LOC_EDGE, 1, false}, {"yEdge", LOC_EDGE, 1, false}, {"zEdge", LOC_EDGE, 1, false},
         {"dcEdge", LOC_EDGE, 1, false}, {"dvEdge", LOC_EDGE, 1, false},
@@ -1801,6 +1884,8 @@ extern "C" int sih_ir_init(sih_ctx *c, const sih_ir_desc *m)
     d.nVertices = nV;
     d.nEdges = nE;
     d.M = M;
+    d.vdeg = D;
+    d.nRemap = NR;
     d.nCat = ir->nCat;
     d.padC = c->padC;
     d.padV = c->padV;
@@ -2158,7 +2243,10 @@ static int irRun(sih_ctx *c, double dt, int checks, bool timed, double *totalMs,
     }
     mark(2);
     hipLaunchKernelGGL(k_ir_departure_points, dim3(gV), blk, 0, s, d, dt);
-    hipLaunchKernelGGL(k_ir_triangles, dim3((d.nEdges + 127) / 128), dim3(128), 0, s, d);
+    if (d.vdeg == 4)
+        hipLaunchKernelGGL(k_ir_triangles<4>, dim3((d.nEdges + 127) / 128), dim3(128), 0, s, d);
+    else
+        hipLaunchKernelGGL(k_ir_triangles<3>, dim3((d.nEdges + 127) / 128), dim3(128), 0, s, d);
     mark(3);
     if (ir->fluxMode == 2 && ir->walkOk)
         hipLaunchKernelGGL(k_ir_flux_walk, dim3(xcdGrid(gE, d.nCat)), blk, sizeof(double) * 256 * ir->nSlots, s, d,

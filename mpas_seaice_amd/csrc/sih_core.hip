@@ -176,8 +176,10 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
         return SIH_ERR_ARG;
     }
     *out = nullptr;  // the caller's handle is defined on every return
-    if (m->maxEdges < 3 || m->maxEdges > SIH_MAXE || m->vertexDegree != 3) {
-        sih_set_error("sih_block_create: maxEdges must be in [3,10] and vertexDegree 3");
+    // vertexDegree 4 (quadrilateral meshes) is accepted for the incremental remap; the velocity solver and the upwind
+    // advection refuse such a block at their own set-up
+    if (m->maxEdges < 3 || m->maxEdges > SIH_MAXE || (m->vertexDegree != 3 && m->vertexDegree != 4)) {
+        sih_set_error("sih_block_create: maxEdges must be in [3,10] and vertexDegree 3 or 4");
         return SIH_ERR_UNSUPPORTED;
     }
     if (m->nCells < 1 || m->nVertices < 1 || m->nCellsSolve > m->nCells || m->nVerticesSolve > m->nVertices ||
@@ -221,7 +223,7 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
     c->padV = roundUp(c->nVertices + 1, 64);
     c->padE = roundUp(std::max(c->nEdges, 0) + 1, 64);
     c->renumber = m->renumber != 0;
-    const int nC = c->nCells, nV = c->nVertices, M = c->M;
+    const int nC = c->nCells, nV = c->nVertices, M = c->M, D = c->D;
 
     // validate connectivity before anything is dereferenced on the device
     for (int i = 0; i < nC; i++) {
@@ -239,7 +241,7 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
             }
         }
     }
-    for (size_t k = 0; k < (size_t)nV * 3; k++) {
+    for (size_t k = 0; k < (size_t)nV * D; k++) {
         int cc = m->cellsOnVertex[k];
         if (cc < 0 || cc > nC + 1) {
             sih_set_error("sih_block_create: cellsOnVertex index out of range");
@@ -281,8 +283,8 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
     if (c->renumber) {
         std::vector<int> vkey(nV, nC);
         for (int v = 0; v < nV; v++)
-            for (int k = 0; k < 3; k++) {
-                int cc = m->cellsOnVertex[(size_t)v * 3 + k];
+            for (int k = 0; k < D; k++) {
+                int cc = m->cellsOnVertex[(size_t)v * D + k];
                 if (cc >= 1 && cc <= nC) vkey[v] = std::min(vkey[v], c->cellInv[cc - 1]);
             }
         auto cmp = [&](int a, int b) { return vkey[a] != vkey[b] ? vkey[a] < vkey[b] : a < b; };
@@ -310,7 +312,7 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
     const Spec specs[] = {
         // connectivity in internal numbering
         {"_nEdgesOnCell", LOC_CELL, 1, true}, {"_voc", LOC_CELL, M, true}, {"_coc", LOC_CELL, M, true},
-        {"_cov", LOC_VERTEX, 3, true}, {"_gidx", LOC_VERTEX, 3, true},
+        {"_cov", LOC_VERTEX, D, true}, {"_gidx", LOC_VERTEX, 3, true},
         {"_vertexActive", LOC_VERTEX, 1, true},
         // geometry
         {"xCell", LOC_CELL, 1, false}, {"yCell", LOC_CELL, 1, false}, {"zCell", LOC_CELL, 1, false},
@@ -373,11 +375,11 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
                 coc[(size_t)s * c->padC + i] = (nb >= 1 && nb <= nC) ? c->cellInv[nb - 1] : nC;
             }
         }
-        std::vector<int> cov((size_t)3 * c->padV, nC);
+        std::vector<int> cov((size_t)D * c->padV, nC);
         for (int i = 0; i < nV; i++) {
             int h = c->vertPerm[i];
-            for (int k = 0; k < 3; k++) {
-                int cc = m->cellsOnVertex[(size_t)h * 3 + k];
+            for (int k = 0; k < D; k++) {
+                int cc = m->cellsOnVertex[(size_t)h * D + k];
                 cov[(size_t)k * c->padV + i] = (cc >= 1 && cc <= nC) ? c->cellInv[cc - 1] : nC;
             }
         }

@@ -491,17 +491,184 @@ def make_planar_hex_mesh(nx: int, ny: int, dc: float) -> Mesh:
     return m
 
 
+# ----------------------------------------------------------------------------- quadrilateral meshes
+def _structured_quad_connectivity(nx: int, ny: int, periodic_x: bool):
+    """Connectivity of nx by ny quadrilateral cells (vertexDegree 4, maxEdges 4), 1-based with the n+1 sentinel.
+
+    Cell (i, j) has the vertices (i, j), (i+1, j), (i+1, j+1), (i, j+1) counter-clockwise and its k-th edge joins
+    its k-th and (k+1)-th vertex (bottom, right, top, left), the convention of the other generators of this module.
+    ``periodic_x`` closes the mesh in i (a band around a sphere); in j it always ends at a boundary."""
+    nvx = nx if periodic_x else nx + 1
+    N, T = nx * ny, nvx * (ny + 1)
+    nH = nx * (ny + 1)
+    nE = nH + nvx * ny
+
+    def vid(i, j):
+        return j * nvx + (i % nvx if periodic_x else i)
+
+    def cid(i, j):
+        if j < 0 or j >= ny:
+            return N
+        if periodic_x:
+            return j * nx + i % nx
+        return j * nx + i if 0 <= i < nx else N
+
+    def hid(i, j):
+        return j * nx + (i % nx if periodic_x else i)
+
+    def wid(i, j):
+        return nH + j * nvx + (i % nvx if periodic_x else i)
+
+    voc = np.zeros((4, N), dtype=np.int32, order="F")
+    eoc = np.zeros((4, N), dtype=np.int32, order="F")
+    coc = np.zeros((4, N), dtype=np.int32, order="F")
+    for j in range(ny):
+        for i in range(nx):
+            c = j * nx + i
+            voc[:, c] = (vid(i, j) + 1, vid(i + 1, j) + 1, vid(i + 1, j + 1) + 1, vid(i, j + 1) + 1)
+            eoc[:, c] = (hid(i, j) + 1, wid(i + 1, j) + 1, hid(i, j + 1) + 1, wid(i, j) + 1)
+            coc[:, c] = (cid(i, j - 1) + 1, cid(i + 1, j) + 1, cid(i, j + 1) + 1, cid(i - 1, j) + 1)
+    coe = np.full((2, nE), N + 1, dtype=np.int32, order="F")
+    voe = np.zeros((2, nE), dtype=np.int32, order="F")
+    # cell 1 is the lower-numbered existing cell and lies to the left of vertex 1 -> vertex 2
+    for j in range(ny + 1):
+        for i in range(nx):
+            e = hid(i, j)
+            south, north = cid(i, j - 1), cid(i, j)
+            if south < N:
+                coe[:, e] = (south + 1, north + 1)
+                voe[:, e] = (vid(i + 1, j) + 1, vid(i, j) + 1)      # heading west: the southern cell on the left
+            else:
+                coe[:, e] = (north + 1, N + 1)
+                voe[:, e] = (vid(i, j) + 1, vid(i + 1, j) + 1)
+    for j in range(ny):
+        for i in range(nvx):
+            e = wid(i, j)
+            west, east = cid(i - 1, j), cid(i, j)
+            if west < N and east < N and east < west:                  # the periodic seam: cell 1 = the lower number
+                coe[:, e] = (east + 1, west + 1)
+                voe[:, e] = (vid(i, j + 1) + 1, vid(i, j) + 1)      # heading south: the eastern cell on the left
+            elif west < N:
+                coe[:, e] = (west + 1, east + 1)
+                voe[:, e] = (vid(i, j) + 1, vid(i, j + 1) + 1)      # heading north: the western cell on the left
+            else:
+                coe[:, e] = (east + 1, N + 1)
+                voe[:, e] = (vid(i, j + 1) + 1, vid(i, j) + 1)
+    cov = np.full((4, T), N + 1, dtype=np.int32, order="F")
+    eov = np.full((4, T), nE + 1, dtype=np.int32, order="F")
+    for j in range(ny + 1):
+        for i in range(nvx):
+            v = vid(i, j)
+            cells = [cid(i, j), cid(i - 1, j), cid(i - 1, j - 1), cid(i, j - 1)]                      # NE, NW, SW, SE
+            edges = [hid(i, j) if (periodic_x or i < nx) else nE, wid(i, j) if j < ny else nE,
+                     hid(i - 1, j) if (periodic_x or i > 0) else nE, wid(i, j - 1) if j > 0 else nE]   # E, N, W, S
+            cells = [c for c in cells if c < N]
+            edges = [e for e in edges if e < nE]
+            cov[:len(cells), v] = np.asarray(cells) + 1
+            eov[:len(edges), v] = np.asarray(edges) + 1
+    return dict(N=N, T=T, nE=nE, nvx=nvx, voc=voc, eoc=eoc, coc=coc, coe=coe, voe=voe, cov=cov, eov=eov)
+
+
+def _quad_mesh_from(con, on_a_sphere, radius):
+    m = Mesh()
+    N, T, nE = con["N"], con["T"], con["nE"]
+    m["nCells"], m["nVertices"], m["nEdges"] = N, T, nE
+    m["nCellsSolve"], m["nVerticesSolve"], m["nEdgesSolve"] = N, T, nE
+    m["maxEdges"], m["vertexDegree"] = 4, 4
+    m["on_a_sphere"], m["sphere_radius"] = bool(on_a_sphere), float(radius)
+    m["nEdgesOnCell"] = np.full(N, 4, dtype=np.int32)
+    m["verticesOnCell"], m["edgesOnCell"], m["cellsOnCell"] = con["voc"], con["eoc"], con["coc"]
+    m["cellsOnVertex"], m["edgesOnVertex"] = con["cov"], con["eov"]
+    m["cellsOnEdge"], m["verticesOnEdge"] = con["coe"], con["voe"]
+    return m
+
+
+def make_planar_quad_mesh(nx: int, ny: int, dc: float) -> Mesh:
+    """Non-periodic planar mesh of nx by ny squares of side ``dc`` (vertexDegree 4): the shape of the reference's
+    ``square`` test-case meshes (/root/reference/testing_and_setup/testcases/square/square_quadhex), for the
+    quadrilateral branches of the incremental remap."""
+    con = _structured_quad_connectivity(nx, ny, False)
+    m = _quad_mesh_from(con, False, 1.0)
+    N, T, nE = con["N"], con["T"], con["nE"]
+    ci, cj = np.meshgrid(np.arange(nx), np.arange(ny))
+    m["xCell"], m["yCell"], m["zCell"] = ((ci + 0.5) * dc).reshape(-1), ((cj + 0.5) * dc).reshape(-1), np.zeros(N)
+    vi, vj = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1))
+    m["xVertex"], m["yVertex"], m["zVertex"] = (vi * dc).reshape(-1).astype(float), (vj * dc).reshape(-1).astype(float), np.zeros(T)
+    voe = con["voe"].astype(np.int64) - 1
+    m["xEdge"] = 0.5 * (m["xVertex"][voe[0]] + m["xVertex"][voe[1]])
+    m["yEdge"] = 0.5 * (m["yVertex"][voe[0]] + m["yVertex"][voe[1]])
+    m["zEdge"] = np.zeros(nE)
+    m["areaCell"] = np.full(N, dc * dc)
+    m["kiteAreasOnVertex"] = np.asfortranarray(np.where(con["cov"] <= N, 0.25 * dc * dc, 0.0))
+    m["areaTriangle"] = np.full(T, dc * dc)
+    m["dcEdge"] = np.full(nE, dc)
+    m["dvEdge"] = np.full(nE, dc)
+    for nm, n_ in (("Cell", N), ("Vertex", T), ("Edge", nE)):
+        m["lat" + nm] = np.zeros(n_)
+        m["lon" + nm] = np.zeros(n_)
+        m["f" + nm] = np.zeros(n_)
+    add_reconstruction_coefficients(m)
+    return m
+
+
+def make_latlon_quad_mesh(nlon: int, nlat: int, lat_max_deg: float = 60.0, radius: float = EARTH_RADIUS) -> Mesh:
+    """A band of nlon by nlat latitude-longitude quadrilaterals between -lat_max and +lat_max on the sphere, closed in
+    longitude, with boundaries along the two outer parallels (vertexDegree 4).  Stands in for the reference's
+    spherical quadrilateral meshes (the gx3 / gx1 cases named at
+    /root/reference/src/shared/mpas_seaice_advection_incremental_remap.F:105-119, not in the repository): on the
+    sphere the edges E5 / E6 beside an edge along a parallel bend away from its line, which is what the split of
+    side triangles (:5807-5958) is for."""
+    con = _structured_quad_connectivity(nlon, nlat, True)
+    m = _quad_mesh_from(con, True, radius)
+    N, T, nE = con["N"], con["T"], con["nE"]
+    dlon = 2.0 * np.pi / nlon
+    L = np.deg2rad(lat_max_deg)
+    dlat = 2.0 * L / nlat
+
+    def sph(lon, lat):
+        return np.stack([np.cos(lat) * np.cos(lon), np.cos(lat) * np.sin(lon), np.sin(lat)], axis=-1)
+
+    ci, cj = np.meshgrid(np.arange(nlon), np.arange(nlat))
+    pc = sph(((ci + 0.5) * dlon).reshape(-1), (-L + (cj + 0.5) * dlat).reshape(-1))
+    vi, vj = np.meshgrid(np.arange(nlon), np.arange(nlat + 1))
+    pv = sph((vi * dlon).reshape(-1), (-L + vj * dlat).reshape(-1))
+    voe = con["voe"].astype(np.int64) - 1
+    coe = con["coe"].astype(np.int64) - 1
+    pe = _unit(pv[voe[0]] + pv[voe[1]])
+    m["xCell"], m["yCell"], m["zCell"] = (np.ascontiguousarray(radius * pc[:, k]) for k in range(3))
+    m["xVertex"], m["yVertex"], m["zVertex"] = (np.ascontiguousarray(radius * pv[:, k]) for k in range(3))
+    m["xEdge"], m["yEdge"], m["zEdge"] = (np.ascontiguousarray(radius * pe[:, k]) for k in range(3))
+    lat_lo = (-L + cj * dlat).reshape(-1)
+    m["areaCell"] = radius ** 2 * dlon * (np.sin(lat_lo + dlat) - np.sin(lat_lo))
+    latv = (-L + vj * dlat).reshape(-1)
+    lo, hi = np.maximum(latv - 0.5 * dlat, -L), np.minimum(latv + 0.5 * dlat, L)
+    m["areaTriangle"] = radius ** 2 * dlon * (np.sin(hi) - np.sin(lo))
+    cov = con["cov"].astype(np.int64) - 1
+    ncv = np.maximum((cov < N).sum(axis=0), 1)
+    m["kiteAreasOnVertex"] = np.asfortranarray(np.where(cov < N, (m["areaTriangle"] / ncv)[None, :], 0.0))
+    m["dvEdge"] = radius * _arc(pv[voe[0]], pv[voe[1]])
+    both = coe[1] < N
+    c2 = np.where(both, coe[1], coe[0])
+    m["dcEdge"] = np.where(both, radius * _arc(pc[coe[0]], pc[c2]), radius * dlat)
+    for nm, p in (("Cell", pc), ("Vertex", pv), ("Edge", pe)):
+        m["lat" + nm] = np.arcsin(np.clip(p[:, 2], -1.0, 1.0))
+        m["lon" + nm] = np.mod(np.arctan2(p[:, 1], p[:, 0]), 2.0 * np.pi)
+        m["f" + nm] = 2.0 * OMEGA * np.sin(m["lat" + nm])
+    add_reconstruction_coefficients(m)
+    return m
+
+
 # ----------------------------------------------------------------------------- reconstruction
 def edges_on_vertex(m: Mesh):
-    """edgesOnVertex (3, nVertices) from verticesOnEdge, nEdges+1 where a vertex has fewer edges."""
-    nV, nE = m["nVertices"], m["nEdges"]
-    eov = np.full((3, nV), nE + 1, dtype=np.int32, order="F")
+    """edgesOnVertex (vertexDegree, nVertices) from verticesOnEdge, nEdges+1 where a vertex has fewer edges."""
+    nV, nE, D = m["nVertices"], m["nEdges"], int(m["vertexDegree"])
+    eov = np.full((D, nV), nE + 1, dtype=np.int32, order="F")
     cnt = np.zeros(nV, dtype=np.int64)
     voe = np.asarray(m["verticesOnEdge"]) - 1
     for e in range(nE):
         for k in range(2):
             v = voe[k, e]
-            if 0 <= v < nV and cnt[v] < 3:
+            if 0 <= v < nV and cnt[v] < D:
                 eov[cnt[v], v] = e + 1
                 cnt[v] += 1
     return eov

@@ -45,13 +45,16 @@ class IRError(RuntimeError):
 def seaice_init_advection(domain):
     """seaice_init_advection_incremental_remap :165-816"""
     cfg = domain.configs
-    if int(cfg.get("config_num_halos", 2)) < 2 and len(domain.blocklist) > 1:
-        raise IRError("IR requires at least two halo layers")          # check_halo_layer_number :829-874
+    # check_halo_layer_number :829-874 (two layers on hexagonal meshes, three on quadrilateral ones); as in the device
+    # mirror it only matters where there are halos at all
+    need = 3 if int(domain.blocklist[0].dimensions["vertexDegree"]) == 4 else 2
+    if int(cfg.get("config_num_halos", need)) < need and len(domain.blocklist) > 1:
+        raise IRError("MPAS-seaice: IR too few halo layers for incremental remapping")
     trc.seaice_add_tracers_to_linked_list(domain)
     for b in domain.blocklist:
         d, m = b.dimensions, b.structs["mesh"]
-        if d["vertexDegree"] != 3:
-            raise IRError("the oracle restates the hexagonal-mesh branches only")
+        if d["vertexDegree"] not in (3, 4):
+            raise IRError("IR: vertexDegree must be 3 (hexagonal meshes) or 4 (quadrilateral meshes)")
         nC, nV, nE, M = d["nCells"], d["nVertices"], d["nEdges"], d["maxEdges"]
         sphere = bool(m["on_a_sphere"])
         rot = bool(cfg["config_rotate_cartesian_grid"]) and sphere
@@ -82,8 +85,8 @@ def seaice_init_advection(domain):
         ir["yVertexOnEdge"] = np.zeros((NVER, nE + 1), order="F")
         ir["minLengthEdgesOnVertex"] = np.zeros(nV + 1)
         bad = calli("ira_get_geometry", nE, nV, nC, d["nCellsSolve"], M, m["nEdgesOnCell"], *xyz["Cell"], *xyz["Vertex"],
-                    *xyz["Edge"], m["cellsOnEdge"], m["verticesOnEdge"], m["edgesOnCell"], m["edgesOnVertex"], sphere,
-                    ir["transGlobalToEdge"], ir["remapEdge"], ir["cellsOnEdgeRemap"], ir["edgesOnEdgeRemap"],
+                    *xyz["Edge"], m["cellsOnEdge"], m["verticesOnEdge"], m["edgesOnCell"], m["edgesOnVertex"],
+                    int(d["vertexDegree"]), sphere, ir["transGlobalToEdge"], ir["remapEdge"], ir["cellsOnEdgeRemap"], ir["edgesOnEdgeRemap"],
                     ir["xVertexOnEdge"], ir["yVertexOnEdge"], ir["minLengthEdgesOnVertex"])
         if bad:
             raise IRError("cell 1 is not in the left half-plane")
@@ -242,7 +245,8 @@ def incremental_remap_block(domain, b, dt, tracersHead, diagnostics=None):
     ir["triangleArea"] = np.zeros((NTRI, nE + 1), order="F")
     errs = calli("ira_departure_triangles", nE, nC, M, m["nEdgesOnCell"], ir["xVertexOnEdge"], ir["yVertexOnEdge"],
                  ir["xVertexOnCell"], ir["yVertexOnCell"], m["verticesOnCell"], m["verticesOnEdge"], ir["remapEdge"],
-                 ir["cellsOnEdgeRemap"], ir["edgesOnEdgeRemap"], ir["departurePoint"], sphere, ir["maskEdge"],
+                 ir["cellsOnEdgeRemap"], ir["edgesOnEdgeRemap"], int(d["vertexDegree"]), ir["departurePoint"], sphere,
+                 ir["maskEdge"],
                  ir["xTriangle"], ir["yTriangle"], ir["iCellTriangle"], ir["triangleArea"])
     if errs:
         raise IRError("IR: basis vectors for IR coordinate transformations must not be parallel")

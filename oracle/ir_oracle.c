@@ -203,16 +203,17 @@ int ira_vertex_on_cell(int nCells, int M, const int *nEdgesOnCell, const int *ve
     return bad;
 }
 
-/* get_geometry_incremental_remap :1105-1808 (vertexDegree = 3).  Returns the number of edges whose
- * cell 1 is not in the left half-plane (a fatal mesh error in the reference, :1345-1350). */
+/* get_geometry_incremental_remap :1105-1808, hexagonal (vertexDegree = 3) and quadrilateral (4) meshes.  Returns
+ * the number of edges whose cell 1 is not in the left half-plane (a fatal mesh error in the reference, :1345-1350). */
 int ira_get_geometry(int nEdges, int nVertices, int nCells, int nCellsSolve, int M, const int *nEdgesOnCell,
                      const double *xC, const double *yC, const double *zC, const double *xV, const double *yV,
                      const double *zV, const double *xE, const double *yE, const double *zE, const int *cellsOnEdge,
-                     const int *verticesOnEdge, const int *edgesOnCell, const int *edgesOnVertex, int onSphere,
-                     const double *g2e, int *remapEdge, int *cellsOnEdgeRemap, int *edgesOnEdgeRemap, double *xVOE,
+                     const int *verticesOnEdge, const int *edgesOnCell, const int *edgesOnVertex, int vertexDegree,
+                     int onSphere, const double *g2e, int *remapEdge, int *cellsOnEdgeRemap, int *edgesOnEdgeRemap, double *xVOE,
                      double *yVOE, double *minLengthEdgesOnVertex)
 {
     int bad = 0;
+    const int nEdgesOnEdgeRemap = vertexDegree == 4 ? 6 : 4; /* :1587-1591 */
     for (int e = 0; e <= nEdges; e++) remapEdge[e] = 0;
     for (int c = 1; c <= nCellsSolve; c++)
         for (int i = 1; i <= nEdgesOnCell[c - 1]; i++) remapEdge[edgesOnCell[I2(i, c, M)] - 1] = 1;
@@ -286,16 +287,56 @@ int ira_get_geometry(int nEdges, int nVertices, int nCells, int nCellsSolve, int
                     }
                 }
             }
-            cellsOnEdgeRemap[I2(3, e, NEER)] = nCells + 1;
-            cellsOnEdgeRemap[I2(4, e, NEER)] = nCells + 1;
-            for (int k = 1; k <= 2; k++) {
-                int en = edgesOnEdgeRemap[I2(k, e, NEER)];
-                if (en < 1 || en > nEdges) en = edgesOnEdgeRemap[I2(k + 2, e, NEER)];
-                for (int j = 1; j <= 2; j++) {
-                    int cn = cellsOnEdge[I2(j, en, 2)];
-                    if (cn >= 1 && cn <= nCells)
-                        if (cn != cellsOnEdgeRemap[I2(1, e, NEER)] && cn != cellsOnEdgeRemap[I2(2, e, NEER)])
-                            cellsOnEdgeRemap[I2(k + 2, e, NEER)] = cn;
+            if (vertexDegree == 4) { /* E5 and E6: the edge at V1 / V2 not picked up yet, :1479-1507 */
+                for (int k = 1; k <= 2; k++) {
+                    int v = verticesOnEdge[I2(k, e, 2)];
+                    for (int j = 1; j <= vertexDegree; j++) {
+                        int en = edgesOnVertex[I2(j, v, vertexDegree)];
+                        if (en >= 1 && en <= nEdges) {
+                            int isNew = 1;
+                            for (int q = 1; q <= 4; q++)
+                                if (en == edgesOnEdgeRemap[I2(q, e, NEER)] || en == e) {
+                                    isNew = 0;
+                                    break;
+                                }
+                            if (isNew) {
+                                edgesOnEdgeRemap[I2(k + 4, e, NEER)] = en;
+                                break;
+                            }
+                        }
+                    }
+                }
+            }
+            if (vertexDegree == 3) { /* C3 and C4, :1513-1539 */
+                cellsOnEdgeRemap[I2(3, e, NEER)] = nCells + 1;
+                cellsOnEdgeRemap[I2(4, e, NEER)] = nCells + 1;
+                for (int k = 1; k <= 2; k++) {
+                    int en = edgesOnEdgeRemap[I2(k, e, NEER)];
+                    if (en < 1 || en > nEdges) en = edgesOnEdgeRemap[I2(k + 2, e, NEER)];
+                    for (int j = 1; j <= 2; j++) {
+                        int cn = cellsOnEdge[I2(j, en, 2)];
+                        if (cn >= 1 && cn <= nCells)
+                            if (cn != cellsOnEdgeRemap[I2(1, e, NEER)] && cn != cellsOnEdgeRemap[I2(2, e, NEER)])
+                                cellsOnEdgeRemap[I2(k + 2, e, NEER)] = cn;
+                    }
+                }
+            } else { /* C3, C4 beyond E1, E2 (not C1); C5, C6 beyond E3, E4 (not C2), :1541-1578 */
+                for (int q = 3; q <= 6; q++) cellsOnEdgeRemap[I2(q, e, NEER)] = nCells + 1;
+                for (int k = 1; k <= 2; k++) {
+                    int en = edgesOnEdgeRemap[I2(k, e, NEER)];
+                    if (en >= 1 && en <= nEdges)
+                        for (int j = 1; j <= 2; j++) {
+                            int cn = cellsOnEdge[I2(j, en, 2)];
+                            if (cn >= 1 && cn <= nCells && cn != cellsOnEdgeRemap[I2(1, e, NEER)])
+                                cellsOnEdgeRemap[I2(k + 2, e, NEER)] = cn;
+                        }
+                    en = edgesOnEdgeRemap[I2(k + 2, e, NEER)];
+                    if (en >= 1 && en <= nEdges)
+                        for (int j = 1; j <= 2; j++) {
+                            int cn = cellsOnEdge[I2(j, en, 2)];
+                            if (cn >= 1 && cn <= nCells && cn != cellsOnEdgeRemap[I2(2, e, NEER)])
+                                cellsOnEdgeRemap[I2(k + 4, e, NEER)] = cn;
+                        }
                 }
             }
         }
@@ -314,7 +355,7 @@ int ira_get_geometry(int nEdges, int nVertices, int nCells, int nCellsSolve, int
         }
         for (int e = 1; e <= nEdges; e++)
             if (remapEdge[e - 1] == 1)
-                for (int k = 1; k <= 4; k++) {
+                for (int k = 1; k <= nEdgesOnEdgeRemap; k++) {
                     int en = edgesOnEdgeRemap[I2(k, e, NEER)];
                     if (en >= 1 && en <= nEdges) {
                         int n1 = 0, m1 = 0, m2 = 0;
@@ -339,7 +380,7 @@ int ira_get_geometry(int nEdges, int nVertices, int nCells, int nCellsSolve, int
                     xVOE[I2(k, e, NVER)] = xV[v - 1] - xE[e - 1];
                     yVOE[I2(k, e, NVER)] = yV[v - 1] - yE[e - 1];
                 }
-                for (int k = 1; k <= 4; k++) {
+                for (int k = 1; k <= nEdgesOnEdgeRemap; k++) {
                     int en = edgesOnEdgeRemap[I2(k, e, NEER)];
                     if (en >= 1 && en <= nEdges) {
                         int v = 0;
@@ -360,8 +401,8 @@ int ira_get_geometry(int nEdges, int nVertices, int nCells, int nCellsSolve, int
     /* :1764-1806 */
     for (int v = 1; v <= nVertices; v++) {
         double mn = 1.79769313486231571e308;
-        for (int k = 1; k <= 3; k++) {
-            int e = edgesOnVertex[I2(k, v, 3)];
+        for (int k = 1; k <= vertexDegree; k++) {
+            int e = edgesOnVertex[I2(k, v, vertexDegree)];
             if (e >= 1 && e <= nEdges) {
                 int v1 = verticesOnEdge[I2(1, e, 2)], v2 = verticesOnEdge[I2(2, e, 2)];
                 double w[3] = {xV[v2 - 1] - xV[v1 - 1], yV[v2 - 1] - yV[v1 - 1], zV[v2 - 1] - zV[v1 - 1]};
@@ -712,11 +753,13 @@ static int shift_vertices(int iEdge, int iCell, int M, const int *nEdgesOnCell, 
 #define XT(q, t, e) xTri[(((size_t)(e) - 1) * NTRI + ((t) - 1)) * NQP + ((q) - 1)]
 #define YT(q, t, e) yTri[(((size_t)(e) - 1) * NTRI + ((t) - 1)) * NQP + ((q) - 1)]
 
-/* find_departure_triangles :5365-6254 (vertexDegree = 3).  Returns the number of parallel-basis errors. */
+/* find_departure_triangles :5365-6254 (vertexDegree 3, or 4 with the split of a side triangle at E5 / E6,
+ * :5807-5958).  Returns the number of parallel-basis errors. */
 int ira_departure_triangles(int nEdges, int nCells, int M, const int *nEdgesOnCell, const double *xVOE,
                             const double *yVOE, const double *xVOC, const double *yVOC, const int *verticesOnCell,
                             const int *verticesOnEdge, const int *remapEdge, const int *cellsOnEdgeRemap,
-                            const int *edgesOnEdgeRemap, const double *dpIn, int onSphere, int *maskEdge, double *xTri,
+                            const int *edgesOnEdgeRemap, int vertexDegree, const double *dpIn, int onSphere,
+                            int *maskEdge, double *xTri,
                             double *yTri, int *iCellTri, double *triArea)
 {
     int errs = 0;
@@ -777,8 +820,11 @@ int ira_departure_triangles(int nEdges, int nCells, int M, const int *nEdgesOnCe
                     if (onSphere) {
                         ev1[tc - 1][0] = en2[0] - en1[0];
                         ev1[tc - 1][1] = en2[1] - en1[1];
-                        iOtherEdge = ieoe + 2;
-                        if (iOtherEdge > 4) iOtherEdge = iOtherEdge - 4;
+                        if (vertexDegree == 3) {
+                            iOtherEdge = ieoe + 2;
+                            if (iOtherEdge > 4) iOtherEdge = iOtherEdge - 4;
+                        } else
+                            iOtherEdge = k + 4; /* E5 for V1, E6 for V2 */
                         iOtherVertex = iOtherEdge + 2;
                         en2[0] = xVOE[I2(iOtherVertex, e, NVER)];
                         en2[1] = yVOE[I2(iOtherVertex, e, NVER)];
@@ -786,6 +832,61 @@ int ira_departure_triangles(int nEdges, int nCells, int M, const int *nEdgesOnCe
                         ev2[tc - 1][1] = en2[1] - en1[1];
                     }
                     fluxSign[tc - 1] = side == 0 ? 1 : -1;
+                    if (vertexDegree == 4) { /* :5807-5958 */
+                        int hitMain, e56 = edgesOnEdgeRemap[I2(k + 4, e, NEER)];
+                        double ip0[2];
+                        if (e56 >= 1 && e56 <= nEdges) {
+                            en2[0] = xVOE[I2(k + 6, e, NVER)]; /* V7 or V8 */
+                            en2[1] = yVOE[I2(k + 6, e, NVER)];
+                            hitMain = find_line_intersection(dp[0], dp[1], en1, en2, ip0);
+                        } else
+                            hitMain = 0;
+                        if (hitMain) {
+                            /* the triangle just made ends at the line of the main edge instead */
+                            XT(3, tc, e) = ip0[0];
+                            YT(3, tc, e) = ip0[1];
+                            if (side == 0) { /* IP in the left half-plane: this triangle lies in the right one */
+                                c = cellsOnEdgeRemap[I2(k + 4, e, NEER)]; /* C5 or C6 */
+                                iCellTri[I2(tc, e, NTRI)] = c;
+                                for (int iv = 1; iv <= nEdgesOnCell[c - 1]; iv++)
+                                    if (verticesOnEdge[I2(k, e, 2)] == verticesOnCell[I2(iv, c, M)]) tvoc[tc - 1] = iv;
+                                if (onSphere) {
+                                    iOtherVertex = ivoer + 2; /* V3 -> V5, V4 -> V6 */
+                                    ev1[tc - 1][0] = xVOE[I2(iOtherVertex, e, NVER)] - en1[0];
+                                    ev1[tc - 1][1] = yVOE[I2(iOtherVertex, e, NVER)] - en1[1];
+                                }
+                            } else if (onSphere) {
+                                iOtherVertex = ivoer - 2; /* V5 -> V3, V6 -> V4 */
+                                ev1[tc - 1][0] = xVOE[I2(iOtherVertex, e, NVER)] - en1[0];
+                                ev1[tc - 1][1] = yVOE[I2(iOtherVertex, e, NVER)] - en1[1];
+                            }
+                            /* second triangle: V1 / V2, IP0, IP on the side where IP lies */
+                            tc = tc + 1;
+                            XT(1, tc, e) = ev[k - 1][0];
+                            YT(1, tc, e) = ev[k - 1][1];
+                            XT(2, tc, e) = ip0[0];
+                            YT(2, tc, e) = ip0[1];
+                            XT(3, tc, e) = ip[0];
+                            YT(3, tc, e) = ip[1];
+                            c = side == 0 ? cellsOnEdgeRemap[I2(k + 2, e, NEER)] : cellsOnEdgeRemap[I2(k + 4, e, NEER)];
+                            iCellTri[I2(tc, e, NTRI)] = c;
+                            tvoe[tc - 1] = tvoe[tc - 2];
+                            for (int iv = 1; iv <= nEdgesOnCell[c - 1]; iv++)
+                                if (verticesOnEdge[I2(k, e, 2)] == verticesOnCell[I2(iv, c, M)]) tvoc[tc - 1] = iv;
+                            if (onSphere) {
+                                ev1[tc - 1][0] = xVOE[I2(ivoer, e, NVER)] - en1[0];
+                                ev1[tc - 1][1] = yVOE[I2(ivoer, e, NVER)] - en1[1];
+                                ev2[tc - 1][0] = ev2[tc - 2][0];
+                                ev2[tc - 1][1] = ev2[tc - 2][1];
+                            }
+                            fluxSign[tc - 1] = fluxSign[tc - 2];
+                        } else if (side == 1) { /* no crossing of E5 / E6; IP and triangle in the right half-plane */
+                            c = cellsOnEdgeRemap[I2(k + 4, e, NEER)];
+                            iCellTri[I2(tc, e, NTRI)] = c;
+                            for (int iv = 1; iv <= nEdgesOnCell[c - 1]; iv++)
+                                if (verticesOnEdge[I2(k, e, 2)] == verticesOnCell[I2(iv, c, M)]) tvoc[tc - 1] = iv;
+                        }
+                    }
                     dp[k - 1][0] = ip[0];
                     dp[k - 1][1] = ip[1];
                 }

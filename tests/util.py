@@ -13,6 +13,12 @@ def get_mesh(name, **kw):
         if name.startswith("hex"):
             _, nx, ny = name.split("_")
             _MESH_CACHE[key] = meshmod.make_planar_hex_mesh(int(nx), int(ny), 1.28e6 / int(nx))
+        elif name.startswith("quad"):      # quad_<nx>_<ny>: planar squares
+            _, nx, ny = name.split("_")
+            _MESH_CACHE[key] = meshmod.make_planar_quad_mesh(int(nx), int(ny), 1.28e6 / int(nx))
+        elif name.startswith("llquad"):    # llquad_<nlon>_<nlat>: latitude-longitude band on the sphere
+            _, nx, ny = name.split("_")
+            _MESH_CACHE[key] = meshmod.make_latlon_quad_mesh(int(nx), int(ny), **kw)
         elif name.startswith("var"):
             _MESH_CACHE[key] = meshmod.make_variable_sphere_mesh(int(name[3:]), **kw)
         elif name.startswith("geo"):
