@@ -47,7 +47,7 @@ module seaice_hip_interface
      integer(c_int32_t) :: useColumnVerticalThermodynamics = 0
      integer(c_int32_t) :: iceStrengthFormulation = 1, ridgingParticipation = 1, ridgingRedistribution = 1
      real(c_double)     :: ridgingEfoldingScale = 3.0_c_double, ridgingWorkRatio = 17.0_c_double
-     integer(c_int32_t) :: wachspressIntegrationType = 1   ! 1 dunavant (order 8), 2 trapezoidal (orders 1..21)
+     integer(c_int32_t) :: wachspressIntegrationType = 1   ! 1 dunavant, 2 trapezoidal (orders 1..21), 3 fekete
   end type sih_evp_config
 
   !> struct sih_ir_desc

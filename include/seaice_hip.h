@@ -84,7 +84,7 @@ typedef struct sih_evp_config {
     int32_t constitutiveRelation;     /* 1 evp, 2 evp_revised, 3 linear */
     int32_t variationalBasis;         /* 1 wachspress, 2 pwl (both computed on device), 0 none (host supplies it) */
     int32_t variationalDenominator;   /* 0 original, 1 alternate */
-    int32_t wachspressIntegrationOrder; /* dunavant rule order; 8 is the reference default */
+    int32_t wachspressIntegrationOrder; /* order of the rule; dunavant 8 is the reference default */
     int32_t rotateCartesianGrid;
     int32_t includeMetricTerms;
     int32_t useAirStress;
@@ -123,8 +123,9 @@ typedef struct sih_evp_config {
     int32_t ridgingRedistribution;    /* config_ridging_redistribution_function (krdg_redist): 0 Hibler80, 1 exponential */
     double ridgingEfoldingScale;      /* config_ridiging_efolding_scale (mu_rdg), 3.0 */
     double ridgingWorkRatio;          /* config_ratio_ridging_work_to_PE (Cf), 17.0 */
-    int32_t wachspressIntegrationType; /* config_wachspress_integration_type: 0 or 1 dunavant (order 8 only),
-                                          2 trapezoidal (orders 1..21); wachspress.F:1223-1387 */
+    int32_t wachspressIntegrationType; /* config_wachspress_integration_type: 0 or 1 dunavant (orders 1-10, 12),
+                                          2 trapezoidal (orders 1..21), 3 fekete (orders 1-6, 8, 9);
+                                          wachspress.F:1223-1941 */
 } sih_evp_config;
 
 /* ---- life cycle ----------------------------------------------------------------------------- */

@@ -19,14 +19,18 @@ def hipcc():
     return "hipcc"
 
 
+def _headers():
+    d = os.path.join(HERE, "csrc")
+    return [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith(".h")] + [os.path.join(ROOT, "include", "seaice_hip.h")]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(HERE, "csrc", s) for s in SOURCES] + [
-        os.path.join(HERE, "csrc", "sih_internal.h"), os.path.join(HERE, "csrc", "sih_normals.h"),
-        os.path.join(ROOT, "include", "seaice_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    d = os.path.join(HERE, "csrc")
+    deps = [os.path.join(d, f) for f in os.listdir(d) if f.endswith(".hip")] + _headers()
+    return any(os.path.getmtime(x) > t for x in deps if os.path.exists(x))
 
 
 def build(force=False, verbose=True):
@@ -44,8 +48,7 @@ def build(force=False, verbose=True):
         o = os.path.join(HERE, "csrc", "obj", os.path.basename(s) + ".o")
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(
-                os.path.getmtime(s), os.path.getmtime(os.path.join(HERE, "csrc", "sih_internal.h")),
-                os.path.getmtime(os.path.join(ROOT, "include", "seaice_hip.h"))):
+                [os.path.getmtime(s)] + [os.path.getmtime(h) for h in _headers()]):
             cmd = [hipcc()] + flags + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)

@@ -11,20 +11,16 @@
 
 SihField *sih_find_field(sih_ctx *c, const char *name);
 
-// Dunavant (1985) degree-8 rule, 16 points, as carried (14 digits) by
-// src/shared/mpas_seaice_velocity_solver_wachspress.F:1573-1597; normalisation factor 2 (:1426)
-static const double h_dunU[16] = {0.33333333333333, 0.45929258829272, 0.45929258829272, 0.08141482341455,
-                                  0.17056930775176, 0.17056930775176, 0.65886138449648, 0.05054722831703,
-                                  0.05054722831703, 0.89890554336594, 0.26311282963464, 0.72849239295540,
-                                  0.00839477740996, 0.72849239295540, 0.26311282963464, 0.00839477740996};
-static const double h_dunV[16] = {0.33333333333333, 0.45929258829272, 0.08141482341455, 0.45929258829272,
-                                  0.17056930775176, 0.65886138449648, 0.17056930775176, 0.05054722831703,
-                                  0.89890554336594, 0.05054722831703, 0.72849239295540, 0.00839477740996,
-                                  0.26311282963464, 0.26311282963464, 0.00839477740996, 0.72849239295540};
-static const double h_dunW[16] = {0.14431560767779, 0.09509163426728, 0.09509163426728, 0.09509163426728,
-                                  0.10321737053472, 0.10321737053472, 0.10321737053472, 0.03245849762320,
-                                  0.03245849762320, 0.03245849762320, 0.02723031417443, 0.02723031417443,
-                                  0.02723031417443, 0.02723031417443, 0.02723031417443, 0.02723031417443};
+// the Dunavant and Fekete integration rules as a table of numbers (get_integration_factors_dunavant / _fekete,
+// src/shared/mpas_seaice_velocity_solver_wachspress.F:1401-1941); normalisation factor 2 for all of them (:1426, :1751)
+#include "wachspress_rules.h"
+
+static const sih_rule_entry *findRule(int kind, int order)
+{
+    for (int r = 0; r < SIH_RULE_COUNT; r++)
+        if (sih_rule_table[r].kind == kind && sih_rule_table[r].order == order) return &sih_rule_table[r];
+    return nullptr;
+}
 
 struct InitArgs {
     int nCells, nVertices, nVerticesSolve, M, padC, padV, rotate, onASphere, includeMetric, alternateDenominator;
@@ -628,8 +624,13 @@ extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
     if (cfg->variationalBasis == 1) {
         // get_integration_factors, wachspress.F:1223-1285
         if (cfg->wachspressIntegrationType == 0 || cfg->wachspressIntegrationType == 1) {
-            if (cfg->wachspressIntegrationOrder != 8) {
-                sih_set_error("of the dunavant rules only order 8 (the reference default) is implemented on the device");
+            if (!findRule(1, cfg->wachspressIntegrationOrder)) {  // the reference's message, :1706
+                sih_set_error("get_integration_factors_dunavant: Unimplemented integration order for Dunavant wachspress integration");
+                return SIH_ERR_UNSUPPORTED;
+            }
+        } else if (cfg->wachspressIntegrationType == 3) {
+            if (!findRule(3, cfg->wachspressIntegrationOrder)) {  // :1935
+                sih_set_error("get_integration_factors_fekete: Unimplemented integration order for Fekete wachspress integration");
                 return SIH_ERR_UNSUPPORTED;
             }
         } else if (cfg->wachspressIntegrationType == 2) {
@@ -637,8 +638,8 @@ extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
                 sih_set_error("trapezoidal integration: the order must lie between 1 and 21");
                 return SIH_ERR_UNSUPPORTED;
             }
-        } else {
-            sih_set_error("Unknown Wachspress integration type (the fekete rules are not implemented on the device)");
+        } else {  // :1279
+            sih_set_error("get_integration_factors: Unknown wachspress integration type");
             return SIH_ERR_UNSUPPORTED;
         }
     }
@@ -725,10 +726,11 @@ extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
                 }
             qNorm = 6.0 * ((double)n * (double)n);
         } else {
-            nQ = 16;
-            rule.insert(rule.end(), h_dunU, h_dunU + 16);
-            rule.insert(rule.end(), h_dunV, h_dunV + 16);
-            rule.insert(rule.end(), h_dunW, h_dunW + 16);
+            const sih_rule_entry *r = findRule(cfg->wachspressIntegrationType == 3 ? 3 : 1, cfg->wachspressIntegrationOrder);
+            nQ = r->n;
+            rule.insert(rule.end(), sih_rule_u + r->first, sih_rule_u + r->first + nQ);
+            rule.insert(rule.end(), sih_rule_v + r->first, sih_rule_v + r->first + nQ);
+            rule.insert(rule.end(), sih_rule_w + r->first, sih_rule_w + r->first + nQ);
             qNorm = 2.0;
         }
         if (!c->d_rule) {

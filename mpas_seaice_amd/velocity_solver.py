@@ -125,10 +125,10 @@ def _evp_config(domain, block):
     c.variationalDenominator = 1 if den == "alternate" else 0
     c.wachspressIntegrationOrder = int(cfg["config_wachspress_integration_order"])
     itype = cfg["config_wachspress_integration_type"]
-    if itype not in ("dunavant", "trapezoidal"):  # get_integration_factors, wachspress.F:1250-1283
-        raise _lib.SeaiceHipError("Unknown Wachspress integration type (on the device: 'dunavant' order 8 or "
-                                  "'trapezoidal'): " + str(itype))
-    c.wachspressIntegrationType = 1 if itype == "dunavant" else 2
+    types = {"dunavant": 1, "trapezoidal": 2, "fekete": 3}   # get_integration_factors, wachspress.F:1250-1283
+    if itype not in types:
+        raise _lib.SeaiceHipError("get_integration_factors: Unknown wachspress integration type: " + str(itype))
+    c.wachspressIntegrationType = types[itype]
     c.rotateCartesianGrid = int(bool(cfg["config_rotate_cartesian_grid"]))
     c.includeMetricTerms = int(bool(cfg["config_include_metric_terms"]))
     c.useAirStress = int(bool(cfg["config_use_air_stress"]))

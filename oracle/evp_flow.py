@@ -170,7 +170,7 @@ def _interp_c2v(b, vert, cell):
 
 def integration_rule(cfg):
     """get_integration_factors (wachspress.F:1223-1285): points, weights and normalisation on the unit triangle"""
-    types = {"dunavant": 1, "trapezoidal": 2}
+    types = {"dunavant": 1, "trapezoidal": 2, "fekete": 3}
     t = cfg["config_wachspress_integration_type"]
     if t not in types:
         raise ValueError("Unknown Wachspress integration type for the oracle: " + str(t))

@@ -197,22 +197,9 @@ void ora_interior_vertices(int *interiorVertex, int nVerticesSolve, int vertexDe
 
 /* ------------------------------------------------------------------ Wachspress basis */
 
-/* D. A. Dunavant (1985) degree-8 rule, 16 points, to the 14 digits the reference carries
- * (mpas_seaice_velocity_solver_wachspress.F:1573-1597); normalisation factor 2 (:1426). */
-#define NQ 16
-static const double dunU[NQ] = {0.33333333333333, 0.45929258829272, 0.45929258829272, 0.08141482341455,
-                                0.17056930775176, 0.17056930775176, 0.65886138449648, 0.05054722831703,
-                                0.05054722831703, 0.89890554336594, 0.26311282963464, 0.72849239295540,
-                                0.00839477740996, 0.72849239295540, 0.26311282963464, 0.00839477740996};
-static const double dunV[NQ] = {0.33333333333333, 0.45929258829272, 0.08141482341455, 0.45929258829272,
-                                0.17056930775176, 0.65886138449648, 0.17056930775176, 0.05054722831703,
-                                0.89890554336594, 0.05054722831703, 0.72849239295540, 0.00839477740996,
-                                0.26311282963464, 0.26311282963464, 0.00839477740996, 0.72849239295540};
-static const double dunW[NQ] = {0.14431560767779, 0.09509163426728, 0.09509163426728, 0.09509163426728,
-                                0.10321737053472, 0.10321737053472, 0.10321737053472, 0.03245849762320,
-                                0.03245849762320, 0.03245849762320, 0.02723031417443, 0.02723031417443,
-                                0.02723031417443, 0.02723031417443, 0.02723031417443, 0.02723031417443};
-static const double dunNorm = 2.0;
+/* the Dunavant and Fekete rules (get_integration_factors_dunavant / _fekete, wachspress.F:1401-1941) as a table of
+ * numbers */
+#include "wachspress_rules.h"
 
 #define MAXE 16
 
@@ -322,21 +309,26 @@ static void wach_basis_derivative(const wach_cell *w, int i, double x, double y,
 }
 
 /* seaice_init_velocity_solver_wachspress, wachspress.F:46-161 with calculate_wachspress_derivatives
- * (:1083-1206) and integrate_wachspress / integrate_wachspress_polygon (:179-467), Dunavant order 8. */
-/* get_integration_factors (:1223-1285): the rule on the unit triangle.  type 1 dunavant (order 8 only, the
- * table above), type 2 trapezoidal (:1301-1387, any order up to 21 = 253 points).  u, v, w need 256 entries.
- * Returns the number of points, 0 for a rule that is not restated. */
+ * (:1083-1206) and integrate_wachspress / integrate_wachspress_polygon (:179-467). */
+/* get_integration_factors (:1223-1285): the rule on the unit triangle.  type 1 dunavant (:1401-1712, orders 1-10 and
+ * 12), type 3 fekete (:1726-1941, orders 1-6, 8, 9), type 2 trapezoidal (:1301-1387, any order up to 21 = 253
+ * points).  u, v, w need 256 entries.  Returns the number of points, 0 for a rule the reference does not have
+ * ("Unimplemented integration order", :1706, :1935). */
 int ora_integration_rule(int type, int order, double *u, double *v, double *w, double *normalizationFactor)
 {
-    if (type == 1) {
-        if (order != 8) return 0;
-        for (int p = 0; p < NQ; p++) {
-            u[p] = dunU[p];
-            v[p] = dunV[p];
-            w[p] = dunW[p];
-        }
-        *normalizationFactor = dunNorm;
-        return NQ;
+    if (type == 1 || type == 3) {
+        for (int r = 0; r < SIH_RULE_COUNT; r++)
+            if (sih_rule_table[r].kind == type && sih_rule_table[r].order == order) {
+                const int n = sih_rule_table[r].n, f = sih_rule_table[r].first;
+                for (int p = 0; p < n; p++) {
+                    u[p] = sih_rule_u[f + p];
+                    v[p] = sih_rule_v[f + p];
+                    w[p] = sih_rule_w[f + p];
+                }
+                *normalizationFactor = 2.0; /* :1426, :1751 */
+                return n;
+            }
+        return 0;
     }
     if (type == 2) {
         int n = order;

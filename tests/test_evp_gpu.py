@@ -408,10 +408,34 @@ def test_trapezoidal_wachspress_integration(oracle, order):
     compare_domains(dev, ref, STATE, 1e-10)
 
 
+@pytest.mark.parametrize("kind,order", [("dunavant", 1), ("dunavant", 4), ("dunavant", 12), ("fekete", 4), ("fekete", 9)])
+def test_other_integration_rules_of_the_reference(oracle, kind, order):
+    """config_wachspress_integration_type / _order other than the default (dunavant, 8): basis integrals and a whole
+    velocity-solver step against the oracle with the same rule"""
+    cfg = {"config_elastic_subcycle_number": 30, "config_wachspress_integration_type": kind,
+           "config_wachspress_integration_order": order}
+    ref = cases.make_domain(get_mesh("QU480"), "QU480", configs=cfg)
+    dev = cases.make_domain(get_mesh("QU480"), "QU480", configs=cfg)
+    oracle.seaice_init_velocity_solver(ref)
+    oracle.seaice_run_velocity_solver(ref)
+    vs.seaice_mesh_pool_create(dev)
+    try:
+        vs.seaice_init_velocity_solver(dev)
+        vs.seaice_run_velocity_solver(dev)
+    finally:
+        vs.seaice_mesh_pool_destroy(dev)
+    static = [("velocity_variational", k) for k in ("basisIntegralsU", "basisIntegralsV", "basisIntegralsMetric",
+                                                    "variationalDenominator")]
+    compare_domains(dev, ref, static, 1e-13)
+    compare_domains(dev, ref, STATE, 1e-10)
+
+
 def test_unsupported_integration_rules_are_refused():
     from mpas_seaice_amd.lib import SeaiceHipError
-    for cfg, msg in (({"config_wachspress_integration_type": "fekete"}, "integration type"),
-                     ({"config_wachspress_integration_order": 6}, "order 8"),
+    for cfg, msg in (({"config_wachspress_integration_type": "simpson"}, "Unknown wachspress integration type"),
+                     ({"config_wachspress_integration_order": 11}, "Unimplemented integration order for Dunavant"),
+                     ({"config_wachspress_integration_type": "fekete", "config_wachspress_integration_order": 7},
+                      "Unimplemented integration order for Fekete"),
                      ({"config_wachspress_integration_type": "trapezoidal", "config_wachspress_integration_order": 30},
                       "between 1 and 21")):
         dom = cases.make_domain(get_mesh("QU480"), "QU480", configs=cfg)

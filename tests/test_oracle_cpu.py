@@ -382,7 +382,7 @@ def test_trapezoidal_integration_rule(oracle):
         assert abs((w * u).sum() / norm - 1.0 / 6.0) < 1e-14     # integral of x
         assert abs((w * v).sum() / norm - 1.0 / 6.0) < 1e-14
     with pytest.raises(ValueError):
-        oracle.integration_rule({"config_wachspress_integration_type": "fekete", "config_wachspress_integration_order": 4})
+        oracle.integration_rule({"config_wachspress_integration_type": "fekete", "config_wachspress_integration_order": 7})
     mesh = get_mesh("QU480")
     ref = _init(oracle, mesh)
     SM8 = ref.blocklist[0].structs["velocity_variational"]["basisIntegralsMetric"]
