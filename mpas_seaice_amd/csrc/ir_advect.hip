@@ -68,11 +68,21 @@ struct IrDev {
 // The flux kernel gathers them by source cell; one cell's layers then sit in one or two cache lines instead
 // of 3 L different ones.
 #define IR_LCHUNK 8  // layers handled together (flux threads, staging of the records)
-#define IR_REC(T, cat, pc, c, layer) ((((size_t)(cat) * (pc) + (c)) * (T).L + (layer)) * 3)
+#define IR_REC(T, cat, pc, c, layer) ((((size_t)(cat) * (pc) + (c)) * (T).S + (layer)) * 3)
+// The table's pointers are read from memory by the kernels, so the compiler cannot tell that they point to global
+// memory and would use flat loads and stores for everything behind them; a flat access also counts as an LDS access,
+// and a kernel that waits for its LDS traffic (all three large kernels stage through LDS) then waits for every
+// outstanding load behind these pointers as well, look-ahead included.  Declared as global for the device pass.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(1))) double IrG;
+#else
+typedef double IrG;
+#endif
 struct IrTabEntry {
-    double *val, *rec, *xB, *yB, *prod, *flux;
+    IrG *val, *rec, *xB, *yB, *prod, *flux;
     int L, parent, nLev, hasChild;
     int chain[4];  // tracer indices from the mass-like field (chain[0]) to this tracer (chain[nLev-1])
+    int S;         // records per (category, cell) row of `rec` (= L: one row per tracer; a row shared by all tracers was slower)
 };
 
 struct IrTracer {
@@ -817,7 +827,7 @@ __global__ void __launch_bounds__(256) k_ir_reconstruct(IrDev d, const IrTabEntr
                         if (j < T.nLev - 1) {
                             const IrTabEntry &A = tab[T.chain[j]];
                             size_t kj = (size_t)(A.L == 1 ? cat : cat * A.L + layer) * pc + c;
-                            const double *r = A.rec + IR_REC(A, cat, pc, c, A.L == 1 ? 0 : layer);
+                            const IrG *r = A.rec + IR_REC(A, cat, pc, c, A.L == 1 ? 0 : layer);
                             mean[j] = A.val[kj];
                             ce[j] = r[0];
                             gx[j] = r[1];
@@ -870,9 +880,21 @@ __global__ void __launch_bounds__(256) k_ir_reconstruct(IrDev d, const IrTabEntr
         __syncthreads();
         {  // staged records -> memory: per cell nlc * 3 consecutive doubles starting at layer l0
             const int row = nlc * 3, total = nValid * row;
-            for (int i = threadIdx.x; i < total; i += blockDim.x) {
-                const int cl = i / row;
-                T.rec[IR_REC(T, cat, pc, c0 + cl, l0) + (i - cl * row)] = stage[i];
+            if (nlc == T.L) {
+                // the whole tracer in one chunk: the rows of the block's cells follow each other in memory as they do
+                // in the staging area, so this is one linear copy (16 bytes a lane; the block's first record sits at a
+                // multiple of 64 L records)
+                IrG *dst = T.rec + IR_REC(T, cat, pc, c0, 0);
+                typedef double IrPair __attribute__((ext_vector_type(2)));
+                const int pairs = total >> 1;
+                for (int i = threadIdx.x; i < pairs; i += blockDim.x)
+                    ((__attribute__((address_space(1))) IrPair *)dst)[i] = reinterpret_cast<const IrPair *>(stage)[i];
+                if ((total & 1) && threadIdx.x == 0) dst[total - 1] = stage[total - 1];
+            } else {
+                for (int i = threadIdx.x; i < total; i += blockDim.x) {
+                    const int cl = i / row;
+                    T.rec[IR_REC(T, cat, pc, c0 + cl, l0) + (i - cl * row)] = stage[i];
+                }
             }
         }
         __syncthreads();  // the next chunk reuses the staging rows; later tracers read these records
@@ -1160,7 +1182,7 @@ __global__ void __launch_bounds__(256) k_ir_flux(IrDev d, const IrTabEntry *__re
                 for (int j = 0; j < 4; j++) {
                     if (j < T.nLev) {
                         const IrTabEntry &A = tab[T.chain[j]];
-                        const double *r = A.rec + IR_REC(A, cat, pc, c, A.L == 1 ? 0 : layer);
+                        const IrG *r = A.rec + IR_REC(A, cat, pc, c, A.L == 1 ? 0 : layer);
                         const double cj = r[0], gxj = r[1], gyj = r[2];
 #pragma unroll
                         for (int q = 0; q < 6; q++) val[q] = val[q] * (cj + gxj * xq[q] + gyj * yq[q]);
@@ -1208,14 +1230,16 @@ __global__ void __launch_bounds__(256) k_ir_flux_planes(IrDev d, const IrTabEntr
     // ancestors (and the tracer itself if it has one layer) whose value does not depend on the layer
     int nShared = 0;
     const double *recp[4];  // records of category cat, starting at layer0 for a multi-layer chain member
-    int Lk[4];
+    int Lk[4], Sk[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         recp[j] = nullptr;
         Lk[j] = 1;
+        Sk[j] = 1;
         if (j < T.nLev) {
             const IrTabEntry &A = tab[T.chain[j]];
             Lk[j] = A.L;
+            Sk[j] = A.S;
             recp[j] = A.rec + IR_REC(A, cat, pc, 0, A.L == 1 ? 0 : layer0);
             if (A.L == 1 && nShared == j) nShared = j + 1;
         }
@@ -1242,7 +1266,7 @@ __global__ void __launch_bounds__(256) k_ir_flux_planes(IrDev d, const IrTabEntr
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (j < nShared) {
-                const double *r = recp[j] + (size_t)c * 3;  // nShared members have one layer
+                const double *r = recp[j] + (size_t)c * Sk[j] * 3;  // nShared members have one layer
                 const double cj = r[0], gxj = r[1], gyj = r[2];
 #pragma unroll
                 for (int q = 0; q < 6; q++) pv[q] = pv[q] * (cj + gxj * xq[q] + gyj * yq[q]);
@@ -1263,7 +1287,7 @@ __global__ void __launch_bounds__(256) k_ir_flux_planes(IrDev d, const IrTabEntr
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (j >= nShared && j < T.nLev) {
-                        const double *r = recp[j] + ((size_t)c * Lk[j] + (Lk[j] == 1 ? 0 : ly)) * 3;
+                        const double *r = recp[j] + ((size_t)c * Sk[j] + (Lk[j] == 1 ? 0 : ly)) * 3;
                         const double cj = r[0], gxj = r[1], gyj = r[2];
 #pragma unroll
                         for (int q = 0; q < 6; q++) val[q] = val[q] * (cj + gxj * xq[q] + gyj * yq[q]);
@@ -1295,8 +1319,8 @@ struct IrStep {
 // one tracer (all its layers) on one triangle: value at the quadrature points times the parent's (level > 0),
 // the integral added to the tracer's rows in LDS, the values left for the children if it has any
 template <int LEVEL>
-__device__ __forceinline__ void irWalkStep(const IrDev &d, const double *__restrict__ rec, int L,
-                                           const double *__restrict__ nextRec, double (&cur)[3], double *f, double area,
+__device__ __forceinline__ void irWalkStep(const IrDev &d, const IrG *__restrict__ rec, int L,
+                                           const IrG *__restrict__ nextRec, double (&cur)[3], double *f, double area,
                                            const double (&xq)[6], const double (&yq)[6], const double (&par)[6],
                                            double (&own)[6], bool keep, bool first)
 {
@@ -1304,7 +1328,7 @@ __device__ __forceinline__ void irWalkStep(const IrDev &d, const double *__restr
         // `cur` holds this layer's record; the next one (the next layer's, or the first of the next tracer) is
         // requested now, so that it travels while this layer is worked on
         const double cj = cur[0], gxj = cur[1], gyj = cur[2];
-        const double *nx = ly + 1 < L ? rec + (ly + 1) * 3 : nextRec;
+        const IrG *nx = ly + 1 < L ? rec + (ly + 1) * 3 : nextRec;
         if (nx) {
             cur[0] = nx[0];
             cur[1] = nx[1];
@@ -1376,7 +1400,7 @@ __global__ void __launch_bounds__(256, 4) k_ir_flux_walk(IrDev d, const IrTabEnt
 #pragma unroll
         for (int q = 0; q < 6; q++) lv0[q] = lv1[q] = lv2[q] = 1.0;
         if (!curReady) {
-            const double *r0 = T0.rec + IR_REC(T0, cat, pc, c, 0);
+            const IrG *r0 = T0.rec + IR_REC(T0, cat, pc, c, 0);
             cur[0] = r0[0];
             cur[1] = r0[1];
             cur[2] = r0[2];
@@ -1384,8 +1408,8 @@ __global__ void __launch_bounds__(256, 4) k_ir_flux_walk(IrDev d, const IrTabEnt
         for (int si = 0; si < nSteps; si++) {
             const IrStep S = steps[si];  // the same for every lane: the branches below are scalar
             const IrTabEntry T = tab[S.ti];
-            const double *rec = T.rec + IR_REC(T, cat, pc, c, 0);
-            const double *nextRec = nullptr;
+            const IrG *rec = T.rec + IR_REC(T, cat, pc, c, 0);
+            const IrG *nextRec = nullptr;
             if (si + 1 < nSteps) {
                 const IrTabEntry &N = tab[steps[si + 1].ti];
                 nextRec = N.rec + IR_REC(N, cat, pc, c, 0);
@@ -1442,7 +1466,7 @@ __device__ inline void irNextField(const IrTabEntry *__restrict__ tab, int &ti, 
         layer = 0;
     }
 }
-__device__ inline const double *irFluxPlane(const IrTabEntry *__restrict__ tab, int ti, int layer, int cat, size_t pe)
+__device__ inline const IrG *irFluxPlane(const IrTabEntry *__restrict__ tab, int ti, int layer, int cat, size_t pe)
 {
     return tab[ti].flux + (size_t)(cat * tab[ti].L + layer) * pe;
 }
@@ -1491,11 +1515,11 @@ __global__ void __launch_bounds__(IR_UPD_BLOCK) k_ir_update(IrDev d, const IrTab
     if (ti2 < nT) irNextField(tab, ti2, ly2);
     double pendW[IR_UPD_PER], prodNext = 0.0;
     {
-        const double *f0 = irFluxPlane(tab, 0, 0, cat, pe);
+        const IrG *f0 = irFluxPlane(tab, 0, 0, cat, pe);
 #pragma unroll
         for (int j = 0; j < IR_UPD_PER; j++) win[j * IR_UPD_BLOCK + tid] = f0[wi[j]];
         if (ti1 < nT) {
-            const double *f1 = irFluxPlane(tab, ti1, ly1, cat, pe);
+            const IrG *f1 = irFluxPlane(tab, ti1, ly1, cat, pe);
 #pragma unroll
             for (int j = 0; j < IR_UPD_PER; j++) pendW[j] = f1[wi[j]];
         }
@@ -1513,13 +1537,13 @@ __global__ void __launch_bounds__(IR_UPD_BLOCK) k_ir_update(IrDev d, const IrTab
             const bool more1 = ti1 < nT, more2 = ti2 < nT;
             double newW[IR_UPD_PER];
             if (more2) {
-                const double *f2 = irFluxPlane(tab, ti2, ly2, cat, pe);
+                const IrG *f2 = irFluxPlane(tab, ti2, ly2, cat, pe);
 #pragma unroll
                 for (int j = 0; j < IR_UPD_PER; j++) newW[j] = f2[wi[j]];
             }
             const double prodOld = prodNext;
             if (more1) prodNext = tab[ti1].prod[(size_t)(cat * tab[ti1].L + ly1) * pc + c];
-            const double *fp = T.flux + (size_t)l * pe;
+            const IrG *fp = T.flux + (size_t)l * pe;
             double flux = 0.0;
 #pragma unroll
             for (int ie = 0; ie < M; ie++)
@@ -1571,7 +1595,7 @@ __global__ void k_ir_zap(IrDev d, const IrTabEntry *__restrict__ tab, int nT)
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.nCellsSolve) return;
     const int cat = blockIdx.y;
-    double *mass = tab[0].val;
+    IrG *mass = tab[0].val;
     double m = mass[(size_t)cat * d.padC + c];
     if (m > 0.0 && m < 1.0e-22) {
         mass[(size_t)cat * d.padC + c] = 0.0;
@@ -1635,7 +1659,7 @@ __global__ void __launch_bounds__(256) k_ir_recover_means(IrDev d, const IrTabEn
                 for (int j = 0; j < 4; j++) {
                     if (j < T.nLev) {
                         const IrTabEntry &A = tab[T.chain[j]];
-                        const double *r = A.rec + IR_REC(A, cat, pc, c, A.L == 1 ? 0 : layer);
+                        const IrG *r = A.rec + IR_REC(A, cat, pc, c, A.L == 1 ? 0 : layer);
                         const double cj = r[0], gxj = r[1], gyj = r[2];
 #pragma unroll
                         for (int q = 0; q < 6; q++) val[q] = (cj + gxj * xq[q] + gyj * yq[q]) * val[q];
@@ -2049,8 +2073,8 @@ extern "C" int sih_ir_set_tracers(sih_ctx *c, int nTracers, const char *const *n
     for (int i = 0; i < nTracers; i++) {
         const IrTracer &t = list[i];
         IrTabEntry &q = tab[i];
-        q = IrTabEntry{t.val, t.rec, t.xB, t.yB, t.prod, t.flux, t.L, t.parent, t.nParents + 1,
-                       t.hasChild ? 1 : 0, {0, 0, 0, 0}};
+        q = IrTabEntry{(IrG *)t.val, (IrG *)t.rec, (IrG *)t.xB, (IrG *)t.yB, (IrG *)t.prod, (IrG *)t.flux, t.L, t.parent, t.nParents + 1,
+                       t.hasChild ? 1 : 0, {0, 0, 0, 0}, t.L};
         int j = i;
         for (int k = t.nParents; k >= 0; k--) {
             q.chain[k] = j;
@@ -2248,7 +2272,7 @@ static int irRun(sih_ctx *c, double dt, int checks, bool timed, double *totalMs,
     else
         hipLaunchKernelGGL(k_ir_triangles<3>, dim3((d.nEdges + 127) / 128), dim3(128), 0, s, d);
     mark(3);
-    if (ir->fluxMode == 2 && ir->walkOk)
+    if (ir->fluxMode >= 2 && ir->walkOk)
         hipLaunchKernelGGL(k_ir_flux_walk, dim3(xcdGrid(gE, d.nCat)), blk, sizeof(double) * 256 * ir->nSlots, s, d,
                            ir->d_tab, ir->d_steps, ir->nSteps, ir->nSlots);
     else if (ir->fluxMode >= 1)
@@ -2370,14 +2394,14 @@ extern "C" int sih_ir_run_timed(sih_ctx *c, double dt, double *totalMs, double *
 }
 
 // records -> planes, for inspection
-__global__ void k_ir_unpack_records(IrDev d, const double *rec, int L, double *center, double *gx, double *gy)
+__global__ void k_ir_unpack_records(IrDev d, const double *rec, int L, int S, double *center, double *gx, double *gy)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.nCells) return;
     const size_t pc = d.padC;
     for (int cat = 0; cat < d.nCat; cat++)
         for (int layer = 0; layer < L; layer++) {
-            const double *r = rec + (((size_t)cat * pc + c) * L + layer) * 3;
+            const double *r = rec + (((size_t)cat * pc + c) * S + layer) * 3;
             const size_t k = (size_t)(cat * L + layer) * pc + c;
             center[k] = r[0];
             gx[k] = r[1];
@@ -2404,7 +2428,7 @@ extern "C" int sih_ir_unpack_reconstruction(sih_ctx *c)
             *dst[k] = (double *)sih_find_field(c, fn.c_str())->d;
         }
         hipLaunchKernelGGL(k_ir_unpack_records, dim3((ir->d.nCells + 255) / 256), dim3(256), 0, c->stream, ir->d, t.rec, t.L,
-                           t.center, t.gx, t.gy);
+                           t.L, t.center, t.gx, t.gy);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
