@@ -466,8 +466,8 @@ int sih_comm_status(sih_ctx *ctx);
  * Replaces, for one block, seaice_init_advection_incremental_remap and the per-block part of
  * seaice_run_advection_incremental_remap (src/shared/mpas_seaice_advection_incremental_remap.F:165,
  * :2338) with incremental_remap_block (:2740).  Hexagonal meshes (vertexDegree 3) and quadrilateral meshes
- * (vertexDegree 4: six side edges and cells per edge, :1133-1172, and the split of side triangles, :5807-5958); the
- * velocity solver and the upwind advection take vertexDegree 3 only and refuse a quadrilateral block at their set-up. */
+ * (vertexDegree 4: six side edges and cells per edge, :1133-1172, and the split of side triangles, :5807-5958).  The
+ * velocity solver takes a quadrilateral block in its variational scheme on one block; the upwind advection refuses it. */
 
 /* mesh-pool fields the advection reads beyond sih_mesh_desc, and the options it reads
  * (incremental_remap.F:257-340, :2899-2901).  Pointers are borrowed for the duration of the call. */

@@ -23,7 +23,7 @@ static const sih_rule_entry *findRule(int kind, int order)
 }
 
 struct InitArgs {
-    int nCells, nVertices, nVerticesSolve, M, padC, padV, rotate, onASphere, includeMetric, alternateDenominator;
+    int nCells, nVertices, nVerticesSolve, M, D, padC, padV, rotate, onASphere, includeMetric, alternateDenominator;
     int computeHalo;
     // integration rule on the unit triangle: points (qU, qV), weights qW, sum divided by qNorm
     int nQ;
@@ -67,7 +67,7 @@ __global__ void k_init_vertices(InitArgs a)
         a.tanLat[v] = 0.0;
     }
     int nInterior = 0;
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < a.D; k++) {
         int c = a.cov[k * a.padV + v];
         int j = -1;
         if (c < a.nCells) {
@@ -81,10 +81,10 @@ __global__ void k_init_vertices(InitArgs a)
         a.gidx[k * a.padV + v] = (j >= 0) ? j * a.padC + c : a.nCells;
     }
     // vertices the vertex loops cover: the owned ones (the reference's 1..nVerticesSolve) and, on request,
-    // halo vertices that see all three of their cells inside the block
-    const int active = (v < a.nVerticesSolve) || (a.computeHalo && nInterior == 3);
+    // halo vertices that see all of their cells inside the block
+    const int active = (v < a.nVerticesSolve) || (a.computeHalo && nInterior == a.D);
     a.vActive[v] = active ? 1 : 0;
-    if (active) a.interiorVertex[v] = (nInterior == 3) ? 1 : 0;
+    if (active) a.interiorVertex[v] = (nInterior == a.D) ? 1 : 0;
 }
 
 // ---- Wachspress basis on one polygon (wachspress.F:535-1069) --------------------------------
@@ -516,7 +516,7 @@ __global__ void k_var_denominator(InitArgs a)
     if (v >= a.nVertices) return;
     if (a.alternateDenominator) {
         double d = 0.0;
-        for (int k = 0; k < 3; k++) {
+        for (int k = 0; k < a.D; k++) {
             int c = a.cov[k * a.padV + v];
             int j = a.cvav[k * a.padV + v] - 1;
             if (c >= a.nCells || j < 0) continue;
@@ -546,6 +546,7 @@ static InitArgs makeInitArgs(sih_ctx *c)
     a.nVertices = c->nVertices;
     a.nVerticesSolve = c->nVerticesSolve;
     a.M = c->M;
+    a.D = c->D;
     a.padC = c->padC;
     a.padV = c->padV;
     a.rotate = c->cfg.rotateCartesianGrid;
@@ -601,8 +602,8 @@ extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
         sih_set_error("sih_evp_init: null argument");
         return SIH_ERR_ARG;
     }
-    if (c->D != 3) {
-        sih_set_error("velocity solver: only vertexDegree = 3 (hexagonal meshes) is implemented");
+    if (c->D != 3 && (cfg->strainScheme != 0 || cfg->stressDivergenceScheme != 0 || cfg->computeHaloVertices)) {
+        sih_set_error("velocity solver on a mesh with vertexDegree 4: the variational scheme on one block only");
         return SIH_ERR_UNSUPPORTED;
     }
     if (cfg->constitutiveRelation < 1 || cfg->constitutiveRelation > 3) {

@@ -1003,7 +1003,7 @@ int sih_persist_setup(sih_ctx *c)
     sih_persist_state *s = new sih_persist_state();
     c->persist = s;
     const int M = c->M, nC = c->nCells, nV = c->nVertices;
-    if (!c->sparseGrad || !c->splitCells || M > 8 || c->cfg.strainScheme != 0 || c->cfg.stressDivergenceScheme != 0 ||
+    if (!c->sparseGrad || !c->splitCells || M > 8 || c->D != 3 || c->cfg.strainScheme != 0 || c->cfg.stressDivergenceScheme != 0 ||
         c->cfg.averageVariationalStrain || c->cfg.useSpecialBoundariesVelocity || c->cfg.useSpecialBoundariesVelocityMasks) {
         s->reason = 1;
         return SIH_OK;

@@ -166,7 +166,7 @@ __global__ void k_pre0_cells(SihDev d)
 __device__ inline double interpC2V(const SihDev &d, int v, const double *cellVar)
 {
     double acc = 0.0, tot = 0.0;
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < d.D; k++) {
         int c = d.cov[k * d.padV + v];
         acc = acc + d.areaCell[c] * cellVar[c];
         tot = tot + d.areaCell[c];
@@ -757,10 +757,13 @@ __global__ void __launch_bounds__(256) k_avg_strain_vertices(SihDev d)
     if (v >= d.nVerticesSolve) return;
     const int PV = d.padV;
     double a11 = 0.0, a22 = 0.0, a12 = 0.0, den = 0.0;
-    int g[3];
-    bool ok[3];
+    int g[4];
+    bool ok[4];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < 4; k++) {
+        ok[k] = false;
+        g[k] = 0;
+        if (k >= d.D) continue;
         const int c = d.cov[k * PV + v];
         ok[k] = c < d.nCells;
         g[k] = d.gidx[k * PV + v];
@@ -776,7 +779,7 @@ __global__ void __launch_bounds__(256) k_avg_strain_vertices(SihDev d)
     a22 = a22 / den;
     a12 = a12 / den;
 #pragma unroll
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < 4; k++)
         if (ok[k]) {
             d.strain11[g[k]] = a11;
             d.strain22[g[k]] = a22;
@@ -851,11 +854,21 @@ __global__ void __launch_bounds__(256) k_sub_vertices(SihDev d, const int *__res
         dU = d.divU[v];
         dV = d.divV[v];
     } else {
+        // the partial sums of the vertex's cells in cellsOnVertex order: three, or four on a quadrilateral mesh (a
+        // uniform branch, so that the common case keeps its three unconditional loads)
+        if (d.D == 3) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            int g = d.gidx[k * PV + v];
-            dU = dU + d.partU[g];
-            dV = dV + d.partV[g];
+            for (int k = 0; k < 3; k++) {
+                int g = d.gidx[k * PV + v];
+                dU = dU + d.partU[g];
+                dV = dV + d.partV[g];
+            }
+        } else {
+            for (int k = 0; k < d.D; k++) {
+                int g = d.gidx[k * PV + v];
+                dU = dU + d.partU[g];
+                dV = dV + d.partV[g];
+            }
         }
         const double den0 = d.varDenom[v];
         dU = dU / den0;
@@ -910,10 +923,12 @@ __global__ void __launch_bounds__(256) k_div_vertices(SihDev d)
     const int PV = d.padV;
     double dU = 0.0, dV = 0.0;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int g = d.gidx[k * PV + v];
-        dU = dU + d.partU[g];
-        dV = dV + d.partV[g];
+    for (int k = 0; k < 4; k++) {
+        if (k < d.D) {
+            const int g = d.gidx[k * PV + v];
+            dU = dU + d.partU[g];
+            dV = dV + d.partV[g];
+        }
     }
     const double den0 = d.varDenom[v];
     d.divU[v] = dU / den0;

@@ -176,8 +176,8 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
         return SIH_ERR_ARG;
     }
     *out = nullptr;  // the caller's handle is defined on every return
-    // vertexDegree 4 (quadrilateral meshes) is accepted for the incremental remap; the velocity solver and the upwind
-    // advection refuse such a block at their own set-up
+    // vertexDegree 4 (quadrilateral meshes): the velocity solver runs in its two-kernel form, the incremental remap
+    // with six side edges per edge; the weak scheme and the upwind advection refuse such a block at their own set-up
     if (m->maxEdges < 3 || m->maxEdges > SIH_MAXE || (m->vertexDegree != 3 && m->vertexDegree != 4)) {
         sih_set_error("sih_block_create: maxEdges must be in [3,10] and vertexDegree 3 or 4");
         return SIH_ERR_UNSUPPORTED;
@@ -312,7 +312,7 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
     const Spec specs[] = {
         // connectivity in internal numbering
         {"_nEdgesOnCell", LOC_CELL, 1, true}, {"_voc", LOC_CELL, M, true}, {"_coc", LOC_CELL, M, true},
-        {"_cov", LOC_VERTEX, D, true}, {"_gidx", LOC_VERTEX, 3, true},
+        {"_cov", LOC_VERTEX, D, true}, {"_gidx", LOC_VERTEX, D, true},
         {"_vertexActive", LOC_VERTEX, 1, true},
         // geometry
         {"xCell", LOC_CELL, 1, false}, {"yCell", LOC_CELL, 1, false}, {"zCell", LOC_CELL, 1, false},
@@ -343,7 +343,7 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
         {"basisGradientV", LOC_CELL, MM, false}, {"basisIntegralsU", LOC_CELL, MM, false},
         {"basisIntegralsV", LOC_CELL, MM, false}, {"basisIntegralsMetric", LOC_CELL, MM, false},
         {"tanLatVertexRotatedOverRadius", LOC_VERTEX, 1, false}, {"variationalDenominator", LOC_VERTEX, 1, false},
-        {"cellVerticesAtVertex", LOC_VERTEX, 3, true},
+        {"cellVerticesAtVertex", LOC_VERTEX, D, true},
         // compact gradients and per-corner divergence partial sums (library-internal)
         {"_gradU3", LOC_CELL, 3 * M, false}, {"_gradV3", LOC_CELL, 3 * M, false},
         {"_partU", LOC_CELL, M, false}, {"_partV", LOC_CELL, M, false},

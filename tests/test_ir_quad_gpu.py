@@ -101,12 +101,10 @@ def test_quad_advection_matches_oracle(meshname, flow, dt, kw):
         vs.seaice_mesh_pool_destroy(dom)
 
 
-def test_velocity_solver_and_upwind_refuse_quadrilateral_meshes():
+def test_upwind_advection_refuses_quadrilateral_meshes():
     dom = quad_domain("quad_12_9", 600.0)
     vs.seaice_mesh_pool_create(dom)
     try:
-        with pytest.raises(SeaiceHipError, match="vertexDegree"):
-            vs.seaice_init_velocity_solver(dom)
         dom.configs["config_advection_type"] = "upwind"
         with pytest.raises(SeaiceHipError, match="vertexDegree"):
             adv.seaice_init_advection(dom)
