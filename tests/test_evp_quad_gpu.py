@@ -110,3 +110,60 @@ def test_weak_scheme_refuses_quadrilateral_meshes():
             vs.seaice_init_velocity_solver(dom)
     finally:
         vs.seaice_mesh_pool_destroy(dom)
+
+
+def test_one_dimensional_velocity_case_on_squares(oracle):
+    """The reference's 1D_velocity_quad case (testcases/square/1D_velocity_quad/calc_testcase_ic.py): one category
+    whose concentration rises linearly in x, twice as much volume, a uniform wind along x, no ocean current, no
+    Coriolis force, and velocity boundaries that copy the second row onto the outer one at the bottom and at the top.
+    The answer has no structure in y: every column of vertices carries the same velocity, and v stays zero."""
+    nx, ny = 40, 20
+    mesh = get_mesh(f"quad_{nx}_{ny}")
+    cfg = {"config_dt": 600.0, "config_elastic_subcycle_number": 120, "config_use_special_boundaries_velocity": True}
+
+    def make():
+        dom = cases.make_domain(mesh, None, nCategories=1, configs=cfg)
+        b = dom.blocklist[0]
+        m = b.structs["mesh"]
+        nC, nV = b.dimensions["nCells"], b.dimensions["nVertices"]
+        x = m["xCell"][:nC]
+        Lx = m["xVertex"][:nV].max() - m["xVertex"][:nV].min()
+        tr = b.structs["tracers"]
+        tr["iceAreaCategory"][0, 0, :nC] = x / Lx
+        tr["iceVolumeCategory"][0, 0, :nC] = 2.0 * tr["iceAreaCategory"][0, 0, :nC]
+        tr["snowVolumeCategory"][0, 0, :nC] = 0.0
+        at, oc = b.structs["atmos_coupling"], b.structs["ocean_coupling"]
+        at["uAirVelocity"][:nC], at["vAirVelocity"][:nC] = 1.0, 0.0
+        oc["uOceanVelocity"][:nC] = oc["vOceanVelocity"][:nC] = 0.0
+        oc["seaSurfaceTiltU"][:nC] = oc["seaSurfaceTiltV"][:nC] = 0.0
+        m["fVertex"][:] = 0.0
+        b.structs["velocity_solver"]["uVelocity"][:] = 0.0
+        b.structs["velocity_solver"]["vVelocity"][:] = 0.0
+        for k in ("stress11", "stress22", "stress12"):
+            b.structs["velocity_variational"][k][:] = 0.0
+        sb = b.structs["special_boundaries"]
+        typ, src = sb["vertexBoundaryType"], sb["vertexBoundarySource"]
+        for i in range(nx + 1):       # vertex (i, j) has the number j (nx + 1) + i
+            typ[i], src[i] = 1, (ny - 1) * (nx + 1) + i + 1           # bottom row from the row below the top one
+            typ[ny * (nx + 1) + i], src[ny * (nx + 1) + i] = 1, (nx + 1) + i + 1   # top row from the second row
+        return dom
+    ref, dom = make(), make()
+    oracle.seaice_init_velocity_solver(ref)
+    oracle.seaice_run_velocity_solver(ref)
+    vs.seaice_mesh_pool_create(dom)
+    try:
+        vs.seaice_init_velocity_solver(dom)
+        vs.seaice_run_velocity_solver(dom)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+    compare_domains(dom, ref, [("velocity_solver", "uVelocity")], TOL)
+    vd, vr = (d_.blocklist[0].structs["velocity_solver"]["vVelocity"] for d_ in (dom, ref))
+    scale = np.abs(ref.blocklist[0].structs["velocity_solver"]["uVelocity"]).max()
+    assert np.abs(vd - vr).max() <= TOL * scale      # v is rounding noise around zero: measured against the size of u
+    u = dom.blocklist[0].structs["velocity_solver"]["uVelocity"][:(nx + 1) * (ny + 1)].reshape(ny + 1, nx + 1)
+    v = dom.blocklist[0].structs["velocity_solver"]["vVelocity"][:(nx + 1) * (ny + 1)].reshape(ny + 1, nx + 1)
+    assert np.abs(u).max() > 1e-4
+    inner = u[1:-1]
+    assert np.abs(inner - inner[0][None, :]).max() <= 1e-10 * np.abs(u).max()     # no structure in y
+    assert np.abs(v[1:-1]).max() <= 1e-10 * np.abs(u).max()
+    assert np.array_equal(u[0], u[ny - 1]) and np.array_equal(u[ny], u[1])         # the boundary rows are copies
