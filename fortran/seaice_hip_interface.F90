@@ -66,6 +66,7 @@ module seaice_hip_interface
      real(c_double)     :: efoldingScale
      integer(c_int32_t) :: nCategories
      type(c_ptr)        :: categoryThicknessLimits        ! nCategories + 1 doubles
+     integer(c_int32_t) :: itdCleanup = 1                 ! 1: the ITD clean-up of colpkg_step_ridge after ridge_ice
   end type sih_ridge_config
 
   interface

@@ -269,8 +269,13 @@ int sih_column_put(sih_ctx *ctx, int nFields, const char *const *names, int nCat
  * so that velocity solver -> advection -> ridging -> next velocity solver runs without a copy to the host.  Where the
  * reference sets l_stop the call returns SIH_ERR_COLUMN with the reference's stop_label as the message
  * ("Ridging error: aice0 < 0", "Ridging error: ardg > aicen", "ridge_ice: Exceeded max number of ridging iterations",
- * "ridge_ice: total area > 1").  Not included: the ITD clean-up that colpkg_step_ridge runs afterwards (cleanup_itd,
- * src/column/ice_itd.F90:754), which stays with the host's column package. */
+ * "ridge_ice: total area > 1", "ice: ITD cleanup error in colpkg_step_ridge").  With itdCleanup set the ITD clean-up
+ * that colpkg_step_ridge runs after ridge_ice (cleanup_itd, src/column/ice_itd.F90:754-1020) follows in the same
+ * launch; it adds
+ *   in/out: oceanSaltFlux (ocean_fluxes), newlyFormedIce (int32, nCategories,nCells; biogeochemistry pool: set to 1
+ *           for a category the clean-up emptied, otherwise left as it is)
+ *   out:    iceAreaCell (tracers_aggregate)
+ * The aggregation of the other cell means (seaice_column_update_state) stays with the host's column package. */
 typedef struct {
     double dt;                  /* dynamicsTimeStep */
     int32_t dynamicsSubcycleNumber; /* config_dynamics_subcycle_number (ndtd: the fluxes are averaged over the thermodynamic step) */
@@ -279,6 +284,8 @@ typedef struct {
     double efoldingScale;       /* config_ridiging_efolding_scale (mu_rdg) */
     int32_t nCategories;
     const double *categoryThicknessLimits; /* hin_max(0:nCategories) of the `initial` pool, host memory */
+    int32_t itdCleanup;         /* 1: colpkg_step_ridge whole, i.e. the ITD clean-up (cleanup_itd, ice_itd.F90:754-1020:
+                                   rebin, zap_small_areas, zap_snow_temperature) after ridge_ice; 0: ridge_ice alone */
 } sih_ridge_config;
 int sih_column_ridge(sih_ctx *ctx, const sih_ridge_config *cfg);
 /* creates the cell fields listed above (zero-filled) without running anything, so that a host can put its ocean state

@@ -5,7 +5,7 @@
 
 The ridging works on the device fields of the advected tracers, so that between the advection and the next velocity
 solve nothing has to visit the host.  Scope and limits: see ``sih_column_ridge`` in include/seaice_hip.h (standard
-physics tracers, no strata; the ITD clean-up of colpkg_step_ridge is not included)."""
+physics tracers, no strata; the aggregation that follows in seaice_column_update_state is not included)."""
 from __future__ import annotations
 
 from . import pools
@@ -15,18 +15,20 @@ PARTICIPATION = {"Thorndike75": 0, "exponential": 1}
 REDISTRIBUTION = {"Hibler80": 0, "exponential": 1}
 INPUT_FIELDS = (("ridging", "ridgeConvergence"), ("ridging", "ridgeShear"), ("icestate", "openWaterArea"),
                 ("ocean_coupling", "seaFreezingTemperature"), ("ocean_fluxes", "oceanFreshWaterFlux"),
-                ("ocean_fluxes", "oceanHeatFlux"), ("ridging", "fractionNewRidgeArea"),
-                ("ridging", "fractionNewRidgeVolume"))
-OUTPUT_FIELDS = (("icestate", "openWaterArea"), ("ocean_fluxes", "oceanFreshWaterFlux"), ("ocean_fluxes", "oceanHeatFlux")) \
+                ("ocean_fluxes", "oceanHeatFlux"), ("ocean_fluxes", "oceanSaltFlux"), ("ridging", "fractionNewRidgeArea"),
+                ("ridging", "fractionNewRidgeVolume"), ("biogeochemistry", "newlyFormedIce"))
+OUTPUT_FIELDS = (("icestate", "openWaterArea"), ("ocean_fluxes", "oceanFreshWaterFlux"), ("ocean_fluxes", "oceanHeatFlux"),
+                 ("ocean_fluxes", "oceanSaltFlux"), ("biogeochemistry", "newlyFormedIce"), ("tracers_aggregate", "iceAreaCell")) \
     + tuple(("ridging", k) for k in pools.RIDGING_CELL_FIELDS + pools.RIDGING_CATEGORY_FIELDS)
 
 
-def column_ridging(domain, upload=True, download=True):
+def column_ridging(domain, upload=True, download=True, cleanup=True):
     """:3283-3556.  ``upload``: True, the tracers and every cell field the ridging reads go from the pools to the device
     first; "cells", only the cell fields that no device routine computes (ocean state, accumulated fluxes, open water,
     the fractions of the last ridging): for a host that has just run velocity solver and advection on the device;
     False, nothing: the device holds what the ridging before this one left (open water, fluxes accumulated so far).
-    ``download``: tracers, open water, fluxes and diagnostics come back."""
+    ``download``: tracers, open water, fluxes and diagnostics come back.  ``cleanup``: colpkg_step_ridge whole, i.e. the
+    ITD clean-up (cleanup_itd: rebin, zap_small_areas, zap_snow_temperature) after ridge_ice; False: ridge_ice alone."""
     cfg = domain.configs
     for key, table in (("config_ridging_participation_function", PARTICIPATION),
                        ("config_ridging_redistribution_function", REDISTRIBUTION)):
@@ -51,7 +53,7 @@ def column_ridging(domain, upload=True, download=True):
         b.ctx.column_ridge(dt, int(cfg["config_dynamics_subcycle_number"]),
                            PARTICIPATION[cfg["config_ridging_participation_function"]],
                            REDISTRIBUTION[cfg["config_ridging_redistribution_function"]],
-                           float(cfg["config_ridiging_efolding_scale"]), limits)
+                           float(cfg["config_ridiging_efolding_scale"]), limits, cleanup=cleanup)
         limits[-1] = 1.0e8  # ridge_prep writes it into the host's array (ice_mechred.F90:675)
         domain.solver_state["ridge_iterations"] = int(b.ctx.info("ridgeIterations"))
         if download:

@@ -14,7 +14,8 @@
 // (surface temperature, ice enthalpy, ice salinity, snow enthalpy).  Tracers carried on other tracers (ponds, brine,
 // level ice, aerosols: the strata branches :1206-1211, :1389-1394, :1508-1517) are refused.  The module's
 // l_conservation_check is .false. (:64).  The ITD clean-up that colpkg_step_ridge runs after ridge_ice (cleanup_itd,
-// src/column/ice_itd.F90:754) is not here.
+// src/column/ice_itd.F90:754-1020, over the thermodynamic step dt * ndtd, src/column/ice_colpkg.F90:3327-3354) follows
+// in the same thread: rebin with shift_ice, zap_small_areas, zap_snow_temperature, for the same tracer set.
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -33,6 +34,9 @@ struct RidgeTracer {
 
 struct RidgeDev {
     int nCellsSolve, padC, ncat, ntrcr, nslyr, ntTsfc, ntQsno, krdgPartic, krdgRedist, ndtd;
+    int cleanup, nilyr, ntQice;  // the ITD clean-up after the ridging; ice layers and the first ice-enthalpy tracer
+    double *aice, *fsalt;        // iceAreaCell, oceanSaltFlux
+    int *firstIce;               // newlyFormedIce (nCategories planes)
     double dt, muRdg;
     double hinMax[RIDGE_MAXCAT + 1];
     double *aicen, *vicen, *vsnon, *aice0, *atrcrn;
@@ -310,6 +314,227 @@ __device__ int ridgeShift(const RidgeDev &d, int ncat, int cell, RidgeCell<NC> &
     return 0;
 }
 
+// ---- the ITD clean-up, src/column/ice_itd.F90 (constants: constants/cice/ice_constants_colpkg.F90:24-77,
+// ice_therm_shared.F90:27)
+#define ITD_RHOI 917.0
+#define ITD_CP_ICE 2106.0
+#define ITD_LFRESH (2.835e6 - 2.501e6)
+#define ITD_REF_SALINITY 4.0
+#define ITD_HS_MIN 1.0e-4
+#define ITD_TMIN (-100.0)
+
+// colpkg_compute_tracers for category n (ice_colpkg_tracers.F90:216-252, no strata)
+template <int NC>
+__device__ inline void computeTracers(const RidgeDev &d, int n, int cell, const RidgeCell<NC> &s, double Tf)
+{
+    for (int it = 0; it < d.ntrcr; it++) {
+        const int dep = d.tr[it].depend;
+        const double a = atr(d, it, n, cell);
+        double v;
+        if (dep == 0) {
+            if (s.aicen[n] > PUNY)
+                v = a / s.aicen[n];
+            else
+                v = it == d.ntTsfc ? Tf : 0.0;
+        } else {
+            const double div = dep == 1 ? s.vicen[n] : s.vsnon[n];
+            v = div > 0.0 ? a / div : 0.0;
+        }
+        trc(d, it, n, cell) = v;
+    }
+}
+
+// shift_ice :347-665 with one active boundary n (donor category nd), as rebin calls it.  Returns true for one of
+// its four stops; nothing has moved then.
+template <int NC>
+__device__ bool shiftIce(const RidgeDev &d, int ncat, int cell, RidgeCell<NC> &s, double (&hicen)[NC + 1], int n, int nd,
+                         double daice, double dvice, double Tf)
+{
+    for (int m = 1; m <= ncat; m++)
+        for (int it = 0; it < d.ntrcr; it++) {
+            const int dep = d.tr[it].depend;
+            const double b1 = dep == 0, b2 = dep == 1, b3 = dep == 2;
+            atr(d, it, m, cell) = trc(d, it, m, cell) * (b1 * s.aicen[m] + b2 * s.vicen[m] + b3 * s.vsnon[m]);
+        }
+    bool daiceNeg = false, dviceNeg = false, daiceGreater = false, dviceGreater = false;
+    if (daice < 0.0) {
+        if (daice > -PUNY * s.aicen[nd]) {
+            daice = 0.0;
+            dvice = 0.0;
+        } else
+            daiceNeg = true;
+    }
+    if (dvice < 0.0) {
+        if (dvice > -PUNY * s.vicen[nd]) {
+            daice = 0.0;
+            dvice = 0.0;
+        } else
+            dviceNeg = true;
+    }
+    if (daice > s.aicen[nd] * (1.0 - PUNY)) {
+        if (daice < s.aicen[nd] * (1.0 + PUNY)) {
+            daice = s.aicen[nd];
+            dvice = s.vicen[nd];
+        } else
+            daiceGreater = true;
+    }
+    if (dvice > s.vicen[nd] * (1.0 - PUNY)) {
+        if (dvice < s.vicen[nd] * (1.0 + PUNY)) {
+            daice = s.aicen[nd];
+            dvice = s.vicen[nd];
+        } else
+            dviceGreater = true;
+    }
+    if (daiceNeg && daice <= -PUNY * s.aicen[nd]) return true;
+    if (dviceNeg && dvice <= -PUNY * s.vicen[nd]) return true;
+    if (daiceGreater && daice >= s.aicen[nd] * (1.0 + PUNY)) return true;
+    if (dviceGreater && dvice >= s.vicen[nd] * (1.0 + PUNY)) return true;
+    if (daice > 0.0) {
+        const double worka = daice / s.aicen[nd];
+        const int nr = nd == n ? nd + 1 : n;
+        s.aicen[nd] = s.aicen[nd] - daice;
+        s.aicen[nr] = s.aicen[nr] + daice;
+        s.vicen[nd] = s.vicen[nd] - dvice;
+        s.vicen[nr] = s.vicen[nr] + dvice;
+        const double dvsnow = s.vsnon[nd] * worka;
+        s.vsnon[nd] = s.vsnon[nd] - dvsnow;
+        s.vsnon[nr] = s.vsnon[nr] + dvsnow;
+        const double workb = dvsnow;
+        for (int it = 0; it < d.ntrcr; it++) {
+            const int dep = d.tr[it].depend;
+            const double b1 = dep == 0, b2 = dep == 1, b3 = dep == 2;
+            const double datrcr = trc(d, it, nd, cell) * (b1 * daice + b2 * dvice + b3 * workb);
+            atr(d, it, nd, cell) = atr(d, it, nd, cell) - datrcr;
+            atr(d, it, nr, cell) = atr(d, it, nr, cell) + datrcr;
+        }
+    }
+    for (int m = 1; m <= ncat; m++) {
+        hicen[m] = s.aicen[m] > PUNY ? s.vicen[m] / s.aicen[m] : 0.0;
+        computeTracers<NC>(d, m, cell, s, Tf);
+    }
+    return false;
+}
+
+// zap_snow :1340-1422 for category n
+template <int NC>
+__device__ inline void zapSnow(const RidgeDev &d, int n, int cell, RidgeCell<NC> &s, double dt, double &dfresh, double &dfhocn)
+{
+    if (d.ntQsno >= 0)
+        for (int k = 1; k <= d.nslyr; k++) {
+            const double xtmp = trc(d, d.ntQsno + k - 1, n, cell) / dt * s.vsnon[n] / (double)d.nslyr;
+            dfhocn = dfhocn + xtmp;
+            trc(d, d.ntQsno + k - 1, n, cell) = 0.0;
+        }
+    const double xtmp = (RDG_RHOS * s.vsnon[n]) / dt;
+    dfresh = dfresh + xtmp;
+    s.vsnon[n] = 0.0;
+}
+
+// cleanup_itd :754-1020 for one cell: aggregate_area :53-81, rebin :89-280, zap_small_areas :1029-1336,
+// zap_snow_temperature :1426-1559.  Returns true for a stop (colpkg_step_ridge reports them all under one label).
+template <int NC>
+__device__ bool cleanupItd(const RidgeDev &d, int ncat, int cell, RidgeCell<NC> &s, double &aice0, double Tf)
+{
+    const double dt = d.dt * d.ndtd;
+    double dfresh = 0.0, dfsalt = 0.0, dfhocn = 0.0;
+    double aice = 0.0;
+    for (int n = 1; n <= ncat; n++) aice = aice + s.aicen[n];
+    aice0 = fmax(1.0 - aice, 0.0);
+    d.aice[cell] = aice;
+    if (aice > 1.0 + PUNY || aice < -PUNY) return true;  // 'aggregate ice area out of bounds'
+    if (aice > PUNY) {  // rebin
+        double hicen[NC + 1];
+        for (int n = 1; n <= ncat; n++) hicen[n] = s.aicen[n] > PUNY ? s.vicen[n] / s.aicen[n] : 0.0;
+        if (s.aicen[1] > PUNY && hicen[1] <= d.hinMax[0] && d.hinMax[0] > 0.0) {
+            s.aicen[1] = s.vicen[1] / d.hinMax[0];
+            hicen[1] = d.hinMax[0];
+        }
+        // a stop inside shift_ice is not looked at by cleanup_itd: zap_small_areas clears the flag (:1102)
+        for (int n = 1; n <= ncat - 1; n++)
+            if (s.aicen[n] > PUNY && hicen[n] > d.hinMax[n]) shiftIce<NC>(d, ncat, cell, s, hicen, n, n, s.aicen[n], s.vicen[n], Tf);
+        for (int n = ncat - 1; n >= 1; n--)
+            if (s.aicen[n + 1] > PUNY && hicen[n + 1] <= d.hinMax[n])
+                shiftIce<NC>(d, ncat, cell, s, hicen, n, n + 1, s.aicen[n + 1], s.vicen[n + 1], Tf);
+    }
+    // zap_small_areas
+    for (int n = 1; n <= ncat; n++) {
+        if (s.aicen[n] < -PUNY)
+            return true;  // 'Zap ice: negative ice area'
+        else if (fabs(s.aicen[n]) != 0.0 && fabs(s.aicen[n]) <= PUNY) {
+            if (d.ntQice >= 0)
+                for (int k = 1; k <= d.nilyr; k++) {
+                    const double xtmp = trc(d, d.ntQice + k - 1, n, cell) / dt * s.vicen[n] / (double)d.nilyr;
+                    dfhocn = dfhocn + xtmp;
+                    trc(d, d.ntQice + k - 1, n, cell) = 0.0;
+                }
+            double xtmp = (ITD_RHOI * s.vicen[n]) / dt;
+            dfresh = dfresh + xtmp;
+            xtmp = ITD_RHOI * s.vicen[n] * ITD_REF_SALINITY * 0.001 / dt;
+            dfsalt = dfsalt + xtmp;
+            aice0 = aice0 + s.aicen[n];
+            s.aicen[n] = 0.0;
+            s.vicen[n] = 0.0;
+            if (d.ntTsfc >= 0) trc(d, d.ntTsfc, n, cell) = Tf;
+            zapSnow<NC>(d, n, cell, s, dt, dfresh, dfhocn);
+            for (int it = 1; it < d.ntrcr; it++) trc(d, it, n, cell) = 0.0;  // tracers 2..ntrcr (:1203-1211), no brine
+            d.firstIce[(size_t)(n - 1) * d.padC + cell] = 1;
+        }
+    }
+    if (aice > 1.0 + PUNY)
+        return true;  // 'Zap ice: excess ice area'
+    else if (aice > 1.0 && aice < 1.0 + PUNY) {
+        for (int n = 1; n <= ncat; n++) {
+            if (d.ntQice >= 0)
+                for (int k = 1; k <= d.nilyr; k++) {
+                    const double xtmp = trc(d, d.ntQice + k - 1, n, cell) * s.vicen[n] / (double)d.nilyr * (aice - 1.0) / aice / dt;
+                    dfhocn = dfhocn + xtmp;
+                }
+            if (d.ntQsno >= 0)
+                for (int k = 1; k <= d.nslyr; k++) {
+                    const double xtmp = trc(d, d.ntQsno + k - 1, n, cell) * s.vsnon[n] / (double)d.nslyr * (aice - 1.0) / aice / dt;
+                    dfhocn = dfhocn + xtmp;
+                }
+            double xtmp = (ITD_RHOI * s.vicen[n] + RDG_RHOS * s.vsnon[n]) * (aice - 1.0) / aice / dt;
+            dfresh = dfresh + xtmp;
+            xtmp = ITD_RHOI * s.vicen[n] * ITD_REF_SALINITY * 0.001 * (aice - 1.0) / aice / dt;
+            dfsalt = dfsalt + xtmp;
+            s.aicen[n] = s.aicen[n] * (1.0 / aice);
+            s.vicen[n] = s.vicen[n] * (1.0 / aice);
+            s.vsnon[n] = s.vsnon[n] * (1.0 / aice);
+        }
+        aice = 1.0;
+        aice0 = 0.0;
+    }
+    d.aice[cell] = aice;
+    // zap_snow_temperature
+    if (d.ntQsno >= 0) {
+        const double rnslyr = (double)d.nslyr;
+        for (int n = 1; n <= ncat; n++) {
+            bool zap = false;
+            if (s.aicen[n] > PUNY) {
+                const double hsn = s.vsnon[n] / s.aicen[n];
+                for (int k = 1; k <= d.nslyr; k++) {
+                    double zqsn, Tmax;
+                    if (hsn > ITD_HS_MIN) {
+                        zqsn = trc(d, d.ntQsno + k - 1, n, cell);
+                        Tmax = -zqsn * PUNY * rnslyr / (RDG_RHOS * ITD_CP_ICE * s.vsnon[n]);
+                    } else {
+                        zqsn = -RDG_RHOS * ITD_LFRESH;
+                        Tmax = PUNY;
+                    }
+                    const double zTsn = (ITD_LFRESH + zqsn / RDG_RHOS) / ITD_CP_ICE;
+                    if (zTsn < ITD_TMIN || zTsn > Tmax) zap = true;
+                }
+            }
+            if (zap) zapSnow<NC>(d, n, cell, s, dt, dfresh, dfhocn);
+        }
+    }
+    d.fresh[cell] = d.fresh[cell] + dfresh;
+    d.fsalt[cell] = d.fsalt[cell] + dfsalt;
+    d.fhocn[cell] = d.fhocn[cell] + dfhocn;
+    return false;
+}
+
 template <int NC>
 __global__ void __launch_bounds__(128) k_ridge_ice(RidgeDev d)
 {
@@ -395,7 +620,21 @@ __global__ void __launch_bounds__(128) k_ridge_ice(RidgeDev d)
     dti = 1.0 / (d.ndtd * dt);  // :555-562
     d.fresh[cell] = d.fresh[cell] + msnow_mlt * dti;
     d.fhocn[cell] = d.fhocn[cell] + esnow_mlt * dti;
-    if (stop) atomicMax(&d.flag[0], stop);
+    if (stop) {
+        atomicMax(&d.flag[0], stop);
+        return;
+    }
+    if (d.cleanup) {  // colpkg_step_ridge :3327-3354
+        const bool bad = cleanupItd<NC>(d, ncat, cell, s, aice0, Tf);
+        for (int n = 1; n <= ncat; n++) {
+            const size_t k = (size_t)(n - 1) * P + cell;
+            d.aicen[k] = s.aicen[n];
+            d.vicen[k] = s.vicen[n];
+            d.vsnon[k] = s.vsnon[n];
+        }
+        d.aice0[cell] = aice0;
+        if (bad) atomicMax(&d.flag[0], 6);
+    }
 }
 
 __global__ void k_ridge_zero_flags(int *f)
@@ -443,6 +682,18 @@ static int ridgeFields(sih_ctx *c, int nCat, RidgeDev &d)
     if ((rc = fieldPtr(c, "iceVolumeRidgedCategory", LOC_CELL, nCat, &d.dvirdgndt))) return rc;
     if ((rc = fieldPtr(c, "raftingIceArea", LOC_CELL, nCat, &d.araftn))) return rc;
     if ((rc = fieldPtr(c, "raftingIceVolume", LOC_CELL, nCat, &d.vraftn))) return rc;
+    // what the ITD clean-up adds: the aggregate ice area, the salt flux, the categories it emptied
+    if ((rc = fieldPtr(c, "iceAreaCell", LOC_CELL, 1, &d.aice))) return rc;
+    if ((rc = fieldPtr(c, "oceanSaltFlux", LOC_CELL, 1, &d.fsalt))) return rc;
+    if ((rc = sih_add_field(c, "newlyFormedIce", LOC_CELL, nCat, true))) return rc;
+    {
+        SihField *f = sih_find_field(c, "newlyFormedIce");
+        if (!f || f->lead != nCat || !f->isInt) {
+            sih_set_error("sih_column_ridge: field newlyFormedIce exists with another shape");
+            return SIH_ERR_ARG;
+        }
+        d.firstIce = (int *)f->d;
+    }
     return SIH_OK;
 }
 
@@ -493,6 +744,9 @@ extern "C" int sih_column_ridge(sih_ctx *c, const sih_ridge_config *cfg)
     d.ntTsfc = -1;
     d.ntQsno = -1;
     d.nslyr = 0;
+    d.ntQice = -1;
+    d.nilyr = 0;
+    d.cleanup = cfg->itdCleanup != 0;
     int nt = 0;
     for (size_t i = 1; i < tr.size(); i++) {
         if ((int)i == iVol || (int)i == iSnow) continue;
@@ -507,6 +761,10 @@ extern "C" int sih_column_ridge(sih_ctx *c, const sih_ridge_config *cfg)
             return SIH_ERR_UNSUPPORTED;
         }
         if (tr[i].name == "surfaceTemperature") d.ntTsfc = nt;
+        if (tr[i].name == "iceEnthalpy") {
+            d.ntQice = nt;
+            d.nilyr = tr[i].L;
+        }
         if (tr[i].name == "snowEnthalpy") {
             d.ntQsno = nt;
             d.nslyr = tr[i].L;
@@ -554,7 +812,8 @@ extern "C" int sih_column_ridge(sih_ctx *c, const sih_ridge_config *cfg)
         sih_set_error(flags[0] == 1   ? "Ridging error: aice0 < 0"
                       : flags[0] == 2 ? "Ridging error: ardg > aicen"
                       : flags[0] == 3 ? "ridge_ice: Exceeded max number of ridging iterations"
-                                      : "ridge_ice: total area > 1");
+                      : flags[0] == 5 ? "ridge_ice: total area > 1"
+                                      : "ice: ITD cleanup error in colpkg_step_ridge");
         return SIH_ERR_COLUMN;
     }
     return SIH_OK;

@@ -73,7 +73,7 @@ class RidgeConfig(ctypes.Structure):
     _fields_ = [
         ("dt", ctypes.c_double), ("dynamicsSubcycleNumber", ctypes.c_int32), ("participation", ctypes.c_int32),
         ("redistribution", ctypes.c_int32), ("efoldingScale", ctypes.c_double), ("nCategories", ctypes.c_int32),
-        ("categoryThicknessLimits", ctypes.c_void_p),
+        ("categoryThicknessLimits", ctypes.c_void_p), ("itdCleanup", ctypes.c_int32),
     ]
 
 
@@ -522,11 +522,12 @@ class BlockContext:
     def ridge_prepare_fields(self, nCategories):
         check(self._lib.sih_column_ridge_init(self.handle, int(nCategories)), "sih_column_ridge_init")
 
-    def column_ridge(self, dt, ndtd, participation, redistribution, efolding_scale, thickness_limits):
-        """sih_column_ridge: ridge_ice for every owned cell on the device fields"""
+    def column_ridge(self, dt, ndtd, participation, redistribution, efolding_scale, thickness_limits, cleanup=True):
+        """sih_column_ridge: colpkg_step_ridge (ridge_ice, then the ITD clean-up unless ``cleanup`` is false) for every
+        owned cell on the device fields"""
         lim = np.ascontiguousarray(thickness_limits, dtype=np.float64)
         cfg = RidgeConfig(float(dt), int(ndtd), int(participation), int(redistribution), float(efolding_scale),
-                          int(lim.size - 1), lim.ctypes.data)
+                          int(lim.size - 1), lim.ctypes.data, 1 if cleanup else 0)
         check(self._lib.sih_column_ridge(self.handle, ctypes.byref(cfg)), "sih_column_ridge")
 
     def ir_unpack_reconstruction(self):

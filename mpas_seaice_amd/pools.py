@@ -233,7 +233,7 @@ def category_thickness_limits(nCategories):
 def allocate_ridging_pools(block):
     """What column_ridging reaches beyond the tracers (/root/reference/src/shared/mpas_seaice_column.F:3418-3456): the
     diagnostics of the `ridging` pool (Registry dims nCells or nCategories x nCells), the ocean fluxes the ridging adds
-    to, the freezing temperature of the ocean and the category limits of the `initial` pool."""
+    to, the freezing temperature of the ocean, the category limits of the `initial` pool and `newlyFormedIce`."""
     if "ocean_fluxes" in block.structs:
         return
     d = block.dimensions
@@ -243,7 +243,10 @@ def allocate_ridging_pools(block):
         rg[k] = np.zeros(nC + 1)
     for k in RIDGING_CATEGORY_FIELDS:
         rg[k] = np.zeros((nCat, nC + 1), order="F")
-    block.structs["ocean_fluxes"] = {"oceanFreshWaterFlux": np.zeros(nC + 1), "oceanHeatFlux": np.zeros(nC + 1)}
+    block.structs["ocean_fluxes"] = {"oceanFreshWaterFlux": np.zeros(nC + 1), "oceanHeatFlux": np.zeros(nC + 1),
+                                     "oceanSaltFlux": np.zeros(nC + 1)}
+    # the ITD clean-up at the end of colpkg_step_ridge marks categories it emptied (Registry.xml:3962)
+    block.structs["biogeochemistry"] = {"newlyFormedIce": np.zeros((nCat, nC + 1), dtype=np.int32, order="F")}
     block.structs["ocean_coupling"]["seaFreezingTemperature"] = np.full(nC + 1, -1.8)
     block.structs["initial"] = {"categoryThicknessLimits": category_thickness_limits(nCat)}
 

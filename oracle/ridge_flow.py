@@ -1,8 +1,8 @@
 """TEST INFRASTRUCTURE ONLY: column_ridging (/root/reference/src/shared/mpas_seaice_column.F:3283-3556) executed with
 the CPU oracle: for every owned cell the category tracer array is set from the pools (set_cice_tracer_array_category
 :6534-6575 for the standard physics tracers: surface temperature, ice enthalpy and salinity per ice layer, snow
-enthalpy per snow layer), ridge_ice runs (ridge_oracle.c), and the array goes back (get_cice_tracer_array_category).
-The ITD clean-up that follows ridge_ice inside colpkg_step_ridge is not part of this flow (see ridge_oracle.c).
+enthalpy per snow layer), colpkg_step_ridge runs (ridge_oracle.c: ridge_ice, then the ITD clean-up cleanup_itd over the
+thermodynamic step; ``cleanup=False`` leaves the clean-up out), and the array goes back (get_cice_tracer_array_category).
 Parity status: "parity unpinned" (header of ridge_oracle.c)."""
 from __future__ import annotations
 
@@ -14,7 +14,8 @@ from mpas_seaice_amd import pools
 from . import evp_flow
 
 STOP_LABELS = {1: "Ridging error: aice0 < 0", 2: "Ridging error: ardg > aicen",
-               3: "ridge_ice: Exceeded max number of ridging iterations", 5: "ridge_ice: total area > 1"}
+               3: "ridge_ice: Exceeded max number of ridging iterations", 5: "ridge_ice: total area > 1",
+               6: "ice: ITD cleanup error in colpkg_step_ridge"}
 PARTICIPATION = {"Thorndike75": 0, "exponential": 1}
 REDISTRIBUTION = {"Hibler80": 0, "exponential": 1}
 
@@ -24,14 +25,14 @@ def tracer_layout(block):
     volume, 2 snow volume) and the indices the ridging needs (nt_Tsfc, nt_qsno), 0-based."""
     d = block.dimensions
     entries = [("surfaceTemperature", 0, 0)]
-    entries += [("iceEnthalpy", l, 1) for l in range(d["nIceLayers"])]
+    entries += [("iceEnthalpy", l, 1) for l in range(d["nIceLayers"])]   # nt_qice = 1
     entries += [("iceSalinity", l, 1) for l in range(d["nIceLayers"])]
     nt_qsno = len(entries)
     entries += [("snowEnthalpy", l, 2) for l in range(d["nSnowLayers"])]
     return entries, 0, nt_qsno
 
 
-def column_ridging(domain):
+def column_ridging(domain, cleanup=True):
     cfg = domain.configs
     lib = evp_flow.lib()
     for b in domain.blocklist:
@@ -57,6 +58,9 @@ def column_ridging(domain):
         fhocn = b.structs["ocean_fluxes"]["oceanHeatFlux"][:nCS].copy()
         stop = np.zeros(nCS, dtype=np.int32)
         iters = np.zeros(nCS, dtype=np.int32)
+        aice = np.ascontiguousarray(b.structs["tracers_aggregate"]["iceAreaCell"][:nCS])
+        fsalt = b.structs["ocean_fluxes"]["oceanSaltFlux"][:nCS].copy()
+        first = np.ascontiguousarray(b.structs["biogeochemistry"]["newlyFormedIce"][:, :nCS].T == 1).astype(np.int32)
         fn = lib.ora_ridge_cells
         fn.restype = ctypes.c_int
 
@@ -75,7 +79,8 @@ def column_ridging(domain):
                 P(fresh), P(fhocn), P(cat["ridgeParticipationFunction"]), P(cat["ratioRidgeThicknessToIce"]),
                 P(cat["fractionNewRidgeArea"]), P(cat["fractionNewRidgeVolume"]), P(cat["areaLossRidgeCategory"]),
                 P(cat["areaGainRidgeCategory"]), P(cat["iceVolumeRidgedCategory"]), P(cat["raftingIceArea"]),
-                P(cat["raftingIceVolume"]), P(stop), P(iters))
+                P(cat["raftingIceVolume"]), P(stop), P(iters), ctypes.c_int(1 if cleanup else 0), ctypes.c_int(d["nIceLayers"]),
+                ctypes.c_int(1), P(aice), P(fsalt), P(first))
         domain.solver_state["ridge_iterations"] = iters
         if rc:
             raise RuntimeError("column_ridging: " + STOP_LABELS.get(int(rc), f"code {rc}"))
@@ -92,3 +97,7 @@ def column_ridging(domain):
             rg[k][:, :nCS] = cat[k].T
         b.structs["ocean_fluxes"]["oceanFreshWaterFlux"][:nCS] = fresh
         b.structs["ocean_fluxes"]["oceanHeatFlux"][:nCS] = fhocn
+        if cleanup:
+            b.structs["tracers_aggregate"]["iceAreaCell"][:nCS] = aice
+            b.structs["ocean_fluxes"]["oceanSaltFlux"][:nCS] = fsalt
+            b.structs["biogeochemistry"]["newlyFormedIce"][:, :nCS] = first.T   # 1 where the logical came back true

@@ -13,8 +13,9 @@
  * Scope: the tracers of the standard physics set without strata -- surface temperature (on ice area), ice enthalpy
  * and salinity per ice layer (on ice volume), snow enthalpy per snow layer (on snow volume); n_trcr_strata = 0 for
  * all of them, so the strata branches (:1206-1211, :1389-1394, :1508-1517; ponds, brine, aerosols, level ice) are
- * not restated.  The ITD clean-up that colpkg_step_ridge runs after ridge_ice (cleanup_itd, ice_itd.F90:754) is not
- * part of this file.  The module's l_conservation_check is .false. (:64): that block (:299-334, :430-503) is not run. */
+ * not restated.  The ITD clean-up that colpkg_step_ridge runs after ridge_ice (cleanup_itd, ice_itd.F90:754) follows
+ * in the second half of this file.  The module's l_conservation_check is .false. (:64): that block (:299-334,
+ * :430-503) is not run. */
 #include <math.h>
 #include <stddef.h>
 #include <string.h>
@@ -366,6 +367,277 @@ int ora_ridge_ice(double dt, int ndtd, int ncat, int nslyr, int ntrcr, double *h
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * cleanup_itd (ice_itd.F90:754-1020), which colpkg_step_ridge runs after ridge_ice (ice_colpkg.F90:3327-3350), with
+ * the routines it calls, for the standard physics tracers (no aerosols, ponds, brine, bio tracers, zsalinity;
+ * heat_capacity true; limit_aice true): aggregate_area :53-81, rebin :89-280, shift_ice :347-665, zap_small_areas
+ * :1029-1336, zap_snow :1340-1422, zap_snow_temperature :1426-1559.  Category arrays are 1-based (entry 0 unused),
+ * trcrn is (ntrcr, ncat) with the tracer index fastest and category n in column n - 1. */
+static const double rhoi = 917.0, cp_ice = 2106.0, Lfresh = 2.835e6 - 2.501e6, ice_ref_salinity = 4.0, p001 = 0.001;
+static const double hs_min = 1.0e-4, Tmin = -100.0; /* constants/cice/ice_constants_colpkg.F90:24-77, ice_therm_shared.F90:27 */
+
+/* shift_ice :347-665.  Returns 0 or 1 (one of its four stops; nothing has been shifted then). */
+static int shift_ice(int ntrcr, int ncat, const int *trcr_depend, int nt_Tsfc, double Tf, double *aicen, double *trcrn,
+                     double *vicen, double *vsnon, double *hicen, const int *donor, double *daice, double *dvice)
+{
+    double atrcrn[MAXCAT + 1][MAXTR];
+    for (int n = 1; n <= ncat; n++)
+        for (int it = 0; it < ntrcr; it++) {
+            const double b1 = trcr_depend[it] == 0 ? 1.0 : 0.0, b2 = trcr_depend[it] == 1 ? 1.0 : 0.0,
+                         b3 = trcr_depend[it] == 2 ? 1.0 : 0.0;
+            atrcrn[n][it] = trcrn[(size_t)(n - 1) * ntrcr + it] * (b1 * aicen[n] + b2 * vicen[n] + b3 * vsnon[n]);
+        }
+    for (int n = 1; n <= ncat - 1; n++) {
+        int daice_negative = 0, dvice_negative = 0, daice_greater_aicen = 0, dvice_greater_vicen = 0, nd = 0, nr;
+        if (donor[n] > 0) {
+            nd = donor[n];
+            if (daice[n] < c0) {
+                if (daice[n] > -puny * aicen[nd]) {
+                    daice[n] = c0;
+                    dvice[n] = c0;
+                } else
+                    daice_negative = 1;
+            }
+            if (dvice[n] < c0) {
+                if (dvice[n] > -puny * vicen[nd]) {
+                    daice[n] = c0;
+                    dvice[n] = c0;
+                } else
+                    dvice_negative = 1;
+            }
+            if (daice[n] > aicen[nd] * (c1 - puny)) {
+                if (daice[n] < aicen[nd] * (c1 + puny)) {
+                    daice[n] = aicen[nd];
+                    dvice[n] = vicen[nd];
+                } else
+                    daice_greater_aicen = 1;
+            }
+            if (dvice[n] > vicen[nd] * (c1 - puny)) {
+                if (dvice[n] < vicen[nd] * (c1 + puny)) {
+                    daice[n] = aicen[nd];
+                    dvice[n] = vicen[nd];
+                } else
+                    dvice_greater_vicen = 1;
+            }
+        }
+        if (daice_negative && donor[n] > 0 && daice[n] <= -puny * aicen[nd]) return 1;
+        if (dvice_negative && donor[n] > 0 && dvice[n] <= -puny * vicen[nd]) return 1;
+        if (daice_greater_aicen && donor[n] > 0 && daice[n] >= aicen[donor[n]] * (c1 + puny)) return 1;
+        if (dvice_greater_vicen && donor[n] > 0 && dvice[n] >= vicen[donor[n]] * (c1 + puny)) return 1;
+        if (daice[n] > c0) {
+            nd = donor[n];
+            const double worka = daice[n] / aicen[nd];
+            nr = nd == n ? nd + 1 : n;
+            aicen[nd] = aicen[nd] - daice[n];
+            aicen[nr] = aicen[nr] + daice[n];
+            vicen[nd] = vicen[nd] - dvice[n];
+            vicen[nr] = vicen[nr] + dvice[n];
+            const double dvsnow = vsnon[nd] * worka;
+            vsnon[nd] = vsnon[nd] - dvsnow;
+            vsnon[nr] = vsnon[nr] + dvsnow;
+            const double workb = dvsnow;
+            for (int it = 0; it < ntrcr; it++) {
+                const double b1 = trcr_depend[it] == 0 ? 1.0 : 0.0, b2 = trcr_depend[it] == 1 ? 1.0 : 0.0,
+                             b3 = trcr_depend[it] == 2 ? 1.0 : 0.0;
+                const double datrcr = trcrn[(size_t)(nd - 1) * ntrcr + it] * (b1 * daice[n] + b2 * dvice[n] + b3 * workb);
+                atrcrn[nd][it] = atrcrn[nd][it] - datrcr;
+                atrcrn[nr][it] = atrcrn[nr][it] + datrcr;
+            }
+        }
+    }
+    for (int n = 1; n <= ncat; n++) {
+        if (aicen[n] > puny)
+            hicen[n] = vicen[n] / aicen[n];
+        else
+            hicen[n] = c0;
+        compute_tracers(ntrcr, trcr_depend, atrcrn[n], aicen[n], vicen[n], vsnon[n], nt_Tsfc, Tf,
+                        trcrn + (size_t)(n - 1) * ntrcr);
+    }
+    return 0;
+}
+
+/* rebin :89-280.  A stop inside shift_ice is returned but, as in the reference, nobody looks at it: cleanup_itd goes
+ * on to zap_small_areas, which clears the flag (:1102). */
+static int rebin(int ntrcr, const int *trcr_depend, int nt_Tsfc, double Tf, double *aicen, double *trcrn, double *vicen,
+                 double *vsnon, int ncat, const double *hin_max)
+{
+    int donor[MAXCAT + 1], stop = 0;
+    double daice[MAXCAT + 1], dvice[MAXCAT + 1], hicen[MAXCAT + 1];
+    for (int n = 1; n <= ncat; n++) {
+        donor[n] = 0;
+        daice[n] = c0;
+        dvice[n] = c0;
+        if (aicen[n] > puny)
+            hicen[n] = vicen[n] / aicen[n];
+        else
+            hicen[n] = c0;
+    }
+    if (aicen[1] > puny) {
+        if (hicen[1] <= hin_max[0] && hin_max[0] > c0) {
+            aicen[1] = vicen[1] / hin_max[0];
+            hicen[1] = hin_max[0];
+        }
+    }
+    for (int n = 1; n <= ncat - 1; n++) { /* ice too thick for its category moves up */
+        if (aicen[n] > puny && hicen[n] > hin_max[n]) {
+            donor[n] = n;
+            daice[n] = aicen[n];
+            dvice[n] = vicen[n];
+            stop = shift_ice(ntrcr, ncat, trcr_depend, nt_Tsfc, Tf, aicen, trcrn, vicen, vsnon, hicen, donor, daice, dvice);
+            donor[n] = 0;
+            daice[n] = c0;
+            dvice[n] = c0;
+        }
+    }
+    for (int n = ncat - 1; n >= 1; n--) { /* ice too thin moves down */
+        if (aicen[n + 1] > puny && hicen[n + 1] <= hin_max[n]) {
+            donor[n] = n + 1;
+            daice[n] = aicen[n + 1];
+            dvice[n] = vicen[n + 1];
+            stop = shift_ice(ntrcr, ncat, trcr_depend, nt_Tsfc, Tf, aicen, trcrn, vicen, vsnon, hicen, donor, daice, dvice);
+            donor[n] = 0;
+            daice[n] = c0;
+            dvice[n] = c0;
+        }
+    }
+    return stop;
+}
+
+/* zap_snow :1340-1422 for one category */
+static void zap_snow(double dt, int nslyr, double *trcrn, double *vsnon, double *dfresh, double *dfhocn, int nt_qsno)
+{
+    for (int k = 1; k <= nslyr; k++) {
+        const double xtmp = trcrn[nt_qsno + k - 1] / dt * *vsnon / (double)nslyr;
+        *dfhocn = *dfhocn + xtmp;
+        trcrn[nt_qsno + k - 1] = c0;
+    }
+    const double xtmp = (rhos * *vsnon) / dt;
+    *dfresh = *dfresh + xtmp;
+    *vsnon = c0;
+}
+
+/* zap_small_areas :1029-1336.  Returns 0, 1 'Zap ice: negative ice area' or 2 'Zap ice: excess ice area'. */
+static int zap_small_areas(double dt, double Tf, int ntrcr, int ncat, int nilyr, int nslyr, double *aice, double *aice0,
+                           double *aicen, double *trcrn, double *vicen, double *vsnon, double *dfresh, double *dfsalt,
+                           double *dfhocn, int *first_ice, int nt_Tsfc, int nt_qice, int nt_qsno)
+{
+    for (int n = 1; n <= ncat; n++) {
+        double *tr = trcrn + (size_t)(n - 1) * ntrcr;
+        if (aicen[n] < -puny)
+            return 1;
+        else if (fabs(aicen[n]) != c0 && fabs(aicen[n]) <= puny) {
+            for (int k = 1; k <= nilyr; k++) {
+                const double xtmp = tr[nt_qice + k - 1] / dt * vicen[n] / (double)nilyr;
+                *dfhocn = *dfhocn + xtmp;
+                tr[nt_qice + k - 1] = c0;
+            }
+            double xtmp = (rhoi * vicen[n]) / dt;
+            *dfresh = *dfresh + xtmp;
+            xtmp = rhoi * vicen[n] * ice_ref_salinity * p001 / dt;
+            *dfsalt = *dfsalt + xtmp;
+            *aice0 = *aice0 + aicen[n];
+            aicen[n] = c0;
+            vicen[n] = c0;
+            tr[nt_Tsfc] = Tf;
+            zap_snow(dt, nslyr, tr, &vsnon[n], dfresh, dfhocn, nt_qsno);
+            for (int it = 1; it < ntrcr; it++) tr[it] = c0; /* tracers 2..ntrcr (:1203-1211), no brine */
+            first_ice[n] = 1;
+        }
+    }
+    if (*aice > (c1 + puny))
+        return 2;
+    else if (*aice > c1 && *aice < (c1 + puny)) {
+        for (int n = 1; n <= ncat; n++) {
+            const double *tr = trcrn + (size_t)(n - 1) * ntrcr;
+            for (int k = 1; k <= nilyr; k++) {
+                const double xtmp = tr[nt_qice + k - 1] * vicen[n] / (double)nilyr * (*aice - c1) / *aice / dt;
+                *dfhocn = *dfhocn + xtmp;
+            }
+            for (int k = 1; k <= nslyr; k++) {
+                const double xtmp = tr[nt_qsno + k - 1] * vsnon[n] / (double)nslyr * (*aice - c1) / *aice / dt;
+                *dfhocn = *dfhocn + xtmp;
+            }
+            double xtmp = (rhoi * vicen[n] + rhos * vsnon[n]) * (*aice - c1) / *aice / dt;
+            *dfresh = *dfresh + xtmp;
+            xtmp = rhoi * vicen[n] * ice_ref_salinity * p001 * (*aice - c1) / *aice / dt;
+            *dfsalt = *dfsalt + xtmp;
+            aicen[n] = aicen[n] * (c1 / *aice);
+            vicen[n] = vicen[n] * (c1 / *aice);
+            vsnon[n] = vsnon[n] * (c1 / *aice);
+        }
+        *aice = c1;
+        *aice0 = c0;
+    }
+    return 0;
+}
+
+/* zap_snow_temperature :1426-1559 (heat_capacity true) */
+static void zap_snow_temperature(double dt, int ncat, int nslyr, int ntrcr, const double *aicen, double *trcrn, double *vsnon,
+                                 double *dfresh, double *dfhocn, int nt_qsno)
+{
+    const double rnslyr = (double)nslyr;
+    for (int n = 1; n <= ncat; n++) {
+        double *tr = trcrn + (size_t)(n - 1) * ntrcr;
+        int l_zap = 0;
+        if (aicen[n] > puny) {
+            const double hsn = vsnon[n] / aicen[n];
+            for (int k = 1; k <= nslyr; k++) {
+                double zqsn, Tmax;
+                if (hsn > hs_min) {
+                    zqsn = tr[nt_qsno + k - 1];
+                    Tmax = -zqsn * puny * rnslyr / (rhos * cp_ice * vsnon[n]);
+                } else {
+                    zqsn = -rhos * Lfresh;
+                    Tmax = puny;
+                }
+                const double zTsn = (Lfresh + zqsn / rhos) / cp_ice;
+                if (zTsn < Tmin || zTsn > Tmax) l_zap = 1;
+            }
+        }
+        if (l_zap) zap_snow(dt, nslyr, tr, &vsnon[n], dfresh, dfhocn, nt_qsno);
+    }
+}
+
+/* cleanup_itd :754-1020 for one cell.  0-based category arrays of length ncat like ora_ridge_ice.  Returns 0 or 6:
+ * colpkg_step_ridge replaces every stop of the clean-up by 'ice: ITD cleanup error in colpkg_step_ridge' (:3352-3354). */
+int ora_cleanup_itd(double dt, double Tf, int ntrcr, int nilyr, int nslyr, int ncat, const double *hin_max, double *aicen0,
+                    double *trcrn, double *vicen0, double *vsnon0, double *aice0, double *aice, const int *trcr_depend,
+                    int nt_Tsfc, int nt_qice, int nt_qsno, int *first_ice0, double *fresh, double *fsalt, double *fhocn)
+{
+    double aicen[MAXCAT + 1], vicen[MAXCAT + 1], vsnon[MAXCAT + 1];
+    int first_ice[MAXCAT + 1];
+    if (ncat > MAXCAT || ntrcr > MAXTR) return -1;
+    for (int n = 1; n <= ncat; n++) {
+        aicen[n] = aicen0[n - 1];
+        vicen[n] = vicen0[n - 1];
+        vsnon[n] = vsnon0[n - 1];
+        first_ice[n] = first_ice0[n - 1];
+    }
+    double dfresh = c0, dfsalt = c0, dfhocn = c0;
+    int stop = 0;
+    /* aggregate_area :53-81 */
+    *aice = c0;
+    for (int n = 1; n <= ncat; n++) *aice = *aice + aicen[n];
+    *aice0 = fmax(c1 - *aice, c0);
+    if (*aice > c1 + puny || *aice < -puny) return 6; /* 'aggregate ice area out of bounds' */
+    if (*aice > puny) rebin(ntrcr, trcr_depend, nt_Tsfc, Tf, aicen, trcrn, vicen, vsnon, ncat, hin_max);
+    stop = zap_small_areas(dt, Tf, ntrcr, ncat, nilyr, nslyr, aice, aice0, aicen, trcrn, vicen, vsnon, &dfresh, &dfsalt,
+                           &dfhocn, first_ice, nt_Tsfc, nt_qice, nt_qsno);
+    if (!stop) {
+        zap_snow_temperature(dt, ncat, nslyr, ntrcr, aicen, trcrn, vsnon, &dfresh, &dfhocn, nt_qsno);
+        *fresh = *fresh + dfresh;
+        *fsalt = *fsalt + dfsalt;
+        *fhocn = *fhocn + dfhocn;
+    }
+    for (int n = 1; n <= ncat; n++) {
+        aicen0[n - 1] = aicen[n];
+        vicen0[n - 1] = vicen[n];
+        vsnon0[n - 1] = vsnon[n];
+        first_ice0[n - 1] = first_ice[n];
+    }
+    return stop ? 6 : 0;
+}
+
 /* column_ridging's cell loop (mpas_seaice_column.F:3468-3530) over records: for cell c the category arrays are
  * aicen[c * ncat + n] and the tracers trcrn[(c * ncat + n) * ntrcr + it].  Per-category diagnostics likewise.
  * stop[c] receives the cell's return code; the first non-zero code is returned (the reference stops at that cell). */
@@ -374,7 +646,8 @@ int ora_ridge_cells(int nCells, double dt, int ndtd, int ncat, int nslyr, int nt
                     double *aice0, const int *trcr_depend, int nt_Tsfc, int nt_qsno, int krdg_partic, int krdg_redist,
                     double mu_rdg, double *dardg1dt, double *dardg2dt, double *dvirdgdt, double *opening, double *fresh,
                     double *fhocn, double *aparticn, double *krdgn, double *aredistn, double *vredistn, double *dardg1ndt,
-                    double *dardg2ndt, double *dvirdgndt, double *araftn, double *vraftn, int *stop, int *iterations)
+                    double *dardg2ndt, double *dvirdgndt, double *araftn, double *vraftn, int *stop, int *iterations,
+                    int cleanup, int nilyr, int nt_qice, double *aice, double *fsalt, int *first_ice)
 {
     int first = 0;
     for (int c = 0; c < nCells; c++) {
@@ -384,6 +657,11 @@ int ora_ridge_cells(int nCells, double dt, int ndtd, int ncat, int nslyr, int nt
                                 krdg_redist, mu_rdg, dardg1dt + c, dardg2dt + c, dvirdgdt + c, opening + c, fresh + c,
                                 fhocn + c, aparticn + k, krdgn + k, aredistn + k, vredistn + k, dardg1ndt + k, dardg2ndt + k,
                                 dvirdgndt + k, araftn + k, vraftn + k, Tf[c], iterations + c);
+        /* colpkg_step_ridge :3327-3354: the clean-up over the thermodynamic step dtt = dt * ndtd */
+        if (!stop[c] && cleanup)
+            stop[c] = ora_cleanup_itd(dt * ndtd, Tf[c], ntrcr, nilyr, nslyr, ncat, hin_max, aicen + k, trcrn + k * ntrcr,
+                                      vicen + k, vsnon + k, aice0 + c, aice + c, trcr_depend, nt_Tsfc, nt_qice, nt_qsno,
+                                      first_ice + k, fresh + c, fsalt + c, fhocn + c);
         if (stop[c] && !first) first = stop[c];
     }
     return first;

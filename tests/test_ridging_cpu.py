@@ -21,6 +21,9 @@ def _domain(part, redist, conv=2.0e-7, shear=1.0e-7):
     b.structs["velocity_solver"]["dynamicsTimeStep"][0] = 3600.0
     a = b.structs["tracers"]["iceAreaCategory"][0, :, :nC]
     b.structs["icestate"]["openWaterArea"][:nC] = 1.0 - a.sum(axis=0)
+    # the idealised snow enthalpy stands for snow at and above the melting point, which the ITD clean-up would send
+    # into the ocean: 2.5e7 J/m3 colder, i.e. between -20 and -50 degrees
+    b.structs["tracers"]["snowEnthalpy"][..., :nC] -= 0.25e8
     lat = np.asarray(mesh["latCell"])
     b.structs["ridging"]["ridgeConvergence"][:nC] = conv * np.maximum(np.sin(3.0 * lat), 0.0)
     b.structs["ridging"]["ridgeShear"][:nC] = shear * np.cos(lat) ** 2
@@ -64,7 +67,7 @@ def test_no_forcing_and_closed_area_changes_nothing():
     mesh, dom, b = _domain("exponential", "exponential", conv=0.0, shear=0.0)
     nC = mesh.nCells
     before = {k: v.copy() for k, v in b.structs["tracers"].items()}
-    ridge_flow.column_ridging(dom)
+    ridge_flow.column_ridging(dom, cleanup=False)   # ridge_ice alone (the clean-up would sort the ice into its categories)
     ice = before["iceAreaCategory"][0, :, :nC] > 1e-11  # an empty category gets the freezing temperature and zeros
     for k, v in b.structs["tracers"].items():
         diff = np.abs(v[..., :nC] - before[k][..., :nC]) * ice[None]
@@ -105,3 +108,103 @@ def test_single_category_closed_form():
     assert np.allclose(tr["iceVolumeCategory"][0, 0, :nC], 1.0, rtol=1e-13)
     # closing with no open water left: the reference's second iteration finds asum = 1 - c dt < 1 and opens the rest
     assert np.allclose(b.structs["icestate"]["openWaterArea"][:nC], c * 1000.0, rtol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------- the ITD clean-up
+def _thickness_in_bounds(b, nC):
+    tr = b.structs["tracers"]
+    a, v = tr["iceAreaCategory"][0, :, :nC], tr["iceVolumeCategory"][0, :, :nC]
+    lim = b.structs["initial"]["categoryThicknessLimits"]
+    nCat = a.shape[0]
+    h = np.where(a > 1e-11, v / np.where(a > 1e-11, a, 1.0), np.nan)
+    for n in range(nCat):
+        ok = ~np.isnan(h[n])
+        if n < nCat - 1:
+            assert (h[n][ok] <= lim[n + 1] * (1 + 1e-14)).all(), n
+        if n > 0:
+            assert (h[n][ok] > lim[n] * (1 - 1e-14)).all(), n
+
+
+def test_cleanup_sorts_the_ice_into_its_categories_and_conserves():
+    """rebin (ice_itd.F90:89-280): after the clean-up every category holds ice of its own thickness range; area,
+    ice and snow volume, ice energy and salt are what they were (nothing is small enough to be zapped here)."""
+    mesh, dom, b = _domain("exponential", "exponential", conv=0.0, shear=0.0)
+    nC = mesh.nCells
+    tr = b.structs["tracers"]
+    nI = b.dimensions["nIceLayers"]
+    a0, v0, s0 = (tr[k][0, :, :nC].copy() for k in ("iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory"))
+    e0 = (tr["iceEnthalpy"][:, :, :nC] * v0[None] / nI).sum(axis=(0, 1))
+    es0 = (tr["snowEnthalpy"][:, :, :nC] * s0[None]).sum(axis=(0, 1))
+    ridge_flow.column_ridging(dom)
+    a1, v1, s1 = (tr[k][0, :, :nC] for k in ("iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory"))
+    assert np.abs(a1 - a0).max() > 1e-3                         # the idealised state is not sorted: ice has moved
+    _thickness_in_bounds(b, nC)
+    assert np.abs(a1.sum(0) - a0.sum(0)).max() < 1e-14
+    assert np.abs(v1.sum(0) - v0.sum(0)).max() <= 1e-14 * v0.sum(0).max()
+    assert np.abs(s1.sum(0) - s0.sum(0)).max() <= 1e-14 * s0.sum(0).max()
+    e1 = (tr["iceEnthalpy"][:, :, :nC] * v1[None] / nI).sum(axis=(0, 1))
+    es1 = (tr["snowEnthalpy"][:, :, :nC] * s1[None]).sum(axis=(0, 1))
+    assert np.abs(e1 - e0).max() <= 1e-13 * np.abs(e0).max() and np.abs(es1 - es0).max() <= 1e-13 * np.abs(es0).max()
+    assert np.allclose(b.structs["tracers_aggregate"]["iceAreaCell"][:nC], a1.sum(0), rtol=0, atol=1e-15)
+    assert np.allclose(b.structs["icestate"]["openWaterArea"][:nC], np.maximum(1.0 - a1.sum(0), 0.0), rtol=0, atol=1e-15)
+    assert not b.structs["biogeochemistry"]["newlyFormedIce"].any()
+    ridge_flow.column_ridging(dom)                              # sorted ice stays where it is
+    assert np.abs(tr["iceAreaCategory"][0, :, :nC] - a1).max() < 1e-15
+
+
+def test_cleanup_zaps_small_areas_into_the_ocean_fluxes():
+    """zap_small_areas (ice_itd.F90:1029-1336): a category with an area of 1e-12 is emptied; its ice and snow go to the
+    ocean as fresh water (rho_i v_i + rho_s v_s) / dtt, salt (4 ppt of the ice) and heat (its enthalpy), the surface
+    temperature becomes the freezing temperature, the other tracers zero, and the category is marked as new ice."""
+    mesh, dom, b = _domain("exponential", "exponential", conv=0.0, shear=0.0)
+    ridge_flow.column_ridging(dom)                              # sort first, so that only the zapping moves anything
+    nC = mesh.nCells
+    tr = b.structs["tracers"]
+    a = tr["iceAreaCategory"][0, :, :nC]
+    cells = np.flatnonzero(a[2] > 0.01)[:20]
+    assert cells.size == 20
+    lim = b.structs["initial"]["categoryThicknessLimits"]
+    hmid = 0.5 * (lim[2] + lim[3])
+    tr["iceAreaCategory"][0, 2, cells] = 1.0e-12
+    tr["iceVolumeCategory"][0, 2, cells] = 1.0e-12 * hmid
+    tr["snowVolumeCategory"][0, 2, cells] = 2.0e-13
+    b.structs["icestate"]["openWaterArea"][:nC] = 1.0 - tr["iceAreaCategory"][0, :, :nC].sum(0)
+    of = b.structs["ocean_fluxes"]
+    f0, s0, h0 = (of[k][:nC].copy() for k in ("oceanFreshWaterFlux", "oceanSaltFlux", "oceanHeatFlux"))
+    qi = tr["iceEnthalpy"][:, 2, cells].copy()
+    qs = tr["snowEnthalpy"][:, 2, cells].copy()
+    dtt = float(b.structs["velocity_solver"]["dynamicsTimeStep"][0]) * int(dom.configs["config_dynamics_subcycle_number"])
+    ridge_flow.column_ridging(dom)
+    assert np.all(tr["iceAreaCategory"][0, 2, cells] == 0.0) and np.all(tr["iceVolumeCategory"][0, 2, cells] == 0.0)
+    assert np.all(tr["snowVolumeCategory"][0, 2, cells] == 0.0)
+    assert np.all(tr["surfaceTemperature"][0, 2, cells] == -1.8)
+    assert np.all(tr["iceEnthalpy"][:, 2, cells] == 0.0) and np.all(tr["iceSalinity"][:, 2, cells] == 0.0)
+    assert np.all(b.structs["biogeochemistry"]["newlyFormedIce"][2, cells] == 1)
+    assert b.structs["biogeochemistry"]["newlyFormedIce"].sum() == 20
+    vi, vsn = 1.0e-12 * hmid, 2.0e-13
+    assert np.allclose(of["oceanFreshWaterFlux"][cells] - f0[cells], (917.0 * vi + 330.0 * vsn) / dtt, rtol=1e-12)
+    assert np.allclose(of["oceanSaltFlux"][cells] - s0[cells], 917.0 * vi * 4.0 * 0.001 / dtt, rtol=1e-12)
+    heat = (qi * vi / qi.shape[0]).sum(0) / dtt + (qs * vsn / qs.shape[0]).sum(0) / dtt
+    assert np.allclose(of["oceanHeatFlux"][cells] - h0[cells], heat, rtol=1e-10)
+    others = np.setdiff1d(np.arange(nC), cells)
+    assert np.all(of["oceanSaltFlux"][others] == s0[others])
+
+
+def test_cleanup_zaps_snow_that_is_too_warm():
+    """zap_snow_temperature (ice_itd.F90:1426-1559): a snow enthalpy that stands for a temperature above the melting
+    point sends that category's snow into the ocean; the ice stays."""
+    mesh, dom, b = _domain("exponential", "exponential", conv=0.0, shear=0.0)
+    ridge_flow.column_ridging(dom)
+    nC = mesh.nCells
+    tr = b.structs["tracers"]
+    cells = np.flatnonzero((tr["iceAreaCategory"][0, 1, :nC] > 0.01) & (tr["snowVolumeCategory"][0, 1, :nC] > 1e-3))[:10]
+    assert cells.size == 10
+    tr["snowEnthalpy"][0, 1, cells] = -330.0 * 3.34e5 * 0.5     # half molten: T = (Lfresh + q / rho_s) / cp > 0
+    vs0 = tr["snowVolumeCategory"][0, 1, cells].copy()
+    a0 = tr["iceAreaCategory"][0, 1, cells].copy()
+    f0 = b.structs["ocean_fluxes"]["oceanFreshWaterFlux"][cells].copy()
+    dtt = float(b.structs["velocity_solver"]["dynamicsTimeStep"][0]) * int(dom.configs["config_dynamics_subcycle_number"])
+    ridge_flow.column_ridging(dom)
+    assert np.all(tr["snowVolumeCategory"][0, 1, cells] == 0.0) and np.all(tr["snowEnthalpy"][0, 1, cells] == 0.0)
+    assert np.array_equal(tr["iceAreaCategory"][0, 1, cells], a0)
+    assert np.allclose(b.structs["ocean_fluxes"]["oceanFreshWaterFlux"][cells] - f0, 330.0 * vs0 / dtt, rtol=1e-12)

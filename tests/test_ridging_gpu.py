@@ -16,6 +16,13 @@ TRACERS = ["iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory", "surfac
            "iceSalinity", "snowEnthalpy"]
 
 
+def _cold_snow(b):
+    """the idealised snow enthalpy stands for snow at and above the melting point, which the ITD clean-up would send into
+    the ocean: 2.5e7 J/m3 colder, i.e. between -20 and -50 degrees"""
+    nC = b.dimensions["nCells"]
+    b.structs["tracers"]["snowEnthalpy"][..., :nC] -= 0.25e8
+
+
 def _make(mesh, name, extra=None):
     cfg = {"config_elastic_subcycle_number": 60, "config_use_column_package": True}
     cfg.update(extra or {})
@@ -27,6 +34,7 @@ def _make(mesh, name, extra=None):
         # and the ridging closes the sum again)
         b.structs["icestate"]["openWaterArea"][:nC] = 1.0 - b.structs["tracers"]["iceAreaCategory"][0, :, :nC].sum(axis=0)
         b.structs["ocean_fluxes"]["oceanFreshWaterFlux"][:nC] = 1.0e-6
+        _cold_snow(b)
     return dom
 
 
@@ -34,7 +42,9 @@ def _compare(dom, ref, nC):
     b, r = dom.blocklist[0], ref.blocklist[0]
     worst = 0.0
     pairs = [("tracers", t) for t in TRACERS] + [("icestate", "openWaterArea"), ("ocean_fluxes", "oceanFreshWaterFlux"),
-                                                 ("ocean_fluxes", "oceanHeatFlux")]
+                                                 ("ocean_fluxes", "oceanHeatFlux"), ("ocean_fluxes", "oceanSaltFlux"),
+                                                 ("tracers_aggregate", "iceAreaCell")]
+    assert np.array_equal(b.structs["biogeochemistry"]["newlyFormedIce"][:, :nC], r.structs["biogeochemistry"]["newlyFormedIce"][:, :nC])
     pairs += [("ridging", k) for k in pools.RIDGING_CELL_FIELDS + pools.RIDGING_CATEGORY_FIELDS]
     for pool, name in pairs:
         e = rel_linf(b.structs[pool][name][..., :nC], r.structs[pool][name][..., :nC])
@@ -95,7 +105,7 @@ def test_ridging_conserves_volume_and_energy_on_the_device():
         ei0 = (tr["iceEnthalpy"][:, :, :nC] * vi[None] / nI).sum(axis=(0, 1))
         vsn0 = tr["snowVolumeCategory"][0, :, :nC].sum(axis=0)
         f0 = b.structs["ocean_fluxes"]["oceanFreshWaterFlux"][:nC].copy()
-        column.column_ridging(dom, upload="cells", download=True)
+        column.column_ridging(dom, upload="cells", download=True, cleanup=False)   # ridge_ice alone: the clean-up may zap areas below 1e-11
     finally:
         vs.seaice_mesh_pool_destroy(dom)
     v = tr["iceVolumeCategory"][0, :, :nC]
@@ -169,6 +179,7 @@ def _synthetic(mesh, nCategories=5, conv=4.0e-6, shear=2.0e-6, dt=3600.0):
     lon = np.asarray(mesh["lonCell"])
     b.structs["ridging"]["ridgeConvergence"][:nC] = conv * np.sin(3.0 * lat) * np.cos(2.0 * lon)   # both signs
     b.structs["ridging"]["ridgeShear"][:nC] = shear * np.cos(lat) ** 2
+    _cold_snow(b)
     return dom
 
 
@@ -190,3 +201,64 @@ def test_strong_closing_set_by_hand_matches_oracle(nCat):
     assert np.abs(a.sum(axis=0) + dom.blocklist[0].structs["icestate"]["openWaterArea"][:nC] - 1.0).max() < 1e-11
     assert dom.solver_state["ridge_iterations"] == int(ref.solver_state["ridge_iterations"].max())
     print("nCategories", nCat, "worst", worst, "iterations", dom.solver_state["ridge_iterations"])
+
+
+def test_itd_cleanup_cases_match_oracle():
+    """What the clean-up of colpkg_step_ridge does beyond sorting the ice into its categories: a category with an area
+    of 1e-12 goes into the ocean fluxes and is marked as new ice, snow that is too warm is sent to the ocean, and ice
+    whose thickness left its category's range (here: volume doubled by hand) moves up.  Device against oracle."""
+    mesh = get_mesh("QU480")
+
+    def make():
+        dom = _synthetic(mesh, 5, conv=1.0e-7, shear=1.0e-7)
+        b = dom.blocklist[0]
+        nC = mesh.nCells
+        tr = b.structs["tracers"]
+        ridge_flow.column_ridging(dom)          # a sorted state to start from (oracle on both sides: same input)
+        a = tr["iceAreaCategory"][0, :, :nC]
+        cells = np.flatnonzero(a[2] > 0.01)
+        small, warm, thick = cells[:25], cells[25:50], cells[50:75]
+        tr["iceAreaCategory"][0, 2, small] = 1.0e-12
+        tr["iceVolumeCategory"][0, 2, small] = 2.0e-12
+        tr["snowVolumeCategory"][0, 2, small] = 2.0e-13
+        tr["snowEnthalpy"][0, 1, warm] = -330.0 * 3.34e5 * 0.5
+        tr["iceVolumeCategory"][0, 1, thick] *= 2.0
+        b.structs["icestate"]["openWaterArea"][:nC] = 1.0 - tr["iceAreaCategory"][0, :, :nC].sum(axis=0)
+        return dom, (small, warm, thick)
+    ref, (small, warm, thick) = make()
+    dom, _ = make()
+    ridge_flow.column_ridging(ref)
+    vs.seaice_mesh_pool_create(dom)
+    try:
+        vs.seaice_init_velocity_solver(dom)
+        adv.seaice_init_advection(dom)
+        column.column_ridging(dom, upload=True, download=True)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+    nC = mesh.nCells
+    _compare(dom, ref, nC)
+    b = dom.blocklist[0]
+    tr = b.structs["tracers"]
+    assert np.all(tr["iceAreaCategory"][0, 2, small] == 0.0) and np.all(b.structs["biogeochemistry"]["newlyFormedIce"][2, small] == 1)
+    # (where the ridging or the sorting brought in enough cold snow the mixture may stay: nearly all are zapped)
+    assert (tr["snowVolumeCategory"][0, 1, warm] == 0.0).sum() >= 20
+    assert b.structs["ocean_fluxes"]["oceanSaltFlux"][small].min() > 0.0
+    lim = b.structs["initial"]["categoryThicknessLimits"]
+    a, v = tr["iceAreaCategory"][0, :, :nC], tr["iceVolumeCategory"][0, :, :nC]
+    for n in range(4):
+        ok = a[n] > 1e-11
+        assert (v[n][ok] / a[n][ok] <= lim[n + 1] * (1 + 1e-14)).all()
+
+
+def test_ridge_ice_alone_without_the_cleanup_matches_oracle():
+    mesh = get_mesh("QU480")
+    ref, dom = _synthetic(mesh, 5), _synthetic(mesh, 5)
+    ridge_flow.column_ridging(ref, cleanup=False)
+    vs.seaice_mesh_pool_create(dom)
+    try:
+        vs.seaice_init_velocity_solver(dom)
+        adv.seaice_init_advection(dom)
+        column.column_ridging(dom, upload=True, download=True, cleanup=False)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+    _compare(dom, ref, mesh.nCells)
