@@ -440,7 +440,8 @@ int sih_halo_unpack(sih_ctx *ctx, int location, int nFields, const char *const *
  * fields, nLayers * nCategories summed over the tracers for the tracer halo), then every rank's handle
  * (sih_comm_handle_size bytes, from sih_comm_get_handle) is gathered by whatever the host has -- MPI_Allgather in
  * an MPAS host, a file, a socket -- and the table, in rank order, is given to sih_comm_connect.  All ranks
- * must make the same sequence of exchanges. */
+ * must make the same sequence of exchanges.  Halos must be mutual, as those of MPAS blocks are: a block that sends
+ * to a rank it receives nothing from (or the reverse) is refused by sih_comm_create with SIH_ERR_ARG. */
 size_t sih_comm_handle_size(void);
 int sih_comm_create(sih_ctx *ctx, int rank, int nRanks, int maxCellPlanes, int maxVertexPlanes);
 int sih_comm_get_handle(sih_ctx *ctx, void *handle);

@@ -307,6 +307,19 @@ extern "C" int sih_comm_create(sih_ctx *c, int rank, int nRanks, int maxCellPlan
         sih_set_error("sih_comm_create: a block does not exchange with itself");
         return SIH_ERR_ARG;
     }
+    // the two halves of a slot are enough only while a sender cannot run more than one exchange ahead of its
+    // receiver, and what holds it back is its own pull waiting for that receiver's push
+    for (int p = 0; p < nRanks; p++)
+        if ((s->sendTot[p] > 0) != (s->recvTot[p] > 0)) {
+            char msg[200];
+            snprintf(msg, sizeof msg, "sih_comm_create: block %d %s block %d without %s it (halos of MPAS blocks are mutual; "
+                     "the exchange's two buffer halves rely on it)", rank, s->sendTot[p] > 0 ? "sends to" : "receives from", p,
+                     s->sendTot[p] > 0 ? "receiving from" : "sending to");
+            sih_set_error(msg);
+            delete s;
+            c->comm = nullptr;
+            return SIH_ERR_ARG;
+        }
     s->halfBytes = std::max<size_t>(off, 256);
     s->dataOff = ((size_t)nRanks * SIH_FLAG_STRIDE + 4095) & ~(size_t)4095;
     // tagged words: per received cell the three stresses at every corner, per received vertex the two velocities,
