@@ -85,6 +85,23 @@ module seaice_hip_interface
        integer(c_int) :: ierr
      end function sih_column_ridge
 
+     function sih_column_update_state(ctx, nCategories, dt, tendencies) bind(C, name="sih_column_update_state") result(ierr)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nCategories
+       real(c_double), value :: dt
+       integer(c_int), value :: tendencies
+       integer(c_int) :: ierr
+     end function sih_column_update_state
+
+     function sih_column_reinitialize_diagnostics(ctx, nCategories) &
+          bind(C, name="sih_column_reinitialize_diagnostics") result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nCategories
+       integer(c_int) :: ierr
+     end function sih_column_reinitialize_diagnostics
+
      function sih_block_create(mesh, device, ctx) bind(C, name="sih_block_create") result(ierr)
        import :: sih_mesh_desc, c_int, c_ptr
        type(sih_mesh_desc), intent(in) :: mesh

@@ -291,6 +291,21 @@ int sih_column_ridge(sih_ctx *ctx, const sih_ridge_config *cfg);
 /* creates the cell fields listed above (zero-filled) without running anything, so that a host can put its ocean state
  * and accumulated fluxes before the first sih_column_ridge */
 int sih_column_ridge_init(sih_ctx *ctx, int nCategories);
+/* seaice_column_update_state(domain, "transport", dt, 0) (src/shared/mpas_seaice_column.F:4279-4377), which follows the
+ * ridging in seaice_column_dynamics_time_integration (:1139-1194): for every owned cell colpkg_aggregate
+ * (src/column/ice_colpkg.F90:3366-3480, through seaice_column_aggregate :4391-4494) -- iceAreaCell, iceVolumeCell,
+ * snowVolumeCell, openWaterArea and the cell value of every category tracer, written to the cell field
+ * "<tracer>Cell" with the tracer's layers (surfaceTemperatureCell, iceEnthalpyCell, iceSalinityCell, snowEnthalpyCell
+ * of the `tracers_aggregate` pool; created on first use) -- and, with tendencies != 0, the transport tendencies
+ * iceAreaTendencyTransport = (iceAreaCell - iceAreaTendencyTransport) / dt and the same for the volume (:4352-4355;
+ * the ice age, config_use_ice_age, is not carried).  Same tracer set as sih_column_ridge; asynchronous on the
+ * context's stream. */
+int sih_column_update_state(sih_ctx *ctx, int nCategories, double dt, int tendencies);
+/* seaice_column_reinitialize_diagnostics_dynamics (:13569-13723) for the fields of this path, at the start of a
+ * dynamics subcycle: areaLossRidge, areaGainRidge, iceVolumeRidged, openingRateRidge = 0; iceAreaTendencyTransport =
+ * iceAreaCell, iceVolumeTendencyTransport = iceVolumeCell, iceAgeTendencyTransport = 0 (whole arrays).  The velocity
+ * solver's diagnostics the reference zeroes there as well are all set by sih_evp_run. */
+int sih_column_reinitialize_diagnostics(sih_ctx *ctx, int nCategories);
 /* sih_field_get for callers that cannot allocate: code under HIP graph capture elsewhere in the process, tight
  * serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  The layout conversion is
  * staged in a 16 MiB array that is part of the library's code object on every GPU, so the call makes no

@@ -5,7 +5,8 @@
 
 The ridging works on the device fields of the advected tracers, so that between the advection and the next velocity
 solve nothing has to visit the host.  Scope and limits: see ``sih_column_ridge`` in include/seaice_hip.h (standard
-physics tracers, no strata; the aggregation that follows in seaice_column_update_state is not included)."""
+physics tracers, no strata), and so does the aggregation that follows it, ``seaice_column_update_state`` (:4279-4377 ->
+``seaice_column_aggregate`` :4391-4494 -> ``colpkg_aggregate``, /root/reference/src/column/ice_colpkg.F90:3366-3480)."""
 from __future__ import annotations
 
 from . import pools
@@ -16,7 +17,8 @@ REDISTRIBUTION = {"Hibler80": 0, "exponential": 1}
 INPUT_FIELDS = (("ridging", "ridgeConvergence"), ("ridging", "ridgeShear"), ("icestate", "openWaterArea"),
                 ("ocean_coupling", "seaFreezingTemperature"), ("ocean_fluxes", "oceanFreshWaterFlux"),
                 ("ocean_fluxes", "oceanHeatFlux"), ("ocean_fluxes", "oceanSaltFlux"), ("ridging", "fractionNewRidgeArea"),
-                ("ridging", "fractionNewRidgeVolume"), ("biogeochemistry", "newlyFormedIce"))
+                ("ridging", "fractionNewRidgeVolume"), ("biogeochemistry", "newlyFormedIce"),
+                ("diagnostics", "iceAreaTendencyTransport"), ("diagnostics", "iceVolumeTendencyTransport"))
 OUTPUT_FIELDS = (("icestate", "openWaterArea"), ("ocean_fluxes", "oceanFreshWaterFlux"), ("ocean_fluxes", "oceanHeatFlux"),
                  ("ocean_fluxes", "oceanSaltFlux"), ("biogeochemistry", "newlyFormedIce"), ("tracers_aggregate", "iceAreaCell")) \
     + tuple(("ridging", k) for k in pools.RIDGING_CELL_FIELDS + pools.RIDGING_CATEGORY_FIELDS)
@@ -60,9 +62,66 @@ def column_ridging(domain, upload=True, download=True, cleanup=True):
             b.ctx.get_many([(n, tp[n]) for n in names] + [(n, b.structs[p][n]) for p, n in OUTPUT_FIELDS])
 
 
+AGGREGATE_FIELDS = (("tracers_aggregate", "iceAreaCell"), ("tracers_aggregate", "iceVolumeCell"),
+                    ("tracers_aggregate", "snowVolumeCell"), ("icestate", "openWaterArea"),
+                    ("diagnostics", "iceAreaTendencyTransport"), ("diagnostics", "iceVolumeTendencyTransport"))
+# category tracers whose cell values the `tracers_aggregate` pool holds as <name>Cell (get_cice_physics_tracer_array_cell
+# :7007-7183, the standard physics set)
+AGGREGATED_TRACERS = ("surfaceTemperature", "iceEnthalpy", "iceSalinity", "snowEnthalpy")
+
+
+def seaice_column_update_state(domain, stateUpdateType="transport", dt=None, upload=False, download=True):
+    """:4279-4377 on the device, for the category tracers the device holds: the aggregate state of every owned cell
+    and the transport tendencies.  ``upload``: tracers, freezing temperature and the tendencies' start values go up
+    first (a host that has not just run the ridging on the device)."""
+    if stateUpdateType != "transport":
+        raise SeaiceHipError("seaice_column_update_state: Unknown update type: " + stateUpdateType)
+    names = [t.tracerName for t in domain.solver_state["tracersHead"]]
+    for b in domain.blocklist:
+        pools.allocate_ridging_pools(b)
+        tp = b.structs["tracers"]
+        step = float(b.structs["velocity_solver"]["dynamicsTimeStep"][0]) if dt is None else float(dt)
+        nCat = b.dimensions["nCategories"]
+        if upload:
+            b.ctx.ridge_prepare_fields(nCat)
+            b.ctx.column_update_state(nCat, step, tendencies=False)  # creates the fields; overwritten below
+            b.ctx.put_many([(n, tp[n]) for n in names]
+                           + [("seaFreezingTemperature", b.structs["ocean_coupling"]["seaFreezingTemperature"])]
+                           + [(n, b.structs["diagnostics"][n]) for n in ("iceAreaTendencyTransport",
+                                                                         "iceVolumeTendencyTransport")])
+        b.ctx.column_update_state(nCat, step, tendencies=True)
+        if download:
+            ta = b.structs["tracers_aggregate"]
+            b.ctx.get_many([(n, b.structs[p][n]) for p, n in AGGREGATE_FIELDS]
+                           + [(n + "Cell", ta[n + "Cell"]) for n in AGGREGATED_TRACERS if n in names])
+
+
+def seaice_column_reinitialize_diagnostics_dynamics(domain, on_device=False):
+    """:13569-13723 for the fields of this path, at the start of a dynamics subcycle: the ridging rates back to zero,
+    the transport tendencies set to the aggregate state before the dynamics.  On the pools, or (``on_device``) on the
+    device fields, for a step whose state stays there between two dynamics subcycles."""
+    if not domain.configs["config_use_column_package"]:
+        return
+    for b in domain.blocklist:
+        pools.allocate_ridging_pools(b)
+        if on_device:
+            b.ctx.column_reinitialize_diagnostics(b.dimensions["nCategories"])
+            continue
+        rg, ta, dg = b.structs["ridging"], b.structs["tracers_aggregate"], b.structs["diagnostics"]
+        for k in pools.RIDGING_CELL_FIELDS:
+            rg[k][:] = 0.0
+        dg["iceAreaTendencyTransport"][:] = ta["iceAreaCell"]
+        dg["iceVolumeTendencyTransport"][:] = ta["iceVolumeCell"]
+        dg["iceAgeTendencyTransport"][:] = 0.0
+
+
 def seaice_column_dynamics_time_integration(domain, upload=True, download=True):
-    """:1139-1194, the ridging part (column_combine_snow_ice_tracers and seaice_column_update_state belong to column
-    physics options outside this library)"""
+    """:1139-1194: the ridging, then the aggregate state and the transport tendencies (column_combine_snow_ice_tracers
+    belongs to config_use_vertical_tracers, outside this library)"""
     cfg = domain.configs
-    if cfg["config_use_column_package"] and cfg.get("config_use_column_ridging", True):
+    if not cfg["config_use_column_package"]:
+        return
+    ridging = cfg.get("config_use_column_ridging", True)
+    if ridging:
         column_ridging(domain, upload=upload, download=download)
+    seaice_column_update_state(domain, "transport", upload=(upload is True and not ridging), download=download)

@@ -26,10 +26,12 @@
 
 #define RIDGE_MAXCAT 10
 #define RIDGE_MAXTR 48
+#define RIDGE_BLOCK 64  // cells (threads) per block of the ridging kernel
+typedef __attribute__((address_space(3))) double RidgeLdsDouble;
 
 struct RidgeTracer {
     double *val;  // plane 0 of the field
-    int L, layer, depend;
+    int L, layer, depend, pad;
 };
 
 struct RidgeDev {
@@ -44,7 +46,9 @@ struct RidgeDev {
     double *dardg1dt, *dardg2dt, *dvirdgdt, *opening, *fresh, *fhocn;
     double *aparticn, *krdgn, *aredistn, *vredistn, *dardg1ndt, *dardg2ndt, *dvirdgndt, *araftn, *vraftn;
     int *flag;  // [0] highest stop code of any cell, [1] most iterations of any cell
-    RidgeTracer tr[RIDGE_MAXTR];
+    // the tracers, in device memory (indexed by run-time values: as a member array the whole argument block would be
+    // copied to scratch memory for it)
+    const RidgeTracer *tr;
 };
 
 struct sih_ridge_state {
@@ -52,12 +56,15 @@ struct sih_ridge_state {
     int planes = 0;
     int *d_flag = nullptr;
     int lastIterations = 0;
+    RidgeTracer *d_tr = nullptr;       // RIDGE_MAXTR entries
+    std::vector<RidgeTracer> hostTr;   // what d_tr holds
 };
 
 void sih_ridge_destroy(sih_ctx *c)
 {
     if (!c->ridge) return;
     if (c->ridge->d_flag) (void)hipFree(c->ridge->d_flag);
+    if (c->ridge->d_tr) (void)hipFree(c->ridge->d_tr);
     delete c->ridge;
     c->ridge = nullptr;
 }
@@ -72,6 +79,11 @@ void sih_ridge_destroy(sih_ctx *c)
 #define RDG_HSTAR 25.0
 #define RDG_RHOS 330.0
 
+// Loops over the categories run to the compile-time bound, so that every index into the per-cell arrays is a constant
+// and the arrays stay in registers (with run-time bounds they lived in scratch memory)
+#define FORCAT(n) _Pragma("unroll") for (int n = 1; n <= NC; n++) if (n <= ncat)
+#define FORCAT0(n) _Pragma("unroll") for (int n = 0; n <= NC; n++) if (n <= ncat)
+
 // category arrays are 1-based (index 0 of apartic is the open water), as in the reference
 template <int NC>
 struct RidgeCell {
@@ -82,7 +94,7 @@ struct RidgeCell {
 
 // ridge_itd :741-1012
 template <int NC>
-__device__ void ridgeItd(const RidgeDev &d, int ncat, double aice0, RidgeCell<NC> &s, double &aksum)
+__device__ __forceinline__ void ridgeItd(const RidgeDev &d, int ncat, double aice0, RidgeCell<NC> &s, double &aksum)
 {
     const double Gstari = 1.0 / RDG_GSTAR, astari = 1.0 / RDG_ASTAR;
     double GsumA[NC + 2];
@@ -90,7 +102,7 @@ __device__ void ridgeItd(const RidgeDev &d, int ncat, double aice0, RidgeCell<NC
     Gsum[-1] = 0.0;
     Gsum[0] = aice0 > PUNY ? aice0 : Gsum[-1];
     s.apartic[0] = 0.0;
-    for (int n = 1; n <= ncat; n++) {
+    FORCAT(n) {
         Gsum[n] = 1.0;
         s.apartic[n] = 0.0;
         s.hrmin[n] = 0.0;
@@ -103,9 +115,9 @@ __device__ void ridgeItd(const RidgeDev &d, int ncat, double aice0, RidgeCell<NC
             Gsum[n] = Gsum[n - 1];
     }
     const double work = 1.0 / Gsum[ncat];
-    for (int n = 0; n <= ncat; n++) Gsum[n] = Gsum[n] * work;
+    FORCAT0(n) Gsum[n] = Gsum[n] * work;
     if (d.krdgPartic == 0) {
-        for (int n = 0; n <= ncat; n++) {
+        FORCAT0(n) {
             if (Gsum[n] < RDG_GSTAR)
                 s.apartic[n] = Gstari * (Gsum[n] - Gsum[n - 1]) * (2.0 - Gstari * (Gsum[n - 1] + Gsum[n]));
             else if (Gsum[n - 1] < RDG_GSTAR)
@@ -114,13 +126,13 @@ __device__ void ridgeItd(const RidgeDev &d, int ncat, double aice0, RidgeCell<NC
     } else {
         const double xtmp = 1.0 / (1.0 - exp(-astari));
         Gsum[-1] = exp(-Gsum[-1] * astari) * xtmp;
-        for (int n = 0; n <= ncat; n++) {
+        FORCAT0(n) {
             Gsum[n] = exp(-Gsum[n] * astari) * xtmp;
             s.apartic[n] = Gsum[n - 1] - Gsum[n];
         }
     }
     if (d.krdgRedist == 0) {
-        for (int n = 1; n <= ncat; n++)
+        FORCAT(n)
             if (s.aicen[n] > PUNY) {
                 const double hi = s.vicen[n] / s.aicen[n];
                 s.hrmin[n] = fmin(2.0 * hi, hi + RDG_MAXRAFT);
@@ -130,7 +142,7 @@ __device__ void ridgeItd(const RidgeDev &d, int ncat, double aice0, RidgeCell<NC
                 s.krdg[n] = hrmean / hi;
             }
     } else {
-        for (int n = 1; n <= ncat; n++)
+        FORCAT(n)
             if (s.aicen[n] > PUNY) {
                 double hi = s.vicen[n] / s.aicen[n];
                 hi = fmax(hi, PUNY);
@@ -143,7 +155,7 @@ __device__ void ridgeItd(const RidgeDev &d, int ncat, double aice0, RidgeCell<NC
             }
     }
     aksum = s.apartic[0];
-    for (int n = 1; n <= ncat; n++) aksum = aksum + s.apartic[n] * (1.0 - 1.0 / s.krdg[n]);
+    FORCAT(n) aksum = aksum + s.apartic[n] * (1.0 - 1.0 / s.krdg[n]);
 }
 
 __device__ inline double &trc(const RidgeDev &d, int it, int n, int cell)  // trcrn(it, n), n = 1 .. ncat
@@ -156,24 +168,25 @@ __device__ inline double &atr(const RidgeDev &d, int it, int n, int cell)  // at
     return d.atrcrn[((size_t)it * d.ncat + (n - 1)) * d.padC + cell];
 }
 
-// ridge_shift :1030-1541; returns the number of the reference's stop (1 'aice0 < 0', 2 'ardg > aicen') or 0
+// ridge_shift :1030-1541; returns the number of the reference's stop (1 'aice0 < 0', 2 'ardg > aicen') or 0.
+// The reference moves the tracer products of a ridging category to the receiving ones inside its loops over category
+// pairs (:1206-1211, :1508-1517).  Here those loops only keep what the products need (the areas and volumes that
+// leave category n, the fractions farea / fvol that category nr receives of them), and the products of one tracer
+// at a time are then formed, moved and divided again in registers, in the reference's order of operations for every
+// product: a tracer is read once and written once, and the tracers are independent of each other.
 template <int NC>
-__device__ int ridgeShift(const RidgeDev &d, int ncat, int cell, RidgeCell<NC> &s, double &aice0, double aksum,
+__device__ __forceinline__ int ridgeShift(const RidgeDev &d, int ncat, int cell, RidgeCell<NC> &s, double &aice0, double aksum,
                           double closing_net, double &opning, double &ardg1, double &ardg2, double &virdg, double &aopen,
-                          double &msnow_mlt, double &esnow_mlt, double Tf)
+                          double &msnow_mlt, double &esnow_mlt, double Tf, RidgeLdsDouble *frac)
 {
     double aicen_init[NC + 1], vicen_init[NC + 1], vsnon_init[NC + 1];
     const int ntrcr = d.ntrcr;
     const double dt = d.dt;
-    for (int n = 1; n <= ncat; n++) {
+    FORCAT(n)
+    {
         aicen_init[n] = s.aicen[n];
         vicen_init[n] = s.vicen[n];
         vsnon_init[n] = s.vsnon[n];
-        for (int it = 0; it < ntrcr; it++) {
-            const int dep = d.tr[it].depend;
-            const double b1 = dep == 0, b2 = dep == 1, b3 = dep == 2;
-            atr(d, it, n, cell) = trc(d, it, n, cell) * (b1 * s.aicen[n] + b2 * s.vicen[n] + b3 * s.vsnon[n]);
-        }
     }
     double closing_gross = closing_net / aksum;
     if (s.apartic[0] > 0.0) {
@@ -184,15 +197,15 @@ __device__ int ridgeShift(const RidgeDev &d, int ncat, int cell, RidgeCell<NC> &
             opning = opning * tmpfac;
         }
     }
-    for (int n = 1; n <= ncat; n++)
-        if (s.aicen[n] > PUNY && s.apartic[n] > 0.0) {
-            const double wk1 = s.apartic[n] * closing_gross * dt;
-            if (wk1 > s.aicen[n]) {
-                const double tmpfac = s.aicen[n] / wk1;
-                closing_gross = closing_gross * tmpfac;
-                opning = opning * tmpfac;
-            }
+    FORCAT(n)
+    if (s.aicen[n] > PUNY && s.apartic[n] > 0.0) {
+        const double wk1 = s.apartic[n] * closing_gross * dt;
+        if (wk1 > s.aicen[n]) {
+            const double tmpfac = s.aicen[n] / wk1;
+            closing_gross = closing_gross * tmpfac;
+            opning = opning * tmpfac;
         }
+    }
     aice0 = aice0 - s.apartic[0] * closing_gross * dt + opning * dt;
     if (aice0 < -PUNY)
         return 1;
@@ -200,7 +213,15 @@ __device__ int ridgeShift(const RidgeDev &d, int ncat, int cell, RidgeCell<NC> &
         aice0 = 0.0;
     aopen = opning * dt;
 
-    for (int n = 1; n <= ncat; n++) {
+    // category n ridges in this call: ardg1n, ardg2n, virdgn of the cell's state and vsrdgnC are those of this call.
+    // The fractions farea(n, nr), fvol(n, nr) wait for the tracers in LDS (`frac`: this thread's column of
+    // [2 * NC * NC][RIDGE_BLOCK]): 50 more doubles would not fit the registers beside the cell's state
+    bool moves[NC + 1];
+    double vsrdgnC[NC + 1];
+    bool any = false;
+    FORCAT(n)
+    {
+        moves[n] = false;
         if (aicen_init[n] > PUNY && s.apartic[n] > 0.0 && closing_gross > 0.0) {
             double ardg1n = s.apartic[n] * closing_gross * dt;
             if (ardg1n > aicen_init[n] + PUNY)
@@ -220,6 +241,9 @@ __device__ int ridgeShift(const RidgeDev &d, int ncat, int cell, RidgeCell<NC> &
             s.ardg1n[n] = ardg1n;
             s.ardg2n[n] = ardg2n;
             s.virdgn[n] = virdgn;
+            moves[n] = true;
+            any = true;
+            vsrdgnC[n] = vsrdgn;
             msnow_mlt = msnow_mlt + RDG_RHOS * vsrdgn * (1.0 - RDG_FSNOW);
             const double dhr = s.hrmax[n] - s.hrmin[n];
             const double dhr2 = s.hrmax[n] * s.hrmax[n] - s.hrmin[n] * s.hrmin[n];
@@ -228,18 +252,8 @@ __device__ int ridgeShift(const RidgeDev &d, int ncat, int cell, RidgeCell<NC> &
                     const double esrdgn = vsrdgn * trc(d, d.ntQsno + k - 1, n, cell) / (double)d.nslyr;
                     esnow_mlt = esnow_mlt + esrdgn * (1.0 - RDG_FSNOW);
                 }
-            for (int it = 0; it < ntrcr; it++) {
-                const int dep = d.tr[it].depend;
-                const double f1 = (dep == 0 ? 1.0 : 0.0) * ardg1n, f2 = (dep == 1 ? 1.0 : 0.0) * virdgn,
-                             f3 = (dep == 2 ? 1.0 : 0.0) * vsrdgn;
-                const double tv = trc(d, it, n, cell);
-                double work = 0.0;
-                work = work + f1 * tv;
-                work = work + f2 * tv;
-                work = work + f3 * tv;
-                atr(d, it, n, cell) = atr(d, it, n, cell) - work;
-            }
-            for (int nr = 1; nr <= ncat; nr++) {
+            FORCAT(nr)
+            {
                 double farea, fvol, hL, hR;
                 if (d.krdgRedist == 0) {
                     if (s.hrmin[n] >= d.hinMax[nr] || s.hrmax[n] <= d.hinMax[nr - 1]) {
@@ -279,38 +293,63 @@ __device__ int ridgeShift(const RidgeDev &d, int ncat, int cell, RidgeCell<NC> &
                 s.aicen[nr] = s.aicen[nr] + farea * ardg2n;
                 s.vicen[nr] = s.vicen[nr] + fvol * virdgn;
                 s.vsnon[nr] = s.vsnon[nr] + fvol * vsrdgn * RDG_FSNOW;
-                for (int it = 0; it < ntrcr; it++) {
-                    const int dep = d.tr[it].depend;
-                    const double f1 = (dep == 0 ? 1.0 : 0.0) * ardg2n * farea, f2 = (dep == 1 ? 1.0 : 0.0) * virdgn * fvol,
-                                 f3 = (dep == 2 ? 1.0 : 0.0) * vsrdgn * fvol * RDG_FSNOW;
-                    const double tv = trc(d, it, n, cell);
-                    double work = 0.0;
-                    work = work + f1 * tv;
-                    work = work + f2 * tv;
-                    work = work + f3 * tv;
-                    atr(d, it, nr, cell) = atr(d, it, nr, cell) + work;
-                }
+                frac[((n - 1) * NC + nr - 1) * RIDGE_BLOCK] = farea;
+                frac[(NC * NC + (n - 1) * NC + nr - 1) * RIDGE_BLOCK] = fvol;
             }
         }
     }
-    // colpkg_compute_tracers, ice_colpkg_tracers.F90:216-252 (no strata; the loop over the three divisors keeps the last
-    // positive one, which with a unit trcr_base is the tracer's own base quantity)
-    for (int n = 1; n <= ncat; n++)
-        for (int it = 0; it < ntrcr; it++) {
-            const int dep = d.tr[it].depend;
-            const double a = atr(d, it, n, cell);
+    // The tracers.  Where nothing ridges the products are formed and divided again all the same (:1151, :1530): a
+    // category below puny then gets its tracers reset (colpkg_compute_tracers).  The next tracer's values are requested
+    // before this one's are stored.
+    double tvNext[NC + 1];
+    if (ntrcr > 0) FORCAT(n) tvNext[n] = trc(d, 0, n, cell);
+    for (int it = 0; it < ntrcr; it++) {
+        const int dep = d.tr[it].depend;
+        const double b1 = dep == 0 ? 1.0 : 0.0, b2 = dep == 1 ? 1.0 : 0.0, b3 = dep == 2 ? 1.0 : 0.0;
+        double tv[NC + 1], at[NC + 1];
+        FORCAT(n) tv[n] = tvNext[n];
+        if (it + 1 < ntrcr) FORCAT(n) tvNext[n] = trc(d, it + 1, n, cell);
+        FORCAT(n) at[n] = tv[n] * (b1 * aicen_init[n] + b2 * vicen_init[n] + b3 * vsnon_init[n]);
+        if (any) FORCAT(n)
+        if (moves[n]) {
+            {
+                const double f1 = b1 * s.ardg1n[n], f2 = b2 * s.virdgn[n], f3 = b3 * vsrdgnC[n];
+                double work = 0.0;
+                work = work + f1 * tv[n];
+                work = work + f2 * tv[n];
+                work = work + f3 * tv[n];
+                at[n] = at[n] - work;
+            }
+            FORCAT(nr)
+            {
+                const double farea = frac[((n - 1) * NC + nr - 1) * RIDGE_BLOCK],
+                             fvol = frac[(NC * NC + (n - 1) * NC + nr - 1) * RIDGE_BLOCK];
+                const double f1 = b1 * s.ardg2n[n] * farea, f2 = b2 * s.virdgn[n] * fvol, f3 = b3 * vsrdgnC[n] * fvol * RDG_FSNOW;
+                double work = 0.0;
+                work = work + f1 * tv[n];
+                work = work + f2 * tv[n];
+                work = work + f3 * tv[n];
+                at[nr] = at[nr] + work;
+            }
+        }
+        // colpkg_compute_tracers, ice_colpkg_tracers.F90:216-252 (no strata; the loop over the three divisors keeps the
+        // last positive one, which with a unit trcr_base is the tracer's own base quantity)
+        FORCAT(n)
+        {
+            const double an = s.aicen[n], vn = s.vicen[n], sn = s.vsnon[n];  // (read before the branches on purpose)
             double v;
             if (dep == 0) {
-                if (s.aicen[n] > PUNY)
-                    v = a / s.aicen[n];
+                if (an > PUNY)
+                    v = at[n] / an;
                 else
                     v = it == d.ntTsfc ? Tf : 0.0;
             } else {
-                const double div = dep == 1 ? s.vicen[n] : s.vsnon[n];
-                v = div > 0.0 ? a / div : 0.0;
+                const double div = dep == 1 ? vn : sn;
+                v = div > 0.0 ? at[n] / div : 0.0;
             }
             trc(d, it, n, cell) = v;
         }
+    }
     return 0;
 }
 
@@ -325,19 +364,20 @@ __device__ int ridgeShift(const RidgeDev &d, int ncat, int cell, RidgeCell<NC> &
 
 // colpkg_compute_tracers for category n (ice_colpkg_tracers.F90:216-252, no strata)
 template <int NC>
-__device__ inline void computeTracers(const RidgeDev &d, int n, int cell, const RidgeCell<NC> &s, double Tf)
+__device__ __forceinline__ void computeTracers(const RidgeDev &d, int n, int cell, const RidgeCell<NC> &s, double Tf)
 {
     for (int it = 0; it < d.ntrcr; it++) {
         const int dep = d.tr[it].depend;
         const double a = atr(d, it, n, cell);
+        const double an = s.aicen[n], vn = s.vicen[n], sn = s.vsnon[n];  // (read before the branches on purpose)
         double v;
         if (dep == 0) {
-            if (s.aicen[n] > PUNY)
-                v = a / s.aicen[n];
+            if (an > PUNY)
+                v = a / an;
             else
                 v = it == d.ntTsfc ? Tf : 0.0;
         } else {
-            const double div = dep == 1 ? s.vicen[n] : s.vsnon[n];
+            const double div = dep == 1 ? vn : sn;
             v = div > 0.0 ? a / div : 0.0;
         }
         trc(d, it, n, cell) = v;
@@ -347,10 +387,10 @@ __device__ inline void computeTracers(const RidgeDev &d, int n, int cell, const 
 // shift_ice :347-665 with one active boundary n (donor category nd), as rebin calls it.  Returns true for one of
 // its four stops; nothing has moved then.
 template <int NC>
-__device__ bool shiftIce(const RidgeDev &d, int ncat, int cell, RidgeCell<NC> &s, double (&hicen)[NC + 1], int n, int nd,
+__device__ __forceinline__ bool shiftIce(const RidgeDev &d, int ncat, int cell, RidgeCell<NC> &s, double (&hicen)[NC + 1], int n, int nd,
                          double daice, double dvice, double Tf)
 {
-    for (int m = 1; m <= ncat; m++)
+    FORCAT(m)
         for (int it = 0; it < d.ntrcr; it++) {
             const int dep = d.tr[it].depend;
             const double b1 = dep == 0, b2 = dep == 1, b3 = dep == 2;
@@ -408,7 +448,7 @@ __device__ bool shiftIce(const RidgeDev &d, int ncat, int cell, RidgeCell<NC> &s
             atr(d, it, nr, cell) = atr(d, it, nr, cell) + datrcr;
         }
     }
-    for (int m = 1; m <= ncat; m++) {
+    FORCAT(m) {
         hicen[m] = s.aicen[m] > PUNY ? s.vicen[m] / s.aicen[m] : 0.0;
         computeTracers<NC>(d, m, cell, s, Tf);
     }
@@ -417,7 +457,7 @@ __device__ bool shiftIce(const RidgeDev &d, int ncat, int cell, RidgeCell<NC> &s
 
 // zap_snow :1340-1422 for category n
 template <int NC>
-__device__ inline void zapSnow(const RidgeDev &d, int n, int cell, RidgeCell<NC> &s, double dt, double &dfresh, double &dfhocn)
+__device__ __forceinline__ void zapSnow(const RidgeDev &d, int n, int cell, RidgeCell<NC> &s, double dt, double &dfresh, double &dfhocn)
 {
     if (d.ntQsno >= 0)
         for (int k = 1; k <= d.nslyr; k++) {
@@ -433,31 +473,31 @@ __device__ inline void zapSnow(const RidgeDev &d, int n, int cell, RidgeCell<NC>
 // cleanup_itd :754-1020 for one cell: aggregate_area :53-81, rebin :89-280, zap_small_areas :1029-1336,
 // zap_snow_temperature :1426-1559.  Returns true for a stop (colpkg_step_ridge reports them all under one label).
 template <int NC>
-__device__ bool cleanupItd(const RidgeDev &d, int ncat, int cell, RidgeCell<NC> &s, double &aice0, double Tf)
+__device__ __forceinline__ bool cleanupItd(const RidgeDev &d, int ncat, int cell, RidgeCell<NC> &s, double &aice0, double Tf)
 {
     const double dt = d.dt * d.ndtd;
     double dfresh = 0.0, dfsalt = 0.0, dfhocn = 0.0;
     double aice = 0.0;
-    for (int n = 1; n <= ncat; n++) aice = aice + s.aicen[n];
+    FORCAT(n) aice = aice + s.aicen[n];
     aice0 = fmax(1.0 - aice, 0.0);
     d.aice[cell] = aice;
     if (aice > 1.0 + PUNY || aice < -PUNY) return true;  // 'aggregate ice area out of bounds'
     if (aice > PUNY) {  // rebin
         double hicen[NC + 1];
-        for (int n = 1; n <= ncat; n++) hicen[n] = s.aicen[n] > PUNY ? s.vicen[n] / s.aicen[n] : 0.0;
+        FORCAT(n) hicen[n] = s.aicen[n] > PUNY ? s.vicen[n] / s.aicen[n] : 0.0;
         if (s.aicen[1] > PUNY && hicen[1] <= d.hinMax[0] && d.hinMax[0] > 0.0) {
             s.aicen[1] = s.vicen[1] / d.hinMax[0];
             hicen[1] = d.hinMax[0];
         }
         // a stop inside shift_ice is not looked at by cleanup_itd: zap_small_areas clears the flag (:1102)
-        for (int n = 1; n <= ncat - 1; n++)
+        _Pragma("unroll") for (int n = 1; n <= NC - 1; n++) if (n <= ncat - 1)
             if (s.aicen[n] > PUNY && hicen[n] > d.hinMax[n]) shiftIce<NC>(d, ncat, cell, s, hicen, n, n, s.aicen[n], s.vicen[n], Tf);
-        for (int n = ncat - 1; n >= 1; n--)
+        _Pragma("unroll") for (int n = NC - 1; n >= 1; n--) if (n <= ncat - 1)
             if (s.aicen[n + 1] > PUNY && hicen[n + 1] <= d.hinMax[n])
                 shiftIce<NC>(d, ncat, cell, s, hicen, n, n + 1, s.aicen[n + 1], s.vicen[n + 1], Tf);
     }
     // zap_small_areas
-    for (int n = 1; n <= ncat; n++) {
+    FORCAT(n) {
         if (s.aicen[n] < -PUNY)
             return true;  // 'Zap ice: negative ice area'
         else if (fabs(s.aicen[n]) != 0.0 && fabs(s.aicen[n]) <= PUNY) {
@@ -483,7 +523,7 @@ __device__ bool cleanupItd(const RidgeDev &d, int ncat, int cell, RidgeCell<NC> 
     if (aice > 1.0 + PUNY)
         return true;  // 'Zap ice: excess ice area'
     else if (aice > 1.0 && aice < 1.0 + PUNY) {
-        for (int n = 1; n <= ncat; n++) {
+        FORCAT(n) {
             if (d.ntQice >= 0)
                 for (int k = 1; k <= d.nilyr; k++) {
                     const double xtmp = trc(d, d.ntQice + k - 1, n, cell) * s.vicen[n] / (double)d.nilyr * (aice - 1.0) / aice / dt;
@@ -509,7 +549,7 @@ __device__ bool cleanupItd(const RidgeDev &d, int ncat, int cell, RidgeCell<NC> 
     // zap_snow_temperature
     if (d.ntQsno >= 0) {
         const double rnslyr = (double)d.nslyr;
-        for (int n = 1; n <= ncat; n++) {
+        FORCAT(n) {
             bool zap = false;
             if (s.aicen[n] > PUNY) {
                 const double hsn = s.vsnon[n] / s.aicen[n];
@@ -536,13 +576,15 @@ __device__ bool cleanupItd(const RidgeDev &d, int ncat, int cell, RidgeCell<NC> 
 }
 
 template <int NC>
-__global__ void __launch_bounds__(128) k_ridge_ice(RidgeDev d)
+__global__ void __launch_bounds__(RIDGE_BLOCK) k_ridge_ice(RidgeDev d)
 {
+    __shared__ double fracStore[2 * NC * NC * RIDGE_BLOCK];
+    RidgeLdsDouble *frac = (RidgeLdsDouble *)fracStore + threadIdx.x;
     const int cell = blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= d.nCellsSolve) return;
     const int ncat = d.ncat, P = d.padC;
     RidgeCell<NC> s;
-    for (int n = 1; n <= ncat; n++) {
+    FORCAT(n) {
         s.aicen[n] = d.aicen[(size_t)(n - 1) * P + cell];
         s.vicen[n] = d.vicen[(size_t)(n - 1) * P + cell];
         s.vsnon[n] = d.vsnon[(size_t)(n - 1) * P + cell];
@@ -555,7 +597,7 @@ __global__ void __launch_bounds__(128) k_ridge_ice(RidgeDev d)
     double msnow_mlt = 0.0, esnow_mlt = 0.0, ardg1 = 0.0, ardg2 = 0.0, virdg = 0.0, aopen = 0.0;
     // asum_ridging :609-632, ridge_prep :640-722
     double asum = aice0;
-    for (int n = 1; n <= ncat; n++) asum = asum + s.aicen[n];
+    FORCAT(n) asum = asum + s.aicen[n];
     double closing_net = RDG_CS * d.rdgShear[cell] + d.rdgConv[cell];
     double divu_adv = (1.0 - asum) / dt;
     if (divu_adv < 0.0) closing_net = fmax(closing_net, -divu_adv);
@@ -566,10 +608,10 @@ __global__ void __launch_bounds__(128) k_ridge_ice(RidgeDev d)
         double aksum;
         ridgeItd<NC>(d, ncat, aice0, s, aksum);
         stop = ridgeShift<NC>(d, ncat, cell, s, aice0, aksum, closing_net, opning, ardg1, ardg2, virdg, aopen, msnow_mlt,
-                              esnow_mlt, Tf);
+                              esnow_mlt, Tf, frac);
         if (stop) break;
         asum = aice0;
-        for (int n = 1; n <= ncat; n++) asum = asum + s.aicen[n];
+        FORCAT(n) asum = asum + s.aicen[n];
         bool iterate;
         if (fabs(asum - 1.0) < PUNY) {
             iterate = false;
@@ -588,7 +630,7 @@ __global__ void __launch_bounds__(128) k_ridge_ice(RidgeDev d)
         }
     }
     atomicMax(&d.flag[1], niter > nitermax ? nitermax : niter);
-    for (int n = 1; n <= ncat; n++) {
+    FORCAT(n) {
         const size_t k = (size_t)(n - 1) * P + cell;
         d.aicen[k] = s.aicen[n];
         d.vicen[k] = s.vicen[n];
@@ -609,7 +651,7 @@ __global__ void __launch_bounds__(128) k_ridge_ice(RidgeDev d)
     d.dardg2dt[cell] = ardg2 * dti;
     d.dvirdgdt[cell] = virdg * dti;
     d.opening[cell] = aopen * dti;
-    for (int n = 1; n <= ncat; n++) {
+    FORCAT(n) {
         const size_t k = (size_t)(n - 1) * P + cell;
         d.dardg1ndt[k] = s.ardg1n[n] * dti;
         d.dardg2ndt[k] = s.ardg2n[n] * dti;
@@ -626,7 +668,7 @@ __global__ void __launch_bounds__(128) k_ridge_ice(RidgeDev d)
     }
     if (d.cleanup) {  // colpkg_step_ridge :3327-3354
         const bool bad = cleanupItd<NC>(d, ncat, cell, s, aice0, Tf);
-        for (int n = 1; n <= ncat; n++) {
+        FORCAT(n) {
             const size_t k = (size_t)(n - 1) * P + cell;
             d.aicen[k] = s.aicen[n];
             d.vicen[k] = s.vicen[n];
@@ -705,7 +747,13 @@ extern "C" int sih_column_ridge_init(sih_ctx *c, int nCategories)
     }
     HIPCHK(hipSetDevice(c->device));
     RidgeDev d{};
-    return ridgeFields(c, nCategories, d);
+    int rc = ridgeFields(c, nCategories, d);
+    // what sih_column_update_state and sih_column_reinitialize_diagnostics work on besides
+    static const char *more[] = {"iceVolumeCell", "snowVolumeCell", "iceAreaTendencyTransport", "iceVolumeTendencyTransport",
+                                 "iceAgeTendencyTransport"};
+    double *p = nullptr;
+    for (size_t i = 0; !rc && i < sizeof more / sizeof more[0]; i++) rc = fieldPtr(c, more[i], LOC_CELL, 1, &p);
+    return rc;
 }
 
 extern "C" int sih_column_ridge(sih_ctx *c, const sih_ridge_config *cfg)
@@ -741,6 +789,7 @@ extern "C" int sih_column_ridge(sih_ctx *c, const sih_ridge_config *cfg)
         sih_set_error("sih_column_ridge: the tracer list must hold iceVolumeCategory and snowVolumeCategory on the ice area");
         return SIH_ERR_ARG;
     }
+    std::vector<RidgeTracer> hostTr;
     d.ntTsfc = -1;
     d.ntQsno = -1;
     d.nslyr = 0;
@@ -769,7 +818,8 @@ extern "C" int sih_column_ridge(sih_ctx *c, const sih_ridge_config *cfg)
             d.ntQsno = nt;
             d.nslyr = tr[i].L;
         }
-        for (int l = 0; l < tr[i].L; l++) d.tr[nt++] = RidgeTracer{tr[i].val, tr[i].L, l, dep};
+        for (int l = 0; l < tr[i].L; l++) hostTr.push_back(RidgeTracer{tr[i].val, tr[i].L, l, dep});
+        nt += tr[i].L;
     }
     d.ntrcr = nt;
     d.ncat = nCat;
@@ -790,6 +840,14 @@ extern "C" int sih_column_ridge(sih_ctx *c, const sih_ridge_config *cfg)
     if (!c->ridge) c->ridge = new sih_ridge_state();
     sih_ridge_state *rs = c->ridge;
     if (!rs->d_flag) HIPCHK(hipMalloc(&rs->d_flag, 2 * sizeof(int)));
+    if (!rs->d_tr) HIPCHK(hipMalloc(&rs->d_tr, RIDGE_MAXTR * sizeof(RidgeTracer)));
+    if (rs->hostTr.size() != hostTr.size() ||
+        (nt > 0 && memcmp(rs->hostTr.data(), hostTr.data(), hostTr.size() * sizeof(RidgeTracer)) != 0)) {
+        HIPCHK(hipStreamSynchronize(c->stream));  // a launch still reading the old table
+        if (nt > 0) HIPCHK(hipMemcpy(rs->d_tr, hostTr.data(), hostTr.size() * sizeof(RidgeTracer), hipMemcpyHostToDevice));
+        rs->hostTr = hostTr;
+    }
+    d.tr = rs->d_tr;
     if (rs->planes != nt * nCat) {
         const std::string name = "_ridgeProducts" + std::to_string(nt * nCat);
         if ((rc = fieldPtr(c, name.c_str(), LOC_CELL, nt * nCat, &rs->atrcrn))) return rc;
@@ -798,7 +856,7 @@ extern "C" int sih_column_ridge(sih_ctx *c, const sih_ridge_config *cfg)
     d.atrcrn = rs->atrcrn;
     d.flag = rs->d_flag;
     hipLaunchKernelGGL(k_ridge_zero_flags, dim3(1), dim3(64), 0, c->stream, d.flag);
-    const dim3 grid((unsigned)((d.nCellsSolve + 127) / 128)), block(128);
+    const dim3 grid((unsigned)((d.nCellsSolve + RIDGE_BLOCK - 1) / RIDGE_BLOCK)), block(RIDGE_BLOCK);
     if (nCat <= 5)
         hipLaunchKernelGGL(k_ridge_ice<5>, grid, block, 0, c->stream, d);
     else
@@ -816,6 +874,188 @@ extern "C" int sih_column_ridge(sih_ctx *c, const sih_ridge_config *cfg)
                                       : "ice: ITD cleanup error in colpkg_step_ridge");
         return SIH_ERR_COLUMN;
     }
+    return SIH_OK;
+}
+
+// ---- seaice_column_update_state (src/shared/mpas_seaice_column.F:4279-4377) -------------------------------------
+// seaice_column_aggregate (:4391-4494) calls colpkg_aggregate (src/column/ice_colpkg.F90:3366-3480) for every owned
+// cell: sums of the category areas and volumes, the open water, and the cell value of every category tracer
+// (colpkg_compute_tracers on the sums of tracer * base quantity); then the transport tendencies (:4352-4355).
+// One thread per owned cell on the planes the ridging left.
+struct AggTracer {
+    const double *val;  // plane 0 of the category field
+    double *cell;       // plane 0 of the cell field (<name>Cell)
+    int L, layer, depend, isTsfc;
+};
+struct AggDev {
+    int nCellsSolve, padC, ncat, ntrcr, tendencies;
+    double dt;
+    const double *aicen, *vicen, *vsnon, *Tf;
+    double *aice, *vice, *vsno, *aice0, *tendA, *tendV;
+    AggTracer tr[RIDGE_MAXTR];
+};
+
+template <int NC>
+__global__ void __launch_bounds__(256) k_column_aggregate(AggDev d)
+{
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= d.nCellsSolve) return;
+    const int ncat = d.ncat;
+    const size_t P = d.padC;
+    double a[NC], v[NC], s[NC];
+    double aice = 0.0, vice = 0.0, vsno = 0.0;
+    _Pragma("unroll") for (int n = 0; n < NC; n++) if (n < ncat) {
+        a[n] = d.aicen[n * P + cell];
+        v[n] = d.vicen[n * P + cell];
+        s[n] = d.vsnon[n * P + cell];
+        aice = aice + a[n];
+        vice = vice + v[n];
+        vsno = vsno + s[n];
+    }
+    d.aice[cell] = aice;
+    d.vice[cell] = vice;
+    d.vsno[cell] = vsno;
+    d.aice0[cell] = fmax(1.0 - aice, 0.0);
+    const double Tf = d.Tf[cell];
+    for (int it = 0; it < d.ntrcr; it++) {
+        const AggTracer t = d.tr[it];
+        const double b1 = t.depend == 0 ? 1.0 : 0.0, b2 = t.depend == 1 ? 1.0 : 0.0, b3 = t.depend == 2 ? 1.0 : 0.0;
+        double atrcr = 0.0;
+        _Pragma("unroll") for (int n = 0; n < NC; n++) if (n < ncat) {
+            const double atrcrn = t.val[((size_t)n * t.L + t.layer) * P + cell] * (b1 * a[n] + b2 * v[n] + b3 * s[n]);
+            atrcr = atrcr + atrcrn;
+        }
+        double out;  // colpkg_compute_tracers, ice_colpkg_tracers.F90:163-254, trcr_base the unit vector of the base
+        if (t.depend == 0) {
+            if (aice > PUNY)
+                out = atrcr / aice;
+            else
+                out = t.isTsfc ? Tf : 0.0;
+        } else {
+            const double divisor = t.depend == 1 ? vice : vsno;
+            out = divisor > 0.0 ? atrcr / divisor : 0.0;
+        }
+        t.cell[(size_t)t.layer * P + cell] = out;
+    }
+    if (d.tendencies) {  // :4352-4355, stateUpdateType "transport"
+        d.tendA[cell] = (aice - d.tendA[cell]) / d.dt;
+        d.tendV[cell] = (vice - d.tendV[cell]) / d.dt;
+    }
+}
+
+// seaice_column_reinitialize_diagnostics_dynamics (:13680-13718), the fields of this path: whole arrays
+__global__ void k_column_reinit_diagnostics(int n, double *r0, double *r1, double *r2, double *r3, const double *aice,
+                                            const double *vice, double *tendA, double *tendV, double *tendAge)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    r0[i] = 0.0;
+    r1[i] = 0.0;
+    r2[i] = 0.0;
+    r3[i] = 0.0;
+    tendA[i] = aice[i];
+    tendV[i] = vice[i];
+    tendAge[i] = 0.0;
+}
+
+static int aggregateSetup(sih_ctx *c, const char *who, int nCategories, AggDev &d)
+{
+    std::vector<SihTracerInfo> tr;
+    int nCat = 0;
+    if (!sih_ir_tracer_table(c, tr, &nCat)) {
+        sih_set_error(std::string(who) + ": the tracer list is not set (sih_ir_init, sih_ir_set_tracers)");
+        return SIH_ERR_STATE;
+    }
+    if (nCategories != nCat || nCat < 1 || nCat > RIDGE_MAXCAT) {
+        sih_set_error(std::string(who) + ": nCategories must be that of the tracers, at most 10");
+        return SIH_ERR_ARG;
+    }
+    int iVol = -1, iSnow = -1;
+    for (size_t i = 0; i < tr.size(); i++) {
+        if (tr[i].name == "iceVolumeCategory") iVol = (int)i;
+        if (tr[i].name == "snowVolumeCategory") iSnow = (int)i;
+    }
+    if (iVol < 0 || iSnow < 0 || tr[0].L != 1 || tr[iVol].L != 1 || tr[iSnow].L != 1 || tr[iVol].parent != 0 ||
+        tr[iSnow].parent != 0) {
+        sih_set_error(std::string(who) + ": the tracer list must hold iceVolumeCategory and snowVolumeCategory on the ice area");
+        return SIH_ERR_ARG;
+    }
+    int rc, nt = 0;
+    for (size_t i = 1; i < tr.size(); i++) {
+        if ((int)i == iVol || (int)i == iSnow) continue;
+        const int dep = tr[i].parent == 0 ? 0 : tr[i].parent == iVol ? 1 : tr[i].parent == iSnow ? 2 : -1;
+        if (dep < 0) {
+            sih_set_error(std::string(who) + ": tracer " + tr[i].name +
+                          " is carried on another tracer (strata: ponds, brine, level ice, aerosols): not supported");
+            return SIH_ERR_UNSUPPORTED;
+        }
+        if (nt + tr[i].L > RIDGE_MAXTR) {
+            sih_set_error(std::string(who) + ": too many tracer layers");
+            return SIH_ERR_UNSUPPORTED;
+        }
+        double *cell = nullptr;  // the cell field of the `tracers_aggregate` pool: <tracer>Cell, the tracer's layers deep
+        if ((rc = fieldPtr(c, (tr[i].name + "Cell").c_str(), LOC_CELL, tr[i].L, &cell))) return rc;
+        for (int l = 0; l < tr[i].L; l++)
+            d.tr[nt++] = AggTracer{tr[i].val, cell, tr[i].L, l, dep, tr[i].name == "surfaceTemperature" ? 1 : 0};
+    }
+    d.ntrcr = nt;
+    d.ncat = nCat;
+    d.nCellsSolve = c->nCellsSolve;
+    d.padC = c->padC;
+    d.aicen = tr[0].val;
+    d.vicen = tr[iVol].val;
+    d.vsnon = tr[iSnow].val;
+    double *p = nullptr;
+    if ((rc = fieldPtr(c, "seaFreezingTemperature", LOC_CELL, 1, &p))) return rc;
+    d.Tf = p;
+    if ((rc = fieldPtr(c, "iceAreaCell", LOC_CELL, 1, &d.aice))) return rc;
+    if ((rc = fieldPtr(c, "iceVolumeCell", LOC_CELL, 1, &d.vice))) return rc;
+    if ((rc = fieldPtr(c, "snowVolumeCell", LOC_CELL, 1, &d.vsno))) return rc;
+    if ((rc = fieldPtr(c, "openWaterArea", LOC_CELL, 1, &d.aice0))) return rc;
+    if ((rc = fieldPtr(c, "iceAreaTendencyTransport", LOC_CELL, 1, &d.tendA))) return rc;
+    if ((rc = fieldPtr(c, "iceVolumeTendencyTransport", LOC_CELL, 1, &d.tendV))) return rc;
+    return SIH_OK;
+}
+
+extern "C" int sih_column_update_state(sih_ctx *c, int nCategories, double dt, int tendencies)
+{
+    if (!c || (tendencies && !(dt > 0.0))) {
+        sih_set_error("sih_column_update_state: bad argument");
+        return SIH_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    AggDev d{};
+    int rc;
+    if ((rc = aggregateSetup(c, "sih_column_update_state", nCategories, d))) return rc;
+    d.dt = dt;
+    d.tendencies = tendencies != 0;
+    const dim3 grid((unsigned)((d.nCellsSolve + 255) / 256)), block(256);
+    if (d.ncat <= 5)
+        hipLaunchKernelGGL(k_column_aggregate<5>, grid, block, 0, c->stream, d);
+    else
+        hipLaunchKernelGGL(k_column_aggregate<RIDGE_MAXCAT>, grid, block, 0, c->stream, d);
+    HIPCHK(hipGetLastError());
+    return SIH_OK;
+}
+
+extern "C" int sih_column_reinitialize_diagnostics(sih_ctx *c, int nCategories)
+{
+    if (!c) {
+        sih_set_error("sih_column_reinitialize_diagnostics: null argument");
+        return SIH_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    AggDev d{};
+    RidgeDev r{};
+    int rc;
+    if ((rc = aggregateSetup(c, "sih_column_reinitialize_diagnostics", nCategories, d))) return rc;
+    if ((rc = ridgeFields(c, nCategories, r))) return rc;
+    double *age = nullptr;
+    if ((rc = fieldPtr(c, "iceAgeTendencyTransport", LOC_CELL, 1, &age))) return rc;
+    const int n = c->nCells + 1;
+    hipLaunchKernelGGL(k_column_reinit_diagnostics, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, r.dardg1dt,
+                       r.dardg2dt, r.dvirdgdt, r.opening, d.aice, d.vice, d.tendA, d.tendV, age);
+    HIPCHK(hipGetLastError());
     return SIH_OK;
 }
 

@@ -92,7 +92,7 @@ EXPORTS = [
     "sih_halo_exchange", "sih_halo_exchange_start", "sih_halo_exchange_finish", "sih_comm_set_timeout",
     "sih_comm_status", "sih_evp_subcycle_exchange", "sih_field_get_noalloc", "sih_device_count", "sih_evp_subcycle_persistent", "sih_evp_subcycle_fused", "sih_column_get", "sih_column_put", "sih_evp_set_persistent",
     "sih_fields_get_start", "sih_fields_get_finish", "sih_evp_run_early_outputs",
-    "sih_column_ridge", "sih_column_ridge_init",
+    "sih_column_ridge", "sih_column_ridge_init", "sih_column_update_state", "sih_column_reinitialize_diagnostics",
 ]
 
 
@@ -133,6 +133,8 @@ def load():
     lib.sih_fields_get_finish.argtypes = [ctypes.c_void_p]
     lib.sih_column_ridge.argtypes = [ctypes.c_void_p, ctypes.POINTER(RidgeConfig)]
     lib.sih_column_ridge_init.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.sih_column_update_state.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_int]
+    lib.sih_column_reinitialize_diagnostics.argtypes = [ctypes.c_void_p, ctypes.c_int]
     for fn in (lib.sih_fields_put, lib.sih_fields_get, lib.sih_fields_get_start, lib.sih_evp_run_early_outputs):
         fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
                        ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
@@ -529,6 +531,16 @@ class BlockContext:
         cfg = RidgeConfig(float(dt), int(ndtd), int(participation), int(redistribution), float(efolding_scale),
                           int(lim.size - 1), lim.ctypes.data, 1 if cleanup else 0)
         check(self._lib.sih_column_ridge(self.handle, ctypes.byref(cfg)), "sih_column_ridge")
+
+    def column_update_state(self, nCategories, dt, tendencies=True):
+        """sih_column_update_state: the aggregate state of every owned cell (colpkg_aggregate) and, with
+        ``tendencies``, the transport tendencies"""
+        check(self._lib.sih_column_update_state(self.handle, int(nCategories), float(dt), 1 if tendencies else 0),
+              "sih_column_update_state")
+
+    def column_reinitialize_diagnostics(self, nCategories):
+        check(self._lib.sih_column_reinitialize_diagnostics(self.handle, int(nCategories)),
+              "sih_column_reinitialize_diagnostics")
 
     def ir_unpack_reconstruction(self):
         check(self._lib.sih_ir_unpack_reconstruction(self.handle), "sih_ir_unpack_reconstruction")

@@ -230,6 +230,9 @@ def category_thickness_limits(nCategories):
     return h
 
 
+TRANSPORT_TENDENCY_FIELDS = ("iceAreaTendencyTransport", "iceVolumeTendencyTransport", "iceAgeTendencyTransport")
+
+
 def allocate_ridging_pools(block):
     """What column_ridging reaches beyond the tracers (/root/reference/src/shared/mpas_seaice_column.F:3418-3456): the
     diagnostics of the `ridging` pool (Registry dims nCells or nCategories x nCells), the ocean fluxes the ridging adds
@@ -249,6 +252,16 @@ def allocate_ridging_pools(block):
     block.structs["biogeochemistry"] = {"newlyFormedIce": np.zeros((nCat, nC + 1), dtype=np.int32, order="F")}
     block.structs["ocean_coupling"]["seaFreezingTemperature"] = np.full(nC + 1, -1.8)
     block.structs["initial"] = {"categoryThicknessLimits": category_thickness_limits(nCat)}
+    # what seaice_column_update_state fills after the ridging (:4279-4494): the cell values of the category tracers
+    # (`tracers_aggregate`, Registry dims nCells or layers x nCells) and the transport tendencies of `diagnostics`
+    ta = block.structs["tracers_aggregate"]
+    ta["surfaceTemperatureCell"] = np.zeros(nC + 1)
+    ta["iceEnthalpyCell"] = np.zeros((d["nIceLayers"], nC + 1), order="F")
+    ta["iceSalinityCell"] = np.zeros((d["nIceLayers"], nC + 1), order="F")
+    ta["snowEnthalpyCell"] = np.zeros((d["nSnowLayers"], nC + 1), order="F")
+    dg = block.structs.setdefault("diagnostics", {})
+    for k in TRANSPORT_TENDENCY_FIELDS:
+        dg[k] = np.zeros(nC + 1)
 
 
 class Domain:

@@ -47,6 +47,9 @@ def _timestep_dynamics_on_device(domain):
         n = int(cfg["config_dynamics_subcycle_number"])
         for i in range(n):
             last = i == n - 1
+            # :142: ridging rates to zero, transport tendencies from the aggregate state; the first time on the pools
+            # (they go up with the cell fields of the first ridging), later on what the device holds
+            column.seaice_column_reinitialize_diagnostics_dynamics(domain, on_device=(i > 0))
             vs.seaice_run_velocity_solver(domain, tracers_on_device=(i > 0))
             if cfg.get("config_use_advection", True):
                 adv.seaice_run_advection(domain, upload=(i == 0), download=False)

@@ -101,3 +101,83 @@ def column_ridging(domain, cleanup=True):
             b.structs["tracers_aggregate"]["iceAreaCell"][:nCS] = aice
             b.structs["ocean_fluxes"]["oceanSaltFlux"][:nCS] = fsalt
             b.structs["biogeochemistry"]["newlyFormedIce"][:, :nCS] = first.T   # 1 where the logical came back true
+
+
+def column_aggregate(domain):
+    """seaice_column_aggregate (:4391-4494): colpkg_aggregate for every owned cell; the cell values of the physics
+    tracers go to the `tracers_aggregate` pool (get_cice_physics_tracer_array_cell :7007-7183)."""
+    lib = evp_flow.lib()
+    for b in domain.blocklist:
+        pools.allocate_ridging_pools(b)
+        d = b.dimensions
+        nCS, nCat = d["nCellsSolve"], d["nCategories"]
+        tr, ta = b.structs["tracers"], b.structs["tracers_aggregate"]
+        entries, nt_Tsfc, _ = tracer_layout(b)
+        ntrcr = len(entries)
+        depend = np.array([e[2] for e in entries], dtype=np.int32)
+        trcrn = np.zeros((nCS, nCat, ntrcr))
+        for it, (name, layer, _) in enumerate(entries):
+            trcrn[:, :, it] = tr[name][layer, :, :nCS].T
+        aicen = np.ascontiguousarray(tr["iceAreaCategory"][0, :, :nCS].T)
+        vicen = np.ascontiguousarray(tr["iceVolumeCategory"][0, :, :nCS].T)
+        vsnon = np.ascontiguousarray(tr["snowVolumeCategory"][0, :, :nCS].T)
+        aice, vice, vsno, aice0 = (np.zeros(nCS) for _ in range(4))
+        trcr = np.zeros((nCS, ntrcr))
+        Tf = np.ascontiguousarray(b.structs["ocean_coupling"]["seaFreezingTemperature"][:nCS])
+
+        def P(a):
+            return ctypes.c_void_p(a.ctypes.data)
+        lib.ora_aggregate_cells.restype = None
+        lib.ora_aggregate_cells(ctypes.c_int(nCS), ctypes.c_int(nCat), ctypes.c_int(ntrcr), P(Tf), P(aicen), P(trcrn),
+                                P(vicen), P(vsnon), P(aice), P(trcr), P(vice), P(vsno), P(aice0), P(depend),
+                                ctypes.c_int(nt_Tsfc))
+        ta["iceAreaCell"][:nCS] = aice
+        ta["iceVolumeCell"][:nCS] = vice
+        ta["snowVolumeCell"][:nCS] = vsno
+        b.structs["icestate"]["openWaterArea"][:nCS] = aice0
+        for it, (name, layer, _) in enumerate(entries):
+            cell = ta[name + "Cell"]
+            if cell.ndim == 1:
+                cell[:nCS] = trcr[:, it]
+            else:
+                cell[layer, :nCS] = trcr[:, it]
+
+
+def column_update_state(domain, stateUpdateType, dt, iceAgeTimeOffset=0.0):
+    """seaice_column_update_state (:4279-4377) without the ice age (config_use_ice_age false)."""
+    column_aggregate(domain)
+    if stateUpdateType != "transport":
+        raise RuntimeError("seaice_column_update_state: Unknown update type: " + stateUpdateType)
+    for b in domain.blocklist:
+        nCS = b.dimensions["nCellsSolve"]
+        ta, dg = b.structs["tracers_aggregate"], b.structs["diagnostics"]
+        dg["iceAreaTendencyTransport"][:nCS] = (ta["iceAreaCell"][:nCS] - dg["iceAreaTendencyTransport"][:nCS]) / dt
+        dg["iceVolumeTendencyTransport"][:nCS] = (ta["iceVolumeCell"][:nCS] - dg["iceVolumeTendencyTransport"][:nCS]) / dt
+
+
+def column_reinitialize_diagnostics_dynamics(domain):
+    """seaice_column_reinitialize_diagnostics_dynamics (:13569-13723), the part this path's fields belong to: the
+    ridging rates back to zero, the transport tendencies set to the aggregate state before the dynamics (whole
+    arrays).  The velocity solver's own diagnostics it zeroes as well are set by the velocity solver's pre-cycle."""
+    if not domain.configs["config_use_column_package"]:
+        return
+    for b in domain.blocklist:
+        pools.allocate_ridging_pools(b)
+        rg, ta, dg = b.structs["ridging"], b.structs["tracers_aggregate"], b.structs["diagnostics"]
+        for k in pools.RIDGING_CELL_FIELDS:
+            rg[k][:] = 0.0
+        dg["iceAreaTendencyTransport"][:] = ta["iceAreaCell"]
+        dg["iceVolumeTendencyTransport"][:] = ta["iceVolumeCell"]
+        dg["iceAgeTendencyTransport"][:] = 0.0
+
+
+def column_dynamics_time_integration(domain, cleanup=True):
+    """seaice_column_dynamics_time_integration (:1139-1194): ridging, then the aggregate state and the transport
+    tendencies (column_combine_snow_ice_tracers belongs to config_use_vertical_tracers, outside this path)."""
+    cfg = domain.configs
+    if not cfg["config_use_column_package"]:
+        return
+    if cfg.get("config_use_column_ridging", True):
+        column_ridging(domain, cleanup=cleanup)
+    dt = float(domain.blocklist[0].structs["velocity_solver"]["dynamicsTimeStep"][0])
+    column_update_state(domain, "transport", dt, 0.0)

@@ -18,6 +18,7 @@
  * :430-503) is not run. */
 #include <math.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include <string.h>
 
 #define MAXCAT 16
@@ -665,4 +666,36 @@ int ora_ridge_cells(int nCells, double dt, int ndtd, int ncat, int nslyr, int nt
         if (stop[c] && !first) first = stop[c];
     }
     return first;
+}
+
+/* colpkg_aggregate, ice_colpkg.F90:3366-3480, for tracers without strata (trcr_base(it,:) the unit vector of
+ * trcr_depend(it)), over records as above: trcr[c * ntrcr + it] receives the cell values.  This is what
+ * seaice_column_aggregate (mpas_seaice_column.F:4391-4494) calls for every owned cell. */
+void ora_aggregate_cells(int nCells, int ncat, int ntrcr, const double *Tf, const double *aicen, const double *trcrn,
+                         const double *vicen, const double *vsnon, double *aice, double *trcr, double *vice, double *vsno,
+                         double *aice0, const int *trcr_depend, int nt_Tsfc)
+{
+    double *atrcr = (double *)malloc(sizeof(double) * (size_t)(ntrcr > 0 ? ntrcr : 1));
+    for (int c = 0; c < nCells; c++) {
+        const size_t k = (size_t)c * ncat;
+        double a = c0, v = c0, s = c0;
+        for (int it = 0; it < ntrcr; it++) atrcr[it] = c0;
+        for (int n = 0; n < ncat; n++) {
+            a = a + aicen[k + n];
+            v = v + vicen[k + n];
+            s = s + vsnon[k + n];
+            for (int it = 0; it < ntrcr; it++) {
+                const double b1 = trcr_depend[it] == 0 ? c1 : c0, b2 = trcr_depend[it] == 1 ? c1 : c0,
+                             b3 = trcr_depend[it] == 2 ? c1 : c0;
+                const double atrcrn = trcrn[(k + n) * ntrcr + it] * (b1 * aicen[k + n] + b2 * vicen[k + n] + b3 * vsnon[k + n]);
+                atrcr[it] = atrcr[it] + atrcrn;
+            }
+        }
+        aice[c] = a;
+        vice[c] = v;
+        vsno[c] = s;
+        aice0[c] = (c1 - a) > c0 ? (c1 - a) : c0;
+        compute_tracers(ntrcr, trcr_depend, atrcr, a, v, s, nt_Tsfc, Tf[c], trcr + (size_t)c * ntrcr);
+    }
+    free(atrcr);
 }

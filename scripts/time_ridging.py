@@ -1,4 +1,4 @@
-"""Wall time of sih_column_ridge (launch, kernel and the read of its status word) on a named mesh after one velocity
+"""Wall time of sih_column_ridge (launch, kernel and the read of its status word) and of sih_column_update_state on a named mesh after one velocity
 solve and advection; prints one JSON line.  Usage: python scripts/time_ridging.py [mesh] [reps]"""
 import json
 import sys
@@ -28,7 +28,17 @@ try:
         column.column_ridging(dom, upload=False, download=False)
         t.append(time.perf_counter() - t0)
     t.sort()
+    column.seaice_column_update_state(dom, download=False)
+    b.ctx.sync()
+    u = []
+    for _ in range(reps):   # seaice_column_update_state (asynchronous: timed with the wait for the stream)
+        t0 = time.perf_counter()
+        column.seaice_column_update_state(dom, download=False)
+        b.ctx.sync()
+        u.append(time.perf_counter() - t0)
+    u.sort()
     print(json.dumps({"mesh": name, "nCells": int(nC), "ridging_ms_median": 1e3 * t[len(t) // 2], "ridging_ms_min": 1e3 * t[0],
-                      "iterations": dom.solver_state["ridge_iterations"]}))
+                      "iterations": dom.solver_state["ridge_iterations"], "update_state_ms_median": 1e3 * u[len(u) // 2],
+                      "update_state_ms_min": 1e3 * u[0]}))
 finally:
     vs.seaice_mesh_pool_destroy(dom)

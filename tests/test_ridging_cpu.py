@@ -208,3 +208,40 @@ def test_cleanup_zaps_snow_that_is_too_warm():
     assert np.all(tr["snowVolumeCategory"][0, 1, cells] == 0.0) and np.all(tr["snowEnthalpy"][0, 1, cells] == 0.0)
     assert np.array_equal(tr["iceAreaCategory"][0, 1, cells], a0)
     assert np.allclose(b.structs["ocean_fluxes"]["oceanFreshWaterFlux"][cells] - f0, 330.0 * vs0 / dtt, rtol=1e-12)
+
+
+def test_aggregate_and_transport_tendencies():
+    """seaice_column_update_state in the oracle: sums over the categories, open water, cell values as means weighted
+    with each tracer's base quantity, the freezing temperature where there is no ice, tendencies (new - old) / dt."""
+    _, dom, b = _domain("exponential", "exponential")
+    nC = b.dimensions["nCells"]
+    tr, ta, dg = b.structs["tracers"], b.structs["tracers_aggregate"], b.structs["diagnostics"]
+    for k in ("iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory"):
+        tr[k][0, :, :40] = 0.0     # cells without ice
+    tr["snowVolumeCategory"][0, :, 40:80] = 0.0   # ice without snow
+    dg["iceAreaTendencyTransport"][:nC] = 0.25
+    dg["iceVolumeTendencyTransport"][:nC] = 0.75
+    Tf = b.structs["ocean_coupling"]["seaFreezingTemperature"]
+    ridge_flow.column_update_state(dom, "transport", 900.0)
+    a, v, s = (tr[k][0, :, :nC] for k in ("iceAreaCategory", "iceVolumeCategory", "snowVolumeCategory"))
+    assert np.allclose(ta["iceAreaCell"][:nC], a.sum(axis=0), rtol=1e-15, atol=0)
+    assert np.allclose(ta["iceVolumeCell"][:nC], v.sum(axis=0), rtol=1e-15, atol=0)
+    assert np.allclose(ta["snowVolumeCell"][:nC], s.sum(axis=0), rtol=1e-15, atol=0)
+    assert np.allclose(b.structs["icestate"]["openWaterArea"][:nC], np.maximum(1.0 - a.sum(axis=0), 0.0), rtol=1e-15, atol=0)
+    ice = a.sum(axis=0) > 1e-11
+    mean = (tr["surfaceTemperature"][0, :, :nC] * a).sum(axis=0)[ice] / a.sum(axis=0)[ice]
+    assert np.allclose(ta["surfaceTemperatureCell"][:nC][ice], mean, rtol=1e-14, atol=0)
+    assert np.array_equal(ta["surfaceTemperatureCell"][:40], Tf[:40])
+    for l in range(b.dimensions["nIceLayers"]):
+        mean = (tr["iceEnthalpy"][l, :, :nC] * v).sum(axis=0)[ice] / v.sum(axis=0)[ice]
+        assert np.allclose(ta["iceEnthalpyCell"][l, :nC][ice], mean, rtol=1e-14, atol=0)
+        assert not ta["iceEnthalpyCell"][l, :40].any() and not ta["iceSalinityCell"][l, :40].any()
+    snow = s.sum(axis=0) > 0.0
+    mean = (tr["snowEnthalpy"][0, :, :nC] * s).sum(axis=0)[snow] / s.sum(axis=0)[snow]
+    assert np.allclose(ta["snowEnthalpyCell"][0, :nC][snow], mean, rtol=1e-14, atol=0)
+    assert not ta["snowEnthalpyCell"][0, :80].any()
+    assert np.array_equal(dg["iceAreaTendencyTransport"][:nC], (ta["iceAreaCell"][:nC] - 0.25) / 900.0)
+    assert np.array_equal(dg["iceVolumeTendencyTransport"][:nC], (ta["iceVolumeCell"][:nC] - 0.75) / 900.0)
+    dom.configs["config_use_column_package"] = True
+    ridge_flow.column_reinitialize_diagnostics_dynamics(dom)
+    assert np.array_equal(dg["iceAreaTendencyTransport"], ta["iceAreaCell"]) and not b.structs["ridging"]["areaLossRidge"].any()

@@ -53,6 +53,15 @@ def _compare(dom, ref, nC):
     return worst
 
 
+def _compare_aggregate(dom, ref, nC):
+    """what seaice_column_update_state leaves: aggregate state, cell values of the tracers, transport tendencies"""
+    b, r = dom.blocklist[0], ref.blocklist[0]
+    pairs = list(column.AGGREGATE_FIELDS) + [("tracers_aggregate", n + "Cell") for n in column.AGGREGATED_TRACERS]
+    for pool, name in pairs:
+        e = rel_linf(b.structs[pool][name][..., :nC], r.structs[pool][name][..., :nC])
+        assert e <= TOL, (pool, name, e)
+
+
 @pytest.mark.parametrize("part,redist", [("exponential", "exponential"), ("Thorndike75", "Hibler80")])
 def test_ridging_after_velocity_solver_and_advection_matches_oracle(oracle, part, redist):
     """QU240: the idealised forcing gives converging and shearing regions (ridgeConvergence, ridgeShear of the velocity
@@ -127,9 +136,10 @@ def test_dynamics_step_with_the_ridging_on_the_device_keeps_the_tracers_there(or
     oracle.seaice_init_velocity_solver(ref)
     ir_flow.seaice_init_advection(ref)
     for _ in range(2):
+        ridge_flow.column_reinitialize_diagnostics_dynamics(ref)
         oracle.seaice_run_velocity_solver(ref)
         ir_flow.seaice_run_advection(ref)
-        ridge_flow.column_ridging(ref)
+        ridge_flow.column_dynamics_time_integration(ref)
     dom = _make(mesh, "QU240", extra)
     vs.seaice_mesh_pool_create(dom)
     try:
@@ -140,6 +150,9 @@ def test_dynamics_step_with_the_ridging_on_the_device_keeps_the_tracers_there(or
         vs.seaice_mesh_pool_destroy(dom)
     nC, nV = mesh.nCells, mesh.nVertices
     _compare(dom, ref, nC)
+    _compare_aggregate(dom, ref, nC)
+    tend = dom.blocklist[0].structs["diagnostics"]["iceVolumeTendencyTransport"][:nC]
+    assert np.abs(tend).max() > 0.0   # the second subcycle's change of the cell's ice volume per second
     for k in ("uVelocity", "vVelocity"):
         e = rel_linf(dom.blocklist[0].structs["velocity_solver"][k][:nV], ref.blocklist[0].structs["velocity_solver"][k][:nV])
         assert e <= TOL, (k, e)
@@ -262,3 +275,37 @@ def test_ridge_ice_alone_without_the_cleanup_matches_oracle():
     finally:
         vs.seaice_mesh_pool_destroy(dom)
     _compare(dom, ref, mesh.nCells)
+
+
+def test_update_state_alone_matches_oracle_bit_for_bit():
+    """seaice_column_update_state on its own (no ridging) from the pools: sums in category order, one division per
+    tracer -- nothing that may differ between host and device, so the comparison is exact.  The open-water band has
+    cells without ice: their surface temperature is the freezing temperature, their other cell values zero."""
+    mesh = get_mesh("QU240")
+    extra = {"config_use_column_ridging": False}
+    ref = _make(mesh, "QU240", extra)
+    dom = _make(mesh, "QU240", extra)
+    nC = mesh.nCells
+    for d in (ref, dom):
+        b = d.blocklist[0]
+        b.structs["velocity_solver"]["dynamicsTimeStep"][0] = 900.0   # (set by the velocity solver's initialisation)
+        b.structs["diagnostics"]["iceAreaTendencyTransport"][:nC] = 0.5
+        b.structs["diagnostics"]["iceVolumeTendencyTransport"][:nC] = 1.0
+        b.structs["ocean_coupling"]["seaFreezingTemperature"][:nC] = -1.8 + 0.1 * np.cos(np.arange(nC))
+    ridge_flow.column_dynamics_time_integration(ref)
+    vs.seaice_mesh_pool_create(dom)
+    try:
+        adv.seaice_init_advection(dom)   # the tracer list
+        column.seaice_column_dynamics_time_integration(dom, upload=True, download=True)
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+    b, r = dom.blocklist[0], ref.blocklist[0]
+    for pool, name in list(column.AGGREGATE_FIELDS) + [("tracers_aggregate", n + "Cell") for n in column.AGGREGATED_TRACERS]:
+        assert np.array_equal(b.structs[pool][name][..., :nC], r.structs[pool][name][..., :nC]), (pool, name)
+    ta = b.structs["tracers_aggregate"]
+    empty = ta["iceAreaCell"][:nC] == 0.0
+    assert empty.sum() > 50
+    assert np.array_equal(ta["surfaceTemperatureCell"][:nC][empty], b.structs["ocean_coupling"]["seaFreezingTemperature"][:nC][empty])
+    assert not ta["iceEnthalpyCell"][:, :nC][:, empty].any() and ta["iceEnthalpyCell"][:, :nC][:, ~empty].min() < 0.0
+    dt = float(b.structs["velocity_solver"]["dynamicsTimeStep"][0])
+    assert np.array_equal(b.structs["diagnostics"]["iceAreaTendencyTransport"][:nC], (ta["iceAreaCell"][:nC] - 0.5) / dt)
