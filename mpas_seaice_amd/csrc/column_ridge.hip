@@ -89,7 +89,7 @@ template <int NC>
 struct RidgeCell {
     double aicen[NC + 1], vicen[NC + 1], vsnon[NC + 1];
     double apartic[NC + 1], hrmin[NC + 1], hrmax[NC + 1], hrexp[NC + 1], krdg[NC + 1];
-    double ardg1n[NC + 1], ardg2n[NC + 1], virdgn[NC + 1], mraftn[NC + 1], aredistn[NC + 1], vredistn[NC + 1];
+    double ardg1n[NC + 1], ardg2n[NC + 1], virdgn[NC + 1], mraftn[NC + 1];
 };
 
 // ridge_itd :741-1012
@@ -252,6 +252,8 @@ __device__ __forceinline__ int ridgeShift(const RidgeDev &d, int ncat, int cell,
                     const double esrdgn = vsrdgn * trc(d, d.ntQsno + k - 1, n, cell) / (double)d.nslyr;
                     esnow_mlt = esnow_mlt + esrdgn * (1.0 - RDG_FSNOW);
                 }
+            double lastExpR = 0.0;
+            bool haveExp = false;
             FORCAT(nr)
             {
                 double farea, fvol, hL, hR;
@@ -266,28 +268,34 @@ __device__ __forceinline__ int ridgeShift(const RidgeDev &d, int ncat, int cell,
                     farea = (hR - hL) / dhr;
                     fvol = (hR * hR - hL * hL) / dhr2;
                 } else {
+                    // expL of this category is expR of the one before whenever that one received ice: its hR was
+                    // hinMax[nr - 1] > hi1, which is this hL, so the same expression is not evaluated twice
                     const double hi1 = s.hrmin[n], hexp = s.hrexp[n];
                     if (nr < ncat) {
                         if (hi1 >= d.hinMax[nr]) {
                             farea = 0.0;
                             fvol = 0.0;
+                            haveExp = false;
                         } else {
                             hL = fmax(hi1, d.hinMax[nr - 1]);
                             hR = d.hinMax[nr];
-                            const double expL = exp(-(hL - hi1) / hexp);
+                            const double expL = haveExp ? lastExpR : exp(-(hL - hi1) / hexp);
                             const double expR = exp(-(hR - hi1) / hexp);
                             farea = expL - expR;
                             fvol = ((hL + hexp) * expL - (hR + hexp) * expR) / (hi1 + hexp);
+                            lastExpR = expR;
+                            haveExp = true;
                         }
                     } else {
                         hL = fmax(hi1, d.hinMax[nr - 1]);
-                        const double expL = exp(-(hL - hi1) / hexp);
+                        const double expL = haveExp ? lastExpR : exp(-(hL - hi1) / hexp);
                         farea = expL;
                         fvol = (hL + hexp) * expL / (hi1 + hexp);
                     }
                     if (n == 1) {  // diagnostics of the thinnest ridging ice :1462-1469
-                        s.aredistn[nr] = farea * ardg2n;
-                        s.vredistn[nr] = fvol * virdgn;
+                        // (intent(inout) in the reference: the field keeps its value where nothing ridges)
+                        d.aredistn[(size_t)(nr - 1) * d.padC + cell] = farea * ardg2n;
+                        d.vredistn[(size_t)(nr - 1) * d.padC + cell] = fvol * virdgn;
                     }
                 }
                 s.aicen[nr] = s.aicen[nr] + farea * ardg2n;
@@ -310,26 +318,21 @@ __device__ __forceinline__ int ridgeShift(const RidgeDev &d, int ncat, int cell,
         FORCAT(n) tv[n] = tvNext[n];
         if (it + 1 < ntrcr) FORCAT(n) tvNext[n] = trc(d, it + 1, n, cell);
         FORCAT(n) at[n] = tv[n] * (b1 * aicen_init[n] + b2 * vicen_init[n] + b3 * vsnon_init[n]);
+        // The reference forms  work = 0 + f1 * tv + f2 * tv + f3 * tv  with f1 = trcr_base(it,1) * ardg2n * farea etc.
+        // (:1508-1517).  With a unit trcr_base two of the three products are zeros and the third factor is the exact
+        // ardg2n * farea (or virdgn * fvol, or vsrdgn * fvol * fsnowrdg), so 0 + f * tv has the same bits, the sign of a
+        // zero included (0 + x turns -0 into +0 as the long sum does).
         if (any) FORCAT(n)
         if (moves[n]) {
-            {
-                const double f1 = b1 * s.ardg1n[n], f2 = b2 * s.virdgn[n], f3 = b3 * vsrdgnC[n];
-                double work = 0.0;
-                work = work + f1 * tv[n];
-                work = work + f2 * tv[n];
-                work = work + f3 * tv[n];
-                at[n] = at[n] - work;
-            }
+            const double out = dep == 0 ? s.ardg1n[n] : dep == 1 ? s.virdgn[n] : vsrdgnC[n];
+            const double in = dep == 0 ? s.ardg2n[n] : dep == 1 ? s.virdgn[n] : vsrdgnC[n];
+            at[n] = at[n] - (0.0 + out * tv[n]);
             FORCAT(nr)
             {
-                const double farea = frac[((n - 1) * NC + nr - 1) * RIDGE_BLOCK],
-                             fvol = frac[(NC * NC + (n - 1) * NC + nr - 1) * RIDGE_BLOCK];
-                const double f1 = b1 * s.ardg2n[n] * farea, f2 = b2 * s.virdgn[n] * fvol, f3 = b3 * vsrdgnC[n] * fvol * RDG_FSNOW;
-                double work = 0.0;
-                work = work + f1 * tv[n];
-                work = work + f2 * tv[n];
-                work = work + f3 * tv[n];
-                at[nr] = at[nr] + work;
+                const double fr = frac[((dep == 0 ? 0 : NC * NC) + (n - 1) * NC + nr - 1) * RIDGE_BLOCK];
+                double f = in * fr;
+                if (dep == 2) f = f * RDG_FSNOW;
+                at[nr] = at[nr] + (0.0 + f * tv[n]);
             }
         }
         // colpkg_compute_tracers, ice_colpkg_tracers.F90:216-252 (no strata; the loop over the three divisors keeps the
@@ -576,7 +579,7 @@ __device__ __forceinline__ bool cleanupItd(const RidgeDev &d, int ncat, int cell
 }
 
 template <int NC>
-__global__ void __launch_bounds__(RIDGE_BLOCK) k_ridge_ice(RidgeDev d)
+__global__ void __launch_bounds__(RIDGE_BLOCK, 2) k_ridge_ice(RidgeDev d)
 {
     __shared__ double fracStore[2 * NC * NC * RIDGE_BLOCK];
     RidgeLdsDouble *frac = (RidgeLdsDouble *)fracStore + threadIdx.x;
@@ -589,8 +592,6 @@ __global__ void __launch_bounds__(RIDGE_BLOCK) k_ridge_ice(RidgeDev d)
         s.vicen[n] = d.vicen[(size_t)(n - 1) * P + cell];
         s.vsnon[n] = d.vsnon[(size_t)(n - 1) * P + cell];
         s.ardg1n[n] = s.ardg2n[n] = s.virdgn[n] = s.mraftn[n] = 0.0;
-        s.aredistn[n] = d.aredistn[(size_t)(n - 1) * P + cell];  // intent(inout): kept where nothing ridges
-        s.vredistn[n] = d.vredistn[(size_t)(n - 1) * P + cell];
     }
     double aice0 = d.aice0[cell];
     const double Tf = d.Tf[cell], dt = d.dt;
@@ -637,8 +638,6 @@ __global__ void __launch_bounds__(RIDGE_BLOCK) k_ridge_ice(RidgeDev d)
         d.vsnon[k] = s.vsnon[n];
         d.aparticn[k] = s.apartic[n];
         d.krdgn[k] = s.krdg[n];
-        d.aredistn[k] = s.aredistn[n];
-        d.vredistn[k] = s.vredistn[n];
     }
     d.aice0[cell] = aice0;
     if (!stop && fabs(asum - 1.0) > PUNY) stop = 5;  // :576 (after the diagnostics in the reference; they are set below)
@@ -859,6 +858,8 @@ extern "C" int sih_column_ridge(sih_ctx *c, const sih_ridge_config *cfg)
     const dim3 grid((unsigned)((d.nCellsSolve + RIDGE_BLOCK - 1) / RIDGE_BLOCK)), block(RIDGE_BLOCK);
     if (nCat <= 5)
         hipLaunchKernelGGL(k_ridge_ice<5>, grid, block, 0, c->stream, d);
+    else if (nCat <= 7)
+        hipLaunchKernelGGL(k_ridge_ice<7>, grid, block, 0, c->stream, d);
     else
         hipLaunchKernelGGL(k_ridge_ice<RIDGE_MAXCAT>, grid, block, 0, c->stream, d);
     HIPCHK(hipGetLastError());
