@@ -157,7 +157,12 @@ struct sih_ir_desc;
 int sih_evp_set_edge_mesh(sih_ctx *ctx, const struct sih_ir_desc *edges);
 /* replaces the per-block part of seaice_init_velocity_solver (velocity_solver.F:85-252) and
  * interior_vertices (mesh.F:423): time steps, EVP constants, metric terms, cellVerticesAtVertex,
- * local coordinates, Wachspress basis gradients/integrals, variational denominator. */
+ * local coordinates, Wachspress basis gradients/integrals, variational denominator.
+ * One deviation from the reference's bits, by default: basisIntegralsMetric(s, j), the integral of N_s N_j, which the
+ * reference rounds separately for (s, j) and (j, s) (wachspress.F:442-457), is made symmetric bit for bit by mirroring
+ * the entries with s <= j after the variational denominator has been formed (the other half changes in the last place
+ * at most), so that the subcycle kernels fetch one side of the diagonal.  SIH_METRIC_INTEGRALS=as_computed in the
+ * environment keeps all entries as computed; a host-supplied basis (variationalBasis 0) is used as it is. */
 int sih_evp_init(sih_ctx *ctx, const sih_evp_config *cfg);
 /* re-pack the static basis after the host replaced basisGradient* / basisIntegrals* with its own
  * (e.g. the piecewise-linear basis computed by the host model) */

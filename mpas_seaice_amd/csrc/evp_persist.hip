@@ -101,7 +101,7 @@ struct PersistXchg {
 // what the kernel reads of SihDev, and nothing else: the fewer scalar registers the arguments take, the more
 // vector registers are left for the state a thread keeps
 struct PersistDev {
-    int nCells, nVerticesSolve, padC, padV, relation, useOcean, quadratic, haloVertices;
+    int nCells, nVerticesSolve, padC, padV, relation, useOcean, quadratic, haloVertices, symMetric;
     double dtE, dampT, brlx, dtDyn;
     const int *nEdgesOnCell, *voc, *gidx, *vActive, *solveStress, *solveVelocity;
     const double *tanLat, *varDenom, *gradU3, *gradV3, *SU, *SV, *SM, *icePressure;
@@ -115,6 +115,7 @@ static PersistDev makePersistDev(const SihDev &d)
     PersistDev q;
     q.nCells = d.nCells; q.nVerticesSolve = d.nVerticesSolve; q.padC = d.padC; q.padV = d.padV;
     q.relation = d.relation; q.useOcean = d.useOcean; q.quadratic = d.quadratic; q.haloVertices = d.haloVertices;
+    q.symMetric = d.symMetric;
     q.dtE = d.dtE; q.dampT = d.dampT; q.brlx = d.brlx; q.dtDyn = d.dtDyn;
     q.nEdgesOnCell = d.nEdgesOnCell; q.voc = d.voc; q.gidx = d.gidx; q.vActive = d.vActive;
     q.solveStress = d.solveStress; q.solveVelocity = d.solveVelocity;
@@ -800,7 +801,8 @@ __global__ void __launch_bounds__(64 * M, SIH_FUSED_MIN_WAVES) k_sub_fused(Persi
             const size_t kb = (size_t)(g * M + s) * P + c;
             bu[s] = d.SU[kb];
             bv[s] = d.SV[kb];
-            bm[s] = d.SM[kb];
+            // (a symmetric metric matrix is read from one side of its diagonal only, as in k_sub_cells_split)
+            bm[s] = d.SM[d.symMetric ? (size_t)((g > s ? g : s) * M + (g > s ? s : g)) * P + c : kb];
         }
     }
     uT[tid] = uu;

@@ -1053,10 +1053,14 @@ extern "C" int sih_field_get_noalloc(sih_ctx *c, const char *name, void *host, s
 
 static void notePut(sih_ctx *c, const char *name)
 {
-    if (c->inited && (!strncmp(name, "basisGradient", 13) || !strncmp(name, "basisIntegrals", 14)) && c->sparseGrad) {
-        // the compact gradients are stale until sih_evp_static_changed(); the dense kernel variant reads what the
-        // host has just put.  Captured graphs hold launches of the compact variant: they go too.
+    if (c->inited && (!strncmp(name, "basisGradient", 13) || !strncmp(name, "basisIntegrals", 14)) &&
+        (c->sparseGrad || c->symMetric)) {
+        // the compact gradients are stale until sih_evp_static_changed(), and the metric integrals may no longer be
+        // symmetric; the dense kernel variant reads what the host has just put.  Captured graphs hold launches of the
+        // compact variant: they go too.
         c->sparseGrad = false;
+        c->symMetric = false;
+        c->dev.symMetric = 0;
         sih_drop_graphs(c);
     }
 }
@@ -1425,6 +1429,7 @@ extern "C" int sih_get_info(sih_ctx *c, const char *key, double *value)
     if (!c || !key || !value) return SIH_ERR_ARG;
     std::string k = key;
     if (k == "sparseGradient") *value = c->sparseGrad ? 1.0 : 0.0;
+    else if (k == "symmetricMetric") *value = c->symMetric ? 1.0 : 0.0;
     else if (k == "dampingTimescale") *value = c->dev.dampT;
     else if (k == "elasticTimeStep") *value = c->dev.dtE;
     else if (k == "dynamicsTimeStep") *value = c->dev.dtDyn;

@@ -54,6 +54,7 @@ struct SihDev {
     // scalars
     double dtDyn, dtE, dampT, brlx;
     int relation, useOcean, quadratic, useAir, tiltMode, useColumn, haloVertices;
+    int symMetric;  // basisIntegralsMetric(s, j) == (j, s) bit for bit: the cell kernels read one of each pair
     int columnStrength, kstrength, krdgPartic, krdgRedist;  // colpkg_ice_strength in place of Hibler's formula
     double muRdg, Cf;
 };
@@ -85,6 +86,7 @@ struct sih_ctx {
     size_t arenaSize = 0, arenaUsed = 0;
     sih_evp_config cfg{};
     bool inited = false, sparseGrad = false;
+    bool symMetric = false;  // the metric integrals are bitwise symmetric (checked on the device at set-up)
     bool counted = false;  // in the per-device count of live contexts
     int persistMode = -1;  // sih_evp_set_persistent: -1 environment, 0 two-kernel form, 1 persistent kernel, 2 with the exchange inside
     bool splitCells = false;  // cell kernel with one thread per (cell, corner) instead of one per cell

@@ -482,3 +482,40 @@ def test_put_of_a_basis_array_drops_the_captured_graph():
         return dom.blocklist[0].structs["velocity_solver"]["uVelocity"].copy()
     a, b = run(True), run(False)
     assert np.abs(b).max() > 0 and np.array_equal(a, b)
+
+
+def test_metric_integrals_are_mirrored_unless_asked_otherwise(oracle, monkeypatch):
+    """basisIntegralsMetric(s, j) is the integral of N_s N_j: the set-up mirrors the entries with s <= j, so that the
+    matrix is symmetric bit for bit and the cell kernels fetch one side only.  The kept half is the oracle's bit for bit,
+    the mirrored half differs from it in the last place at most; SIH_METRIC_INTEGRALS=as_computed keeps all entries as
+    the reference's arithmetic gives them.  Velocities within 1e-10 of the oracle either way."""
+    mesh = get_mesh("QU480")
+    cfg = {"config_elastic_subcycle_number": 30}
+    ref = cases.make_domain(mesh, "QU480", configs=cfg)
+    oracle.seaice_init_velocity_solver(ref)
+    oracle.seaice_run_velocity_solver(ref)
+    nC = mesh.nCells
+    want = ref.blocklist[0].structs["velocity_variational"]["basisIntegralsMetric"][:, :, :nC]
+    assert not np.array_equal(want, want.transpose(1, 0, 2))   # the reference's own matrix is not symmetric in bits
+    for mode in ("mirrored", "as_computed"):
+        if mode == "as_computed":
+            monkeypatch.setenv("SIH_METRIC_INTEGRALS", "as_computed")
+        dev = cases.make_domain(mesh, "QU480", configs=cfg)
+        vs.seaice_mesh_pool_create(dev)
+        try:
+            vs.seaice_init_velocity_solver(dev)
+            sym = dev.blocklist[0].ctx.info("symmetricMetric")
+            vs.seaice_run_velocity_solver(dev)
+        finally:
+            vs.seaice_mesh_pool_destroy(dev)
+        got = dev.blocklist[0].structs["velocity_variational"]["basisIntegralsMetric"][:, :, :nC]
+        if mode == "mirrored":
+            assert sym == 1.0
+            assert np.array_equal(got, got.transpose(1, 0, 2))
+            iu = np.triu_indices(got.shape[0])          # s <= j
+            assert np.array_equal(got[iu], want[iu])
+            assert np.abs(got - want).max() <= 4.0e-16 * np.abs(want).max()
+        else:
+            assert sym == 0.0
+            assert np.array_equal(got, want)
+        compare_domains(dev, ref, STATE, 1e-10)
