@@ -43,13 +43,15 @@ def b_alg_cell_kernel(M):
     return 16 * M * M + 24 * M * M + 48 * M + 8 * M + (4 * M + 8) + 8 + 24 * 2
 
 
-def b_layout_cell_kernel(M, symmetric_metric=True):
+def b_layout_cell_kernel(M, symmetric_metric=True, derived_gradient=True):
     """Bytes per cell this library's layout makes the cell kernel move: like b_alg_cell_kernel, but the basis
     gradients are stored compactly (three non-zeros per column: 48 M instead of 16 M^2 bytes), the per-corner
     partial sums of the stress divergence are written (16 M), and of the metric integrals, mirrored at set-up to be
-    symmetric bit for bit, one side of the diagonal is fetched (4 M (M + 1) instead of 8 M^2 bytes)."""
+    symmetric bit for bit, one side of the diagonal is fetched (4 M (M + 1) instead of 8 M^2 bytes); of the three
+    gradients of a corner two are fetched."""
     metric = 4 * M * (M + 1) if symmetric_metric else 8 * M * M
-    return 48 * M + 16 * M * M + metric + 48 * M + 16 * M + (4 * M + 8) + 8 + 24 * 2
+    gradients = 32 * M if derived_gradient else 48 * M   # the corner's own gradient is minus the sum of the other two
+    return gradients + 16 * M * M + metric + 48 * M + 16 * M + (4 * M + 8) + 8 + 24 * 2
 
 
 def kernel_source_hash(files=("evp_step.hip", "sih_internal.h")):
@@ -335,6 +337,7 @@ def main():
     advection = None
 
     sym_metric = os.environ.get("SIH_METRIC_INTEGRALS") != "as_computed"
+    derived_grad = os.environ.get("SIH_BASIS_GRADIENTS") != "as_computed"
     if world == 1:
         dom = cases.make_domain(mesh, args.mesh, configs={"config_elastic_subcycle_number": nsub})
         vs.seaice_mesh_pool_create(dom, device=local_rank, renumber=not args.no_renumber)
@@ -356,6 +359,7 @@ def main():
         ctx.sync()
         single_form = int(ctx.info("iterationForm"))
         sym_metric = bool(ctx.info("symmetricMetric"))
+        derived_grad = bool(ctx.info("derivedGradient"))
         cell_ms, vert_ms, nsamp = 0.0, 0.0, 0
         if single_form != 0:
             for _ in range(args.warmup):
@@ -436,7 +440,7 @@ def main():
                               "from": tj.get("kernel_stats_file")}
         else:
             traffic_note = "profiles/traffic_latest.json was taken with other kernel sources: not reported"
-    layout_bytes = b_layout_cell_kernel(M, sym_metric) * cells_per_launch
+    layout_bytes = b_layout_cell_kernel(M, sym_metric, derived_grad) * cells_per_launch
     # a mesh with cells of several degrees: the same accounting with every cell's own number of corners in place of
     # maxEdges (the planes are maxEdges deep, but a corner a cell does not have is never read)
     degree_note = None

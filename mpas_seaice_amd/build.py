@@ -42,6 +42,8 @@ def build(force=False, verbose=True):
     flags = ["-O3", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-std=c++17",
              "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
              "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc")]
+    if os.environ.get("SIH_DEBUG_ALLOC"):   # allocation checker (sih_internal.h); build with force=True to switch
+        flags.append("-DSIH_DEBUG_ALLOC")
     os.makedirs(os.path.join(HERE, "csrc", "obj"), exist_ok=True)
     procs = []
     for s in srcs:

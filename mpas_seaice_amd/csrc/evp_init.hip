@@ -37,6 +37,7 @@ struct InitArgs {
     double *tanLat, *varDenom;
     double *gradU, *gradV, *SU, *SV, *SM, *gradU3, *gradV3;
     int *flag;
+    int *nEdgesDerive;  // nEdgesOnCell | 256 where every corner's own gradient is minus the sum of the other two
 };
 
 // mesh.F:2350-2381
@@ -95,29 +96,11 @@ struct WachCell {
 
 __device__ inline int wrapIdx(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
 
-// The functions below take the polygon's number of vertices as a template parameter N (4 to 7: every loop bound and
-// every index into the polygon's arrays is then a constant, and the arrays are registers; with run-time bounds they
-// lived in scratch memory and the integrals of QU60 took 29 ms) or N = 0 for any other polygon (bounds from w.n).
-#define WACH_N(w) (N ? N : (w).n)
-
-// an element of a small array by a run-time index, without indexing the array by a variable
-template <int N>
-__device__ __forceinline__ double wachPick(const double *arr, int n, int idx)
-{
-    if (N == 0) return arr[idx];
-    double v = arr[0];
-#pragma unroll
-    for (int i = 1; i < (N ? N : 1); i++) v = (i == idx) ? arr[i] : v;
-    (void)n;
-    return v;
-}
-
 // variational_shared.F:191-279 with mesh.F:2021-2061, 2272-2332 (sphere) or :125-177 (plane);
 // then calc_wachspress_coefficients wachspress.F:535-614
-template <int N>
-__device__ __forceinline__ void wachSetup(WachCell &w, const InitArgs &a, int c)
+__device__ void wachSetup(WachCell &w, const InitArgs &a, int c)
 {
-    const int n = N ? N : a.nEdgesOnCell[c];
+    int n = a.nEdgesOnCell[c];
     w.n = n;
     if (a.onASphere) {
         double xc, yc, zc;
@@ -146,7 +129,6 @@ __device__ __forceinline__ void wachSetup(WachCell &w, const InitArgs &a, int c)
             n1 = 0.0;
             n2 = 1.0;
         }
-#pragma unroll
         for (int i = 0; i < n; i++) {
             int v = a.voc[i * a.padC + c];
             double px, py, pz;
@@ -155,14 +137,12 @@ __device__ __forceinline__ void wachSetup(WachCell &w, const InitArgs &a, int c)
             w.y[i] = px * n0 + py * n1 + pz * n2;
         }
     } else {
-#pragma unroll
         for (int i = 0; i < n; i++) {
             int v = a.voc[i * a.padC + c];
             w.x[i] = a.xVertex[v] - a.xCell[c];
             w.y[i] = a.yVertex[v] - a.yCell[c];
         }
     }
-#pragma unroll
     for (int i = 0; i < n; i++) {
         int i1 = wrapIdx(i - 1, n), i2 = i;
         double den = w.x[i1] * w.y[i2] - w.x[i2] * w.y[i1];
@@ -170,7 +150,6 @@ __device__ __forceinline__ void wachSetup(WachCell &w, const InitArgs &a, int c)
         w.B[i] = (w.x[i1] - w.x[i2]) / (w.x[i1] * w.y[i2] - w.x[i2] * w.y[i1]);
     }
     w.kappa[0] = 1.0;
-#pragma unroll
     for (int j = 1; j < n; j++) {
         int i0 = j - 1, i1 = j, i2 = wrapIdx(j + 1, n);
         w.kappa[j] = w.kappa[j - 1] * (w.A[i2] * (w.x[i0] - w.x[i1]) + w.B[i2] * (w.y[i0] - w.y[i1])) /
@@ -178,34 +157,26 @@ __device__ __forceinline__ void wachSetup(WachCell &w, const InitArgs &a, int c)
     }
 }
 
-__device__ __forceinline__ double wachEdge(const WachCell &w, int k, double x, double y) { return 1.0 - w.A[k] * x - w.B[k] * y; }
+__device__ inline double wachEdge(const WachCell &w, int k, double x, double y) { return 1.0 - w.A[k] * x - w.B[k] * y; }
 
-// numerator j = kappa_j * prod over edges k not in {j, j+1}, ascending k (wachspress.F:628-668, 864-925); j is a
-// loop constant of the caller
-template <int N>
-__device__ __forceinline__ double wachNumerator(const WachCell &w, int j, double x, double y)
+// numerator j = kappa_j * prod over edges k not in {j, j+1}, ascending k (wachspress.F:628-668, 864-925)
+__device__ double wachNumerator(const WachCell &w, int j, double x, double y)
 {
-    const int n = WACH_N(w);
-    int skip2 = wrapIdx(j + 1, n);
+    int skip2 = wrapIdx(j + 1, w.n);
     double num = 1.0;
-#pragma unroll
-    for (int k = 0; k < n; k++)
+    for (int k = 0; k < w.n; k++)
         if (k != j && k != skip2) num = num * wachEdge(w, k, x, y);
     return num * w.kappa[j];
 }
 
 // wachspress.F:939-1035
-template <int N>
-__device__ __forceinline__ void wachNumeratorDerivative(const WachCell &w, int j, double x, double y, double &dU, double &dV)
+__device__ void wachNumeratorDerivative(const WachCell &w, int j, double x, double y, double &dU, double &dV)
 {
-    const int n = WACH_N(w);
-    int skip2 = wrapIdx(j + 1, n);
+    int skip2 = wrapIdx(j + 1, w.n);
     double sumU = 0.0, sumV = 0.0;
-#pragma unroll
-    for (int k = 0; k < n; k++) {
+    for (int k = 0; k < w.n; k++) {
         if (k == j || k == skip2) continue;
         double pU = 1.0, pV = 1.0;
-#pragma unroll
         for (int l = 0; l < k; l++) {
             if (l == j || l == skip2) continue;
             double e = wachEdge(w, l, x, y);
@@ -214,8 +185,7 @@ __device__ __forceinline__ void wachNumeratorDerivative(const WachCell &w, int j
         }
         pU = pU * (-w.A[k]);
         pV = pV * (-w.B[k]);
-#pragma unroll
-        for (int l = k + 1; l < n; l++) {
+        for (int l = k + 1; l < w.n; l++) {
             if (l == j || l == skip2) continue;
             double e = wachEdge(w, l, x, y);
             pU = pU * e;
@@ -228,18 +198,15 @@ __device__ __forceinline__ void wachNumeratorDerivative(const WachCell &w, int j
     dV = sumV * w.kappa[j];
 }
 
-// wachspress.F:763-850; i is a run-time index
-template <int N>
-__device__ __forceinline__ void wachBasisDerivative(const WachCell &w, int i, double x, double y, double &dU, double &dV)
+// wachspress.F:763-850
+__device__ void wachBasisDerivative(const WachCell &w, int i, double x, double y, double &dU, double &dV)
 {
-    const int n = WACH_N(w);
     double den = 0.0, sU = 0.0, sV = 0.0, numi = 0.0, dUi = 0.0, dVi = 0.0;
-#pragma unroll
-    for (int j = 0; j < n; j++) {
-        double num = wachNumerator<N>(w, j, x, y);
+    for (int j = 0; j < w.n; j++) {
+        double num = wachNumerator(w, j, x, y);
         den = den + num;
         double du, dv;
-        wachNumeratorDerivative<N>(w, j, x, y, du, dv);
+        wachNumeratorDerivative(w, j, x, y, du, dv);
         sU = sU + du;
         sV = sV + dv;
         if (j == i) {
@@ -252,28 +219,8 @@ __device__ __forceinline__ void wachBasisDerivative(const WachCell &w, int i, do
     dV = dVi / den - (numi / (den * den)) * sV;
 }
 
-// calculate_wachspress_derivatives, wachspress.F:1083-1206, for basis vertex ib of cell c
-template <int N>
-__device__ __forceinline__ void wachGradientsOf(const InitArgs &a, int c, int ib)
-{
-    const int M = a.M;
-    WachCell w;
-    wachSetup<N>(w, a, c);
-    const int n = WACH_N(w);
-    if (ib >= n) return;
-    int gs[3] = {ib, wrapIdx(ib - 1, n), wrapIdx(ib + 1, n)};
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-        int g = gs[q];
-        double du, dv;
-        wachBasisDerivative<N>(w, ib, wachPick<N>(w.x, n, g), wachPick<N>(w.y, n, g), du, dv);
-        a.gradU[(size_t)(g * M + ib) * a.padC + c] = du;
-        a.gradV[(size_t)(g * M + ib) * a.padC + c] = dv;
-    }
-}
-
-// one thread per (cell, basis vertex)
-__global__ void __launch_bounds__(64) k_wach_gradients(InitArgs a)
+// calculate_wachspress_derivatives, wachspress.F:1083-1206: one thread per (cell, basis vertex)
+__global__ void k_wach_gradients(InitArgs a)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     int c = t % a.nCells, ib = t / a.nCells;
@@ -283,32 +230,34 @@ __global__ void __launch_bounds__(64) k_wach_gradients(InitArgs a)
         a.gradU[(size_t)(g * M + ib) * a.padC + c] = 0.0;
         a.gradV[(size_t)(g * M + ib) * a.padC + c] = 0.0;
     }
-    switch (a.nEdgesOnCell[c]) {
-    case 4: wachGradientsOf<4>(a, c, ib); break;
-    case 5: wachGradientsOf<5>(a, c, ib); break;
-    case 6: wachGradientsOf<6>(a, c, ib); break;
-    case 7: wachGradientsOf<7>(a, c, ib); break;
-    default: wachGradientsOf<0>(a, c, ib);
+    WachCell w;
+    wachSetup(w, a, c);
+    if (ib >= w.n) return;
+    int gs[3] = {ib, wrapIdx(ib - 1, w.n), wrapIdx(ib + 1, w.n)};
+    for (int q = 0; q < 3; q++) {
+        int g = gs[q];
+        double du, dv;
+        wachBasisDerivative(w, ib, w.x[g], w.y[g], du, dv);
+        a.gradU[(size_t)(g * M + ib) * a.padC + c] = du;
+        a.gradV[(size_t)(g * M + ib) * a.padC + c] = dv;
     }
 }
 
-// integrate_wachspress / integrate_wachspress_polygon, wachspress.F:179-467, for velocity vertex j of cell c:
-// accumulates the column (:, j) of the three integrals
-template <int N>
-__device__ __forceinline__ void wachIntegralsOf(const InitArgs &a, int c, int j)
+// integrate_wachspress / integrate_wachspress_polygon, wachspress.F:179-467:
+// one thread per (cell, velocity vertex j); accumulates the column (:, j) of the three integrals
+__global__ void k_wach_integrals(InitArgs a)
 {
-    constexpr int NA = N ? N : SIH_MAXE;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int c = t % a.nCells, j = t / a.nCells;
+    if (j >= a.M) return;
     const int M = a.M;
-    double SU[NA], SV[NA], SM[NA];
-#pragma unroll
-    for (int s = 0; s < NA; s++) SU[s] = SV[s] = SM[s] = 0.0;
+    double SU[SIH_MAXE], SV[SIH_MAXE], SM[SIH_MAXE];
+    for (int s = 0; s < SIH_MAXE; s++) SU[s] = SV[s] = SM[s] = 0.0;
     WachCell w;
-    wachSetup<N>(w, a, c);
-    const int n = WACH_N(w);
-    if (j < n) {
-#pragma unroll
-        for (int tri = 0; tri < n; tri++) {
-            int i1 = tri, i2 = wrapIdx(tri + 1, n);
+    wachSetup(w, a, c);
+    if (j < w.n) {
+        for (int tri = 0; tri < w.n; tri++) {
+            int i1 = tri, i2 = wrapIdx(tri + 1, w.n);
             // get_triangle_mapping (:485-517) from the unit triangle (1,0),(0,1)
             double x1 = 1.0, y1 = 0.0, x2 = 0.0, y2 = 1.0;
             double u1 = w.x[i1], v1 = w.y[i1], u2 = w.x[i2], v2 = w.y[i2];
@@ -317,66 +266,38 @@ __device__ __forceinline__ void wachIntegralsOf(const InitArgs &a, int c, int j)
             double m21 = (v2 * y1 - v1 * y2) / (x2 * y1 - x1 * y2);
             double m22 = (v1 * x2 - v2 * x1) / (y1 * x2 - y2 * x1);
             double jac = m11 * m22 - m12 * m21;
-            double sU[NA], sV[NA], sM[NA];
-#pragma unroll
-            for (int s = 0; s < NA; s++) sU[s] = sV[s] = sM[s] = 0.0;
+            double sU[SIH_MAXE], sV[SIH_MAXE], sM[SIH_MAXE];
+            for (int s = 0; s < SIH_MAXE; s++) sU[s] = sV[s] = sM[s] = 0.0;
             for (int p = 0; p < a.nQ; p++) {
                 double px = m11 * a.qU[p] + m12 * a.qV[p];
                 double py = m21 * a.qU[p] + m22 * a.qV[p];
-                double num[NA], den = 0.0;
-#pragma unroll
-                for (int s = 0; s < n; s++) {
-                    num[s] = wachNumerator<N>(w, s, px, py);
+                double num[SIH_MAXE], den = 0.0;
+                for (int s = 0; s < w.n; s++) {
+                    num[s] = wachNumerator(w, s, px, py);
                     den = den + num[s];
                 }
                 double dNu, dNv;
-                wachBasisDerivative<N>(w, j, px, py, dNu, dNv);
-                double Nj = wachPick<N>(num, n, j) / den;
-#pragma unroll
-                for (int s = 0; s < n; s++) {
+                wachBasisDerivative(w, j, px, py, dNu, dNv);
+                double Nj = num[j] / den;
+                for (int s = 0; s < w.n; s++) {
                     double tmp = jac * a.qW[p] * (num[s] / den);
                     sU[s] = sU[s] + tmp * dNu;
                     sV[s] = sV[s] + tmp * dNv;
                     sM[s] = sM[s] + tmp * Nj;
                 }
             }
-#pragma unroll
-            for (int s = 0; s < n; s++) {
+            for (int s = 0; s < w.n; s++) {
                 SU[s] = SU[s] + sU[s] / a.qNorm;
                 SV[s] = SV[s] + sV[s] / a.qNorm;
                 SM[s] = SM[s] + sM[s] / a.qNorm;
             }
         }
     }
-    // host index (iStress s, iVelocity j) -> lead j*M + s
-#pragma unroll
-    for (int s = 0; s < NA; s++)
-        if (s < M) {
-            size_t k = (size_t)(j * M + s) * a.padC + c;
-            a.SU[k] = SU[s];
-            a.SV[k] = SV[s];
-            a.SM[k] = SM[s];
-        }
-    for (int s = NA; s < M; s++) {
+    for (int s = 0; s < M; s++) {  // host index (iStress s, iVelocity j) -> lead j*M + s
         size_t k = (size_t)(j * M + s) * a.padC + c;
-        a.SU[k] = 0.0;
-        a.SV[k] = 0.0;
-        a.SM[k] = 0.0;
-    }
-}
-
-// one thread per (cell, velocity vertex j)
-__global__ void __launch_bounds__(64) k_wach_integrals(InitArgs a)
-{
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    int c = t % a.nCells, j = t / a.nCells;
-    if (j >= a.M) return;
-    switch (a.nEdgesOnCell[c]) {
-    case 4: wachIntegralsOf<4>(a, c, j); break;
-    case 5: wachIntegralsOf<5>(a, c, j); break;
-    case 6: wachIntegralsOf<6>(a, c, j); break;
-    case 7: wachIntegralsOf<7>(a, c, j); break;
-    default: wachIntegralsOf<0>(a, c, j);
+        a.SU[k] = (s < SIH_MAXE) ? SU[s] : 0.0;
+        a.SV[k] = (s < SIH_MAXE) ? SV[s] : 0.0;
+        a.SM[k] = (s < SIH_MAXE) ? SM[s] : 0.0;
     }
 }
 
@@ -459,7 +380,7 @@ __global__ void k_pwl_basis(InitArgs a)
         a.SM[(size_t)k * pc + c] = 0.0;
     }
     WachCell w;  // only its local coordinates are used (seaice_calc_local_coords)
-    wachSetup<0>(w, a, c);
+    wachSetup(w, a, c);
     const int n = w.n;
     if (n < 3) return;
     const double alpha = 1.0 / (double)n;
@@ -550,7 +471,7 @@ __global__ void k_pack_gradients(InitArgs a)
     if (c >= a.nCells) return;
     const int M = a.M;
     int E = a.nEdgesOnCell[c];
-    bool dense = false;
+    bool dense = false, noUnity = false;
     for (int g = 0; g < M; g++) {
         int b3[3];
         if (g < E) {
@@ -584,8 +505,26 @@ __global__ void k_pack_gradients(InitArgs a)
                 if (a.gradU[(size_t)(g * M + b) * a.padC + c] != 0.0 || a.gradV[(size_t)(g * M + b) * a.padC + c] != 0.0)
                     dense = true;
             }
+            // The basis functions sum to one, so the three gradients met at corner g sum to zero: the corner's own
+            // (slot 0 for g = 0, slot 2 for the last corner, else slot 1) is minus the sum of the other two up to
+            // rounding.  A cell where that holds at every corner is marked, and the subcycle kernels do not fetch the
+            // own gradients of its corners.  (Decided cell by cell, from the cell's own numbers: the same in every
+            // block that holds the cell, so that results do not depend on the partition.)
+            const int own = g == 0 ? 0 : (g == E - 1 ? 2 : 1);
+            for (int uv = 0; uv < 2; uv++) {
+                const double *g3 = uv ? a.gradV3 : a.gradU3;
+                double x[3];
+                for (int q = 0; q < 3; q++) x[q] = g3[(size_t)(q * M + g) * a.padC + c];
+                const double o1 = x[own == 0 ? 1 : 0], o2 = x[own == 2 ? 1 : 2];
+                const double derived = -(o1 + o2);
+                const double big = fmax(fabs(x[own]), fmax(fabs(o1), fabs(o2)));
+                // (the gradients of a distorted heptagon miss zero by 160 units in the last place of the largest: the
+                // cancellation inside the Wachspress quotient; 1e-13 is three orders of magnitude inside the parity bar)
+                if (!(fabs(derived - x[own]) <= 1.0e-13 * big)) noUnity = true;
+            }
         }
     }
+    a.nEdgesDerive[c] = E | ((!dense && !noUnity) ? 256 : 0);
     if (dense) atomicOr(a.flag, 1);
 }
 
@@ -658,6 +597,7 @@ static InitArgs makeInitArgs(sih_ctx *c)
     a.SU = fd("basisIntegralsU");
     a.SV = fd("basisIntegralsV");
     a.SM = fd("basisIntegralsMetric");
+    a.nEdgesDerive = (int *)sih_find_field(c, "_nEdgesDerive")->d;
     a.gradU3 = fd("_gradU3");
     a.gradV3 = fd("_gradV3");
     a.flag = c->d_flag;
@@ -692,6 +632,26 @@ __global__ void k_check_metric_symmetry(InitArgs a)
     if (differs) atomicOr(a.flag, 2);
 }
 
+// Where the corner's own gradient is derived from the other two, the compact copy holds the derived value too: the
+// kernels that fetch all three (persistent and fused forms, one thread per cell) then compute with the same bits
+// as the one that derives it.  basisGradientU / V themselves stay as computed.
+__global__ void k_store_derived_gradients(InitArgs a)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.nCells) return;
+    const int M = a.M, E = a.nEdgesOnCell[c];
+    if (!(a.nEdgesDerive[c] & 256)) return;
+    for (int g = 0; g < E; g++) {
+        const int own = g == 0 ? 0 : (g == E - 1 ? 2 : 1);
+        for (int uv = 0; uv < 2; uv++) {
+            double *g3 = uv ? a.gradV3 : a.gradU3;
+            double x[3];
+            for (int q = 0; q < 3; q++) x[q] = g3[(size_t)(q * M + g) * a.padC + c];
+            g3[(size_t)(own * M + g) * a.padC + c] = -(x[own == 0 ? 1 : 0] + x[own == 2 ? 1 : 2]);
+        }
+    }
+}
+
 static int packStatic(sih_ctx *c, const InitArgs &a)
 {
     hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(64), 0, c->stream, c->d_flag, 16);
@@ -703,6 +663,15 @@ static int packStatic(sih_ctx *c, const InitArgs &a)
     HIPCHK(hipStreamSynchronize(c->stream));
     c->sparseGrad = (flag & 1) == 0;
     c->symMetric = (flag & 2) == 0;
+    {
+        // SIH_BASIS_GRADIENTS=as_computed: all three gradients of a corner are fetched as stored
+        const char *e = getenv("SIH_BASIS_GRADIENTS");
+        c->deriveGrad = c->sparseGrad && !(e && strcmp(e, "as_computed") == 0);
+    }
+    if (c->deriveGrad) {
+        hipLaunchKernelGGL(k_store_derived_gradients, dim3((c->nCells + 255) / 256), dim3(256), 0, c->stream, a);
+        HIPCHK(hipGetLastError());
+    }
     return SIH_OK;
 }
 

@@ -65,6 +65,7 @@ void sih_bind_dev(sih_ctx *c)
     d.gradV = fd("basisGradientV");
     d.gradU3 = fd("_gradU3");
     d.gradV3 = fd("_gradV3");
+    d.nEdgesDerive = (const int *)sih_find_field(c, "_nEdgesDerive")->d;
     d.SU = fd("basisIntegralsU");
     d.SV = fd("basisIntegralsV");
     d.SM = fd("basisIntegralsMetric");
@@ -138,6 +139,7 @@ void sih_bind_dev(sih_ctx *c)
     d.openWater = fd("openWaterArea");
     d.haloVertices = c->cfg.computeHaloVertices ? 1 : 0;
     d.symMetric = c->symMetric ? 1 : 0;
+    d.deriveGrad = c->deriveGrad ? 1 : 0;
 }
 
 __device__ inline double sign1(double x) { return copysign(1.0, x); }
@@ -631,7 +633,9 @@ __global__ void __launch_bounds__(64 * M) k_sub_cells_split(SihDev d, const int 
     }
     const int P = d.padC;
     const bool solve = inRange && d.solveStress[c] == 1;
-    const int E = inRange ? d.nEdgesOnCell[c] : 0;
+    // (with derived gradients: the number of edges with the cell's mark in bit 8, from the set-up)
+    const int Ev = inRange ? (SPARSE && d.deriveGrad ? d.nEdgesDerive[c] : d.nEdgesOnCell[c]) : 0;
+    const int E = Ev & 255;
     const bool corner = solve && g < E;
     const size_t k = (size_t)g * P + c;
     double ug = 0.0, vg = 0.0, tg = 0.0;
@@ -665,10 +669,31 @@ __global__ void __launch_bounds__(64 * M) k_sub_cells_split(SihDev d, const int 
             }
             const double xu[3] = {su[i0][lane], su[i1][lane], su[i2][lane]};
             const double xv[3] = {sv[i0][lane], sv[i1][lane], sv[i2][lane]};
+            // the corner's own gradient (slot `own`) is minus the sum of the other two in the cells where the set-up found
+            // the partition of unity to hold to rounding: 32 instead of 48 bytes of gradients per corner from memory
+            const int own = (Ev & 256) ? (g == 0 ? 0 : (g == E - 1 ? 2 : 1)) : -1;
+            double gu3[3], gv3[3];
 #pragma unroll
             for (int q = 0; q < 3; q++) {
-                const double gu = d.gradU3[(size_t)(q * M + g) * P + c];
-                const double gv = d.gradV3[(size_t)(q * M + g) * P + c];
+                gu3[q] = 0.0;
+                gv3[q] = 0.0;
+                if (q != own) {
+                    gu3[q] = d.gradU3[(size_t)(q * M + g) * P + c];
+                    gv3[q] = d.gradV3[(size_t)(q * M + g) * P + c];
+                }
+            }
+            if (own >= 0) {
+                const double du = -((own == 0 ? gu3[1] : gu3[0]) + (own == 2 ? gu3[1] : gu3[2]));
+                const double dv = -((own == 0 ? gv3[1] : gv3[0]) + (own == 2 ? gv3[1] : gv3[2]));
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    gu3[q] = q == own ? du : gu3[q];
+                    gv3[q] = q == own ? dv : gv3[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const double gu = gu3[q], gv = gv3[q];
                 e11 = e11 + xu[q] * gu;
                 e22 = e22 + xv[q] * gv;
                 e12 = e12 + 0.5 * (xu[q] * gv + xv[q] * gu);

@@ -8,7 +8,41 @@
 #include <numeric>
 #include <thread>
 
+#define SIH_DEBUG_ALLOC_IMPL
 #include "sih_internal.h"
+
+#ifdef SIH_DEBUG_ALLOC
+#include <mutex>
+static std::map<char *, std::pair<size_t, std::string>> g_dbgLive;
+static std::mutex g_dbgMutex;
+hipError_t sih_dbg_malloc(void **p, size_t n, const char *file, int line)
+{
+    hipError_t e = hipMalloc(p, n);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(g_dbgMutex);
+    char *b = (char *)*p;
+    for (auto &kv : g_dbgLive)
+        if (b < kv.first + kv.second.first && kv.first < b + n)
+            fprintf(stderr, "SIH_DEBUG_ALLOC: %s:%d got %p+%zu overlapping live %p+%zu from %s\n", file, line, (void *)b, n,
+                    (void *)kv.first, kv.second.first, kv.second.second.c_str());
+    g_dbgLive[b] = {n, std::string(file) + ":" + std::to_string(line)};
+    return e;
+}
+hipError_t sih_dbg_free(void *p, const char *file, int line)
+{
+    if (p) {
+        std::lock_guard<std::mutex> lock(g_dbgMutex);
+        auto it = g_dbgLive.find((char *)p);
+        if (it == g_dbgLive.end())
+            fprintf(stderr, "SIH_DEBUG_ALLOC: %s:%d frees %p which is not live (double free or foreign pointer)\n", file, line, p);
+        else
+            g_dbgLive.erase(it);
+    }
+    return hipFree(p);
+}
+#define hipMalloc(p, n) sih_dbg_malloc((void **)(p), (n), __FILE__, __LINE__)
+#define hipFree(p) sih_dbg_free((void *)(p), __FILE__, __LINE__)
+#endif
 
 static thread_local std::string g_err;
 
@@ -346,7 +380,7 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
         {"cellVerticesAtVertex", LOC_VERTEX, D, true},
         // compact gradients and per-corner divergence partial sums (library-internal)
         {"_gradU3", LOC_CELL, 3 * M, false}, {"_gradV3", LOC_CELL, 3 * M, false},
-        {"_partU", LOC_CELL, M, false}, {"_partV", LOC_CELL, M, false},
+        {"_partU", LOC_CELL, M, false}, {"_partV", LOC_CELL, M, false}, {"_nEdgesDerive", LOC_CELL, 1, true},
         // icestate, aggregates, coupling
         {"iceAreaVertex", LOC_VERTEX, 1, false}, {"totalMassVertex", LOC_VERTEX, 1, false},
         {"iceAreaCellInitial", LOC_CELL, 1, false}, {"totalMassCell", LOC_CELL, 1, false},
@@ -1054,13 +1088,15 @@ extern "C" int sih_field_get_noalloc(sih_ctx *c, const char *name, void *host, s
 static void notePut(sih_ctx *c, const char *name)
 {
     if (c->inited && (!strncmp(name, "basisGradient", 13) || !strncmp(name, "basisIntegrals", 14)) &&
-        (c->sparseGrad || c->symMetric)) {
+        (c->sparseGrad || c->symMetric || c->deriveGrad)) {
         // the compact gradients are stale until sih_evp_static_changed(), and the metric integrals may no longer be
         // symmetric; the dense kernel variant reads what the host has just put.  Captured graphs hold launches of the
         // compact variant: they go too.
         c->sparseGrad = false;
         c->symMetric = false;
         c->dev.symMetric = 0;
+        c->deriveGrad = false;
+        c->dev.deriveGrad = 0;
         sih_drop_graphs(c);
     }
 }
@@ -1430,6 +1466,7 @@ extern "C" int sih_get_info(sih_ctx *c, const char *key, double *value)
     std::string k = key;
     if (k == "sparseGradient") *value = c->sparseGrad ? 1.0 : 0.0;
     else if (k == "symmetricMetric") *value = c->symMetric ? 1.0 : 0.0;
+    else if (k == "derivedGradient") *value = c->deriveGrad ? 1.0 : 0.0;
     else if (k == "dampingTimescale") *value = c->dev.dampT;
     else if (k == "elasticTimeStep") *value = c->dev.dtE;
     else if (k == "dynamicsTimeStep") *value = c->dev.dtDyn;

@@ -9,6 +9,18 @@
 
 #include "seaice_hip.h"
 
+// Allocation checker for hunting double frees and overlapping allocations (build with -DSIH_DEBUG_ALLOC): every
+// hipMalloc / hipFree of the library goes through a registry that reports a free of an unknown or already freed
+// pointer and an allocation that overlaps a live one, with file and line, on stderr.
+#ifdef SIH_DEBUG_ALLOC
+hipError_t sih_dbg_malloc(void **p, size_t n, const char *file, int line);
+hipError_t sih_dbg_free(void *p, const char *file, int line);
+#ifndef SIH_DEBUG_ALLOC_IMPL
+#define hipMalloc(p, n) sih_dbg_malloc((void **)(p), (n), __FILE__, __LINE__)
+#define hipFree(p) sih_dbg_free((void *)(p), __FILE__, __LINE__)
+#endif
+#endif
+
 #define SIH_MAXE 10  // largest maxEdges the kernels are instantiated for
 #define SIH_MAX_TRAPEZOID 21  // largest trapezoidal integration order: (n+1)(n+2)/2 = 253 points
 #define SIH_MAX_RULE 256
@@ -55,6 +67,8 @@ struct SihDev {
     double dtDyn, dtE, dampT, brlx;
     int relation, useOcean, quadratic, useAir, tiltMode, useColumn, haloVertices;
     int symMetric;  // basisIntegralsMetric(s, j) == (j, s) bit for bit: the cell kernels read one of each pair
+    int deriveGrad; // where the three gradients met at a corner sum to zero to rounding the corner's own is not fetched
+    const int *nEdgesDerive;  // nEdgesOnCell | 256 for the cells where that holds at every corner
     int columnStrength, kstrength, krdgPartic, krdgRedist;  // colpkg_ice_strength in place of Hibler's formula
     double muRdg, Cf;
 };
@@ -87,6 +101,7 @@ struct sih_ctx {
     sih_evp_config cfg{};
     bool inited = false, sparseGrad = false;
     bool symMetric = false;  // the metric integrals are bitwise symmetric (checked on the device at set-up)
+    bool deriveGrad = false; // compact gradients obey the partition of unity to rounding (checked likewise)
     bool counted = false;  // in the per-device count of live contexts
     int persistMode = -1;  // sih_evp_set_persistent: -1 environment, 0 two-kernel form, 1 persistent kernel, 2 with the exchange inside
     bool splitCells = false;  // cell kernel with one thread per (cell, corner) instead of one per cell

@@ -519,3 +519,33 @@ def test_metric_integrals_are_mirrored_unless_asked_otherwise(oracle, monkeypatc
             assert sym == 0.0
             assert np.array_equal(got, want)
         compare_domains(dev, ref, STATE, 1e-10)
+
+
+def test_corner_gradient_from_the_partition_of_unity(oracle, monkeypatch):
+    """The three basis gradients met at a corner sum to zero up to rounding (the basis functions sum to one), so the
+    cell kernel fetches two and forms the corner's own as minus their sum; SIH_BASIS_GRADIENTS=as_computed fetches all
+    three as stored.  Velocities within 1e-10 of the oracle either way, on hexagons with pentagons and on the mesh with
+    heptagons; basisGradientU / V as the host sees them are untouched (STATIC_OUTPUTS at 1e-13)."""
+    for name in ("QU480", "var12"):
+        mesh = get_mesh(name)
+        cfg = {"config_elastic_subcycle_number": 30}
+        kw = {} if name == "QU480" else {"open_water_band": (-0.2, 0.3)}
+        ref = cases.make_domain(mesh, name if name == "QU480" else None, configs=cfg, **kw)
+        oracle.seaice_init_velocity_solver(ref)
+        oracle.seaice_run_velocity_solver(ref)
+        for mode in ("derived", "as_computed"):
+            if mode == "as_computed":
+                monkeypatch.setenv("SIH_BASIS_GRADIENTS", "as_computed")
+            else:
+                monkeypatch.delenv("SIH_BASIS_GRADIENTS", raising=False)
+            dev = cases.make_domain(mesh, name if name == "QU480" else None, configs=cfg, **kw)
+            vs.seaice_mesh_pool_create(dev)
+            try:
+                vs.seaice_init_velocity_solver(dev)
+                flag = dev.blocklist[0].ctx.info("derivedGradient")
+                vs.seaice_run_velocity_solver(dev)
+            finally:
+                vs.seaice_mesh_pool_destroy(dev)
+            assert flag == (1.0 if mode == "derived" else 0.0), (name, mode)
+            compare_domains(dev, ref, STATIC_OUTPUTS, 1e-13)
+            compare_domains(dev, ref, STATE, 1e-10)
