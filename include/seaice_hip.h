@@ -162,7 +162,11 @@ int sih_evp_set_edge_mesh(sih_ctx *ctx, const struct sih_ir_desc *edges);
  * reference rounds separately for (s, j) and (j, s) (wachspress.F:442-457), is made symmetric bit for bit by mirroring
  * the entries with s <= j after the variational denominator has been formed (the other half changes in the last place
  * at most), so that the subcycle kernels fetch one side of the diagonal.  SIH_METRIC_INTEGRALS=as_computed in the
- * environment keeps all entries as computed; a host-supplied basis (variationalBasis 0) is used as it is. */
+ * environment keeps all entries as computed; a host-supplied basis (variationalBasis 0) is used as it is.
+ * A second one inside the subcycle kernel only: in cells where the three non-zero basis gradients of every corner sum
+ * to zero to 1e-13 of the largest (the basis functions sum to one), the corner's own gradient is formed as minus the
+ * sum of the other two instead of being fetched; basisGradientU / V are untouched.  SIH_BASIS_GRADIENTS=as_computed
+ * switches that off.  Both keep the velocities within 1e-10 of the reference arithmetic. */
 int sih_evp_init(sih_ctx *ctx, const sih_evp_config *cfg);
 /* re-pack the static basis after the host replaced basisGradient* / basisIntegrals* with its own
  * (e.g. the piecewise-linear basis computed by the host model) */
