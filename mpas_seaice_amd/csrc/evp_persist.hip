@@ -105,7 +105,7 @@ struct PersistDev {
     double dtE, dampT, brlx, dtDyn;
     const int *nEdgesOnCell, *voc, *gidx, *vActive, *solveStress, *solveVelocity;
     const double *tanLat, *varDenom, *gradU3, *gradV3, *SU, *SV, *SM, *icePressure;
-    const double *totalMassVertex, *massF, *airVertU, *airVertV, *tiltForceU, *tiltForceV, *ocnStressU, *ocnStressV;
+    const double *totalMassVertex, *massF, *airTiltU, *airTiltV;
     const double *uOcnVert, *vOcnVert, *iceAreaVertex, *uInit, *vInit;
     double *u, *v, *stress11, *stress22, *stress12;
 };
@@ -121,8 +121,7 @@ static PersistDev makePersistDev(const SihDev &d)
     q.solveStress = d.solveStress; q.solveVelocity = d.solveVelocity;
     q.tanLat = d.tanLat; q.varDenom = d.varDenom; q.gradU3 = d.gradU3; q.gradV3 = d.gradV3;
     q.SU = d.SU; q.SV = d.SV; q.SM = d.SM; q.icePressure = d.icePressure;
-    q.totalMassVertex = d.totalMassVertex; q.massF = d.massF; q.airVertU = d.airVertU; q.airVertV = d.airVertV;
-    q.tiltForceU = d.tiltForceU; q.tiltForceV = d.tiltForceV; q.ocnStressU = d.ocnStressU; q.ocnStressV = d.ocnStressV;
+    q.totalMassVertex = d.totalMassVertex; q.massF = d.massF; q.airTiltU = d.airTiltU; q.airTiltV = d.airTiltV;
     q.uOcnVert = d.uOcnVert; q.vOcnVert = d.vOcnVert; q.iceAreaVertex = d.iceAreaVertex; q.uInit = d.uInit; q.vInit = d.vInit;
     q.u = d.u; q.v = d.v; q.stress11 = d.stress11; q.stress22 = d.stress22; q.stress12 = d.stress12;
     return q;
@@ -283,7 +282,7 @@ __global__ void __launch_bounds__(TC * M, 4) k_sub_persistent(PersistDev d, Pers
     // the vertices the vertex kernel updates: k_sub_vertices' conditions
     const bool solV = hasV && (d.haloVertices ? d.vActive[v] != 0 : v < d.nVerticesSolve) && d.solveVelocity[v] == 1;
     int q0 = 0, q1 = 0, q2 = 0;
-    double den0 = 1.0, m = 0.0, mf = 0.0, airU = 0.0, airV = 0.0, tiltU = 0.0, tiltV = 0.0, osU = 0.0, osV = 0.0;
+    double den0 = 1.0, m = 0.0, mf = 0.0, atU = 0.0, atV = 0.0;  // (air stress + tilt force, as k_sub_vertices takes them)
     double uo = 0.0, vo = 0.0, aV = 0.0, uu = 0.0, vv = 0.0;
     if (hasV) {
         uu = d.u[v];
@@ -296,12 +295,8 @@ __global__ void __launch_bounds__(TC * M, 4) k_sub_persistent(PersistDev d, Pers
         den0 = d.varDenom[v];
         m = d.totalMassVertex[v];
         mf = d.massF[v];
-        airU = d.airVertU[v];
-        airV = d.airVertV[v];
-        tiltU = d.tiltForceU[v];
-        tiltV = d.tiltForceV[v];
-        osU = d.ocnStressU[v];
-        osV = d.ocnStressV[v];
+        atU = d.airTiltU[v];
+        atV = d.airTiltV[v];
         uo = d.uOcnVert[v];
         vo = d.vOcnVert[v];
         aV = d.useOcean ? d.iceAreaVertex[v] : 0.0;
@@ -516,13 +511,13 @@ __global__ void __launch_bounds__(TC * M, 4) k_sub_persistent(PersistDev d, Pers
                 l22 = (brlx + 1.0) * (m / dtD) + coeff * COS_TURN;
                 // the velocities at the start of the dynamics step: read where they are needed, the revised
                 // relation is the rare one and every register counts here
-                r1 = dU + airU + tiltU + coeff * osU + (m * (brlx * uu + d.uInit[v])) / dtD;
-                r2 = dV + airV + tiltV + coeff * osV + (m * (brlx * vv + d.vInit[v])) / dtD;
+                r1 = dU + atU + coeff * uo + (m * (brlx * uu + d.uInit[v])) / dtD;
+                r2 = dV + atV + coeff * vo + (m * (brlx * vv + d.vInit[v])) / dtD;
             } else {
                 l11 = m / dtE + coeff * COS_TURN;
                 l22 = m / dtE + coeff * COS_TURN;
-                r1 = dU + airU + tiltU + coeff * osU + (m * uu) / dtE;
-                r2 = dV + airV + tiltV + coeff * osV + (m * vv) / dtE;
+                r1 = dU + atU + coeff * uo + (m * uu) / dtE;
+                r2 = dV + atV + coeff * vo + (m * vv) / dtE;
             }
             if (relation != 3) {
                 const double den = l11 * l22 - l12 * l21;
@@ -723,8 +718,8 @@ __global__ void __launch_bounds__(64 * M, SIH_FUSED_MIN_WAVES) k_sub_fused(Persi
         const double pu0 = f.sumsIn[q0], pu1 = f.sumsIn[q1], pu2 = f.sumsIn[q2];
         const double pv0 = f.sumsIn[plane + q0], pv1 = f.sumsIn[plane + q1], pv2 = f.sumsIn[plane + q2];
         const double den0 = d.varDenom[v], m = d.totalMassVertex[v], mf = d.massF[v];
-        const double airU = d.airVertU[v], airV = d.airVertV[v], tiltU = d.tiltForceU[v], tiltV = d.tiltForceV[v];
-        const double osU = d.ocnStressU[v], osV = d.ocnStressV[v], uo = d.uOcnVert[v], vo = d.vOcnVert[v];
+        const double atU = d.airTiltU[v], atV = d.airTiltV[v];  // (air stress + tilt force, as k_sub_vertices takes them)
+        const double uo = d.uOcnVert[v], vo = d.vOcnVert[v];
         const double aV = d.useOcean ? d.iceAreaVertex[v] : 0.0;
         const double dtE = d.dtE, brlx = d.brlx, dtD = d.dtDyn;
         const int relation = d.relation;
@@ -753,13 +748,13 @@ __global__ void __launch_bounds__(64 * M, SIH_FUSED_MIN_WAVES) k_sub_fused(Persi
             if (relation == 2) {
                 l11 = (brlx + 1.0) * (m / dtD) + coeff * COS_TURN;
                 l22 = (brlx + 1.0) * (m / dtD) + coeff * COS_TURN;
-                r1 = dU + airU + tiltU + coeff * osU + (m * (brlx * uu + d.uInit[v])) / dtD;
-                r2 = dV + airV + tiltV + coeff * osV + (m * (brlx * vv + d.vInit[v])) / dtD;
+                r1 = dU + atU + coeff * uo + (m * (brlx * uu + d.uInit[v])) / dtD;
+                r2 = dV + atV + coeff * vo + (m * (brlx * vv + d.vInit[v])) / dtD;
             } else {
                 l11 = m / dtE + coeff * COS_TURN;
                 l22 = m / dtE + coeff * COS_TURN;
-                r1 = dU + airU + tiltU + coeff * osU + (m * uu) / dtE;
-                r2 = dV + airV + tiltV + coeff * osV + (m * vv) / dtE;
+                r1 = dU + atU + coeff * uo + (m * uu) / dtE;
+                r2 = dV + atV + coeff * vo + (m * vv) / dtE;
             }
             if (relation != 3) {
                 const double den = l11 * l22 - l12 * l21;

@@ -66,6 +66,8 @@ void sih_bind_dev(sih_ctx *c)
     d.gradU3 = fd("_gradU3");
     d.gradV3 = fd("_gradV3");
     d.nEdgesDerive = (const int *)sih_find_field(c, "_nEdgesDerive")->d;
+    d.airTiltU = fd("_airTiltU");
+    d.airTiltV = fd("_airTiltV");
     d.SU = fd("basisIntegralsU");
     d.SV = fd("basisIntegralsV");
     d.SM = fd("basisIntegralsMetric");
@@ -398,6 +400,12 @@ __global__ void k_pre4_vertices(SihDev d)
         d.tiltForceU[v] = 0.0;
         d.tiltForceV[v] = 0.0;
     }
+    // what the momentum equation's right-hand side holds unchanged through the subcycles: solve_velocity adds the air
+    // stress and the tilt force to the stress divergence one after the other (:3177-3199); the subcycle kernels add
+    // their sum, formed here once (the difference is one rounding of the sum, far inside the parity bar, and two arrays
+    // less to fetch per vertex and subcycle)
+    d.airTiltU[v] = d.airVertU[v] + d.tiltForceU[v];
+    d.airTiltV[v] = d.airVertV[v] + d.tiltForceV[v];
     if (!solve) {
         d.u[v] = 0.0;
         d.v[v] = 0.0;
@@ -915,6 +923,8 @@ __global__ void __launch_bounds__(256) k_sub_vertices(SihDev d, const int *__res
         }
     }
     const double m = d.totalMassVertex[v], mf = d.massF[v];
+    // oceanStressU / V of a solved vertex are the ocean's velocity itself: u cos(0) - v sin(0) sign(f) (:1878-1881 with
+    // the turning angle of :61-63), so `uo`, `vo` stand for them; without ocean stress the coefficient is zero
     double l11, l22, r1, r2;
     const double l12 = -mf - coeff * SIN_TURN * sign1(mf);
     const double l21 = mf + coeff * SIN_TURN * sign1(mf);
@@ -922,14 +932,14 @@ __global__ void __launch_bounds__(256) k_sub_vertices(SihDev d, const int *__res
         const double brlx = d.brlx, dtD = d.dtDyn;
         l11 = (brlx + 1.0) * (m / dtD) + coeff * COS_TURN;
         l22 = (brlx + 1.0) * (m / dtD) + coeff * COS_TURN;
-        r1 = dU + d.airVertU[v] + d.tiltForceU[v] + coeff * d.ocnStressU[v] + (m * (brlx * uu + d.uInit[v])) / dtD;
-        r2 = dV + d.airVertV[v] + d.tiltForceV[v] + coeff * d.ocnStressV[v] + (m * (brlx * vv + d.vInit[v])) / dtD;
+        r1 = dU + d.airTiltU[v] + coeff * uo + (m * (brlx * uu + d.uInit[v])) / dtD;
+        r2 = dV + d.airTiltV[v] + coeff * vo + (m * (brlx * vv + d.vInit[v])) / dtD;
     } else {
         const double dtE = d.dtE;
         l11 = m / dtE + coeff * COS_TURN;
         l22 = m / dtE + coeff * COS_TURN;
-        r1 = dU + d.airVertU[v] + d.tiltForceU[v] + coeff * d.ocnStressU[v] + (m * uu) / dtE;
-        r2 = dV + d.airVertV[v] + d.tiltForceV[v] + coeff * d.ocnStressV[v] + (m * vv) / dtE;
+        r1 = dU + d.airTiltU[v] + coeff * uo + (m * uu) / dtE;
+        r2 = dV + d.airTiltV[v] + coeff * vo + (m * vv) / dtE;
     }
     if (d.relation != 3) {  // the linear relation has no velocity solve (velocity_solver.F:2529-2541)
         const double den = l11 * l22 - l12 * l21;

@@ -381,6 +381,7 @@ extern "C" int sih_block_create(const sih_mesh_desc *m, int device, sih_ctx **ou
         // compact gradients and per-corner divergence partial sums (library-internal)
         {"_gradU3", LOC_CELL, 3 * M, false}, {"_gradV3", LOC_CELL, 3 * M, false},
         {"_partU", LOC_CELL, M, false}, {"_partV", LOC_CELL, M, false}, {"_nEdgesDerive", LOC_CELL, 1, true},
+        {"_airTiltU", LOC_VERTEX, 1, false}, {"_airTiltV", LOC_VERTEX, 1, false},
         // icestate, aggregates, coupling
         {"iceAreaVertex", LOC_VERTEX, 1, false}, {"totalMassVertex", LOC_VERTEX, 1, false},
         {"iceAreaCellInitial", LOC_CELL, 1, false}, {"totalMassCell", LOC_CELL, 1, false},

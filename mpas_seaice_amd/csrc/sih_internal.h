@@ -57,6 +57,7 @@ struct SihDev {
     double *airCellU, *airCellV, *airVertU, *airVertV;
     double *uOcnVert, *vOcnVert, *ocnStressU, *ocnStressV, *ocnCoeff, *ocnStressCellU, *ocnStressCellV;
     double *tiltVertU, *tiltVertV, *tiltForceU, *tiltForceV, *massF;
+    double *airTiltU, *airTiltV;  // airStressVertex + surfaceTiltForce, constant over the subcycles (formed in the pre-cycle)
     double *divergence, *shear, *ridgeConv, *ridgeShear;
     double *iceAreaVertex, *totalMassVertex, *iceAreaCellInitial, *totalMassCell;
     double *iceAreaCell, *iceVolumeCell, *snowVolumeCell;
