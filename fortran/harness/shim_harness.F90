@@ -6,7 +6,8 @@
 !>
 !> The call sequence is the reference's: seaice_init (src/shared/mpas_seaice_initialize.F:104, :121, :126) creates the
 !> mesh pool and initialises the velocity solver and the advection; every dynamics step of seaice_timestep
-!> (src/shared/mpas_seaice_time_integration.F:147-153) runs the velocity solver, then the advection.  With a fourth
+!> (src/shared/mpas_seaice_time_integration.F:142-158) runs the velocity solver, then the advection, then -- with
+!> config_use_column_package -- the column package's ridging and aggregation (seaice_column_dynamics_hip).  With a fourth
 !> argument the steps are also timed (the shims' own timers, which name the transfers and the solver).
 !>
 !> Case file (little-endian stream, written by mpas_seaice_amd/fortran_case.py:write_pools): magic; configs (key, type,
@@ -24,6 +25,8 @@ program shim_harness
   use seaice_velocity_solver, only: seaice_init_velocity_solver, seaice_run_velocity_solver, &
        seaice_velocity_solver_fetch_diagnostics, seaice_finalize_velocity_solver
   use seaice_advection, only: seaice_init_advection, seaice_run_advection
+  use seaice_column_dynamics_hip, only: seaice_column_reinitialize_diagnostics_dynamics, &
+       seaice_column_dynamics_time_integration
 
   implicit none
 
@@ -59,8 +62,10 @@ program shim_harness
 
   ! seaice_timestep, dynamics part
   do iStep = 1, nSteps
-     call seaice_run_velocity_solver(domain, clock)
-     call seaice_run_advection(domain, clock)
+     call seaice_column_reinitialize_diagnostics_dynamics(domain)   ! :142 (nothing without the column package)
+     call seaice_run_velocity_solver(domain, clock)                 ! :147
+     call seaice_run_advection(domain, clock)                       ! :153
+     call seaice_column_dynamics_time_integration(domain, clock)    ! :158: ridging and aggregate state
   enddo
   call seaice_velocity_solver_fetch_diagnostics(domain)   ! nothing unless the diagnostics were left on the device
 

@@ -49,6 +49,8 @@ DEFAULT_CONFIGS = {
     "config_ratio_ridging_work_to_PE": 17.0,
     # ridging of the column package (Registry.xml:1685-1708; column_ridging runs when both are set)
     "config_use_column_ridging": True,
+    "config_use_vertical_tracers": False,   # column_combine_snow_ice_tracers (biogeochemistry): outside this library
+    "config_use_ice_age": False,            # the ice-age tendency of seaice_column_update_state: not carried
     "config_use_special_boundaries_velocity": False,
     "config_use_special_boundaries_velocity_masks": False,
     "config_use_special_boundaries_tracers": False,

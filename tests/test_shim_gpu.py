@@ -125,3 +125,44 @@ def test_shim_modules_run_upwind_advection(oracle, tmp_path):
     for t in ("iceEnthalpy", "iceSalinity", "snowEnthalpy"):  # outside the chain: zeroed, as in the reference
         assert not got[("tracers", t)][0].any()
     assert np.abs(got[("tracers", "iceVolumeCategory")][0]).max() > 0.0
+
+
+def test_shim_modules_run_the_column_dynamics(oracle, tmp_path):
+    """With config_use_column_package the harness runs the whole loop body of seaice_timestep
+    (mpas_seaice_time_integration.F:142-158): seaice_column_reinitialize_diagnostics_dynamics, velocity solver,
+    advection, seaice_column_dynamics_time_integration (ridging with the ITD clean-up, then the aggregate state and the
+    transport tendencies), the last one from fortran/shim/mpas_seaice_column_dynamics_hip.F on the device.  Two steps
+    against the oracle's flow on the same pools."""
+    from oracle import ir_flow, ridge_flow
+    mesh = get_mesh("QU480")
+    cfg = {"config_elastic_subcycle_number": 60, "config_use_column_package": True}
+    ref = cases.make_domain(mesh, "QU480", configs=cfg, open_water_band=(-0.2, 0.3))
+    b = ref.blocklist[0]
+    pools.allocate_ridging_pools(b)
+    nC = mesh.nCells
+    b.structs["icestate"]["openWaterArea"][:nC] = 1.0 - b.structs["tracers"]["iceAreaCategory"][0, :, :nC].sum(axis=0)
+    b.structs["ocean_fluxes"]["oceanFreshWaterFlux"][:nC] = 1.0e-6
+    b.structs["tracers"]["snowEnthalpy"][..., :nC] -= 0.25e8   # snow below the melting point (the clean-up zaps warmer snow)
+    case, res = str(tmp_path / "case.bin"), str(tmp_path / "result.bin")
+    fortran_case.write_pools(case, ref)
+    oracle.seaice_init_velocity_solver(ref)
+    ir_flow.seaice_init_advection(ref)
+    for _ in range(2):
+        ridge_flow.column_reinitialize_diagnostics_dynamics(ref)
+        oracle.seaice_run_velocity_solver(ref)
+        ir_flow.seaice_run_advection(ref)
+        ridge_flow.column_dynamics_time_integration(ref)
+    _harness(case, res, 2)
+    got = fortran_case.read_pools(res)
+    worst = {}
+    _compare(got, b, vs.RUN_OUTPUTS, worst)
+    _compare(got, b, [("tracers", t) for t in TRACERS], worst)
+    from mpas_seaice_amd import column
+    _compare(got, b, list(column.AGGREGATE_FIELDS) + [("tracers_aggregate", t + "Cell") for t in column.AGGREGATED_TRACERS]
+             + [("ridging", k) for k in pools.RIDGING_CELL_FIELDS + pools.RIDGING_CATEGORY_FIELDS]
+             + [("ocean_fluxes", k) for k in ("oceanFreshWaterFlux", "oceanHeatFlux", "oceanSaltFlux")]
+             + [("biogeochemistry", "newlyFormedIce")], worst)
+    assert got[("ridging", "areaLossRidge")][0].max() > 0.0
+    assert np.abs(got[("diagnostics", "iceVolumeTendencyTransport")][0]).max() > 0.0
+    assert got[("initial", "categoryThicknessLimits")][0][-1] == 1.0e8
+    print("worst:", max(worst.items(), key=lambda kv: kv[1]))
