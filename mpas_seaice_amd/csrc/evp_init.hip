@@ -96,11 +96,17 @@ struct WachCell {
 
 __device__ inline int wrapIdx(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
 
+// The functions below take the polygon's number of vertices as a template parameter N (4 to 7: every loop bound and
+// every index into the polygon's arrays is then a constant, and the arrays are registers; with run-time bounds they
+// lived in scratch memory and the integrals of QU60 took 29 ms) or N = 0 for any other polygon (bounds from w.n).
+#define WACH_N(w) (N ? N : (w).n)
+
 // variational_shared.F:191-279 with mesh.F:2021-2061, 2272-2332 (sphere) or :125-177 (plane);
 // then calc_wachspress_coefficients wachspress.F:535-614
-__device__ void wachSetup(WachCell &w, const InitArgs &a, int c)
+template <int N>
+__device__ __forceinline__ void wachSetup(WachCell &w, const InitArgs &a, int c)
 {
-    int n = a.nEdgesOnCell[c];
+    const int n = N ? N : a.nEdgesOnCell[c];
     w.n = n;
     if (a.onASphere) {
         double xc, yc, zc;
@@ -129,6 +135,7 @@ __device__ void wachSetup(WachCell &w, const InitArgs &a, int c)
             n1 = 0.0;
             n2 = 1.0;
         }
+#pragma unroll
         for (int i = 0; i < n; i++) {
             int v = a.voc[i * a.padC + c];
             double px, py, pz;
@@ -137,12 +144,14 @@ __device__ void wachSetup(WachCell &w, const InitArgs &a, int c)
             w.y[i] = px * n0 + py * n1 + pz * n2;
         }
     } else {
+#pragma unroll
         for (int i = 0; i < n; i++) {
             int v = a.voc[i * a.padC + c];
             w.x[i] = a.xVertex[v] - a.xCell[c];
             w.y[i] = a.yVertex[v] - a.yCell[c];
         }
     }
+#pragma unroll
     for (int i = 0; i < n; i++) {
         int i1 = wrapIdx(i - 1, n), i2 = i;
         double den = w.x[i1] * w.y[i2] - w.x[i2] * w.y[i1];
@@ -150,6 +159,7 @@ __device__ void wachSetup(WachCell &w, const InitArgs &a, int c)
         w.B[i] = (w.x[i1] - w.x[i2]) / (w.x[i1] * w.y[i2] - w.x[i2] * w.y[i1]);
     }
     w.kappa[0] = 1.0;
+#pragma unroll
     for (int j = 1; j < n; j++) {
         int i0 = j - 1, i1 = j, i2 = wrapIdx(j + 1, n);
         w.kappa[j] = w.kappa[j - 1] * (w.A[i2] * (w.x[i0] - w.x[i1]) + w.B[i2] * (w.y[i0] - w.y[i1])) /
@@ -157,26 +167,34 @@ __device__ void wachSetup(WachCell &w, const InitArgs &a, int c)
     }
 }
 
-__device__ inline double wachEdge(const WachCell &w, int k, double x, double y) { return 1.0 - w.A[k] * x - w.B[k] * y; }
+__device__ __forceinline__ double wachEdge(const WachCell &w, int k, double x, double y) { return 1.0 - w.A[k] * x - w.B[k] * y; }
 
-// numerator j = kappa_j * prod over edges k not in {j, j+1}, ascending k (wachspress.F:628-668, 864-925)
-__device__ double wachNumerator(const WachCell &w, int j, double x, double y)
+// numerator j = kappa_j * prod over edges k not in {j, j+1}, ascending k (wachspress.F:628-668, 864-925); j is a
+// loop constant of the caller
+template <int N>
+__device__ __forceinline__ double wachNumerator(const WachCell &w, int j, double x, double y)
 {
-    int skip2 = wrapIdx(j + 1, w.n);
+    const int n = WACH_N(w);
+    int skip2 = wrapIdx(j + 1, n);
     double num = 1.0;
-    for (int k = 0; k < w.n; k++)
+#pragma unroll
+    for (int k = 0; k < n; k++)
         if (k != j && k != skip2) num = num * wachEdge(w, k, x, y);
     return num * w.kappa[j];
 }
 
 // wachspress.F:939-1035
-__device__ void wachNumeratorDerivative(const WachCell &w, int j, double x, double y, double &dU, double &dV)
+template <int N>
+__device__ __forceinline__ void wachNumeratorDerivative(const WachCell &w, int j, double x, double y, double &dU, double &dV)
 {
-    int skip2 = wrapIdx(j + 1, w.n);
+    const int n = WACH_N(w);
+    int skip2 = wrapIdx(j + 1, n);
     double sumU = 0.0, sumV = 0.0;
-    for (int k = 0; k < w.n; k++) {
+#pragma unroll
+    for (int k = 0; k < n; k++) {
         if (k == j || k == skip2) continue;
         double pU = 1.0, pV = 1.0;
+#pragma unroll
         for (int l = 0; l < k; l++) {
             if (l == j || l == skip2) continue;
             double e = wachEdge(w, l, x, y);
@@ -185,7 +203,8 @@ __device__ void wachNumeratorDerivative(const WachCell &w, int j, double x, doub
         }
         pU = pU * (-w.A[k]);
         pV = pV * (-w.B[k]);
-        for (int l = k + 1; l < w.n; l++) {
+#pragma unroll
+        for (int l = k + 1; l < n; l++) {
             if (l == j || l == skip2) continue;
             double e = wachEdge(w, l, x, y);
             pU = pU * e;
@@ -198,15 +217,18 @@ __device__ void wachNumeratorDerivative(const WachCell &w, int j, double x, doub
     dV = sumV * w.kappa[j];
 }
 
-// wachspress.F:763-850
-__device__ void wachBasisDerivative(const WachCell &w, int i, double x, double y, double &dU, double &dV)
+// wachspress.F:763-850; i is a run-time index
+template <int N>
+__device__ __forceinline__ void wachBasisDerivative(const WachCell &w, int i, double x, double y, double &dU, double &dV)
 {
+    const int n = WACH_N(w);
     double den = 0.0, sU = 0.0, sV = 0.0, numi = 0.0, dUi = 0.0, dVi = 0.0;
-    for (int j = 0; j < w.n; j++) {
-        double num = wachNumerator(w, j, x, y);
+#pragma unroll
+    for (int j = 0; j < n; j++) {
+        double num = wachNumerator<N>(w, j, x, y);
         den = den + num;
         double du, dv;
-        wachNumeratorDerivative(w, j, x, y, du, dv);
+        wachNumeratorDerivative<N>(w, j, x, y, du, dv);
         sU = sU + du;
         sV = sV + dv;
         if (j == i) {
@@ -219,8 +241,30 @@ __device__ void wachBasisDerivative(const WachCell &w, int i, double x, double y
     dV = dVi / den - (numi / (den * den)) * sV;
 }
 
-// calculate_wachspress_derivatives, wachspress.F:1083-1206: one thread per (cell, basis vertex)
-__global__ void k_wach_gradients(InitArgs a)
+// calculate_wachspress_derivatives, wachspress.F:1083-1206, for basis vertex ib of cell c
+template <int N>
+__device__ __forceinline__ void wachGradientsOf(const InitArgs &a, int c, int ib)
+{
+    const int M = a.M;
+    WachCell w;
+    wachSetup<N>(w, a, c);
+    const int n = WACH_N(w);
+    if (ib >= n) return;
+    // the gradient of basis function ib at its own vertex and at the two beside it (it vanishes at the others); the
+    // loop runs over all vertices with a constant index, so that no array of the polygon is indexed by a variable
+    const int before = wrapIdx(ib - 1, n), after = wrapIdx(ib + 1, n);
+#pragma unroll
+    for (int g = 0; g < n; g++) {
+        if (g != ib && g != before && g != after) continue;
+        double du, dv;
+        wachBasisDerivative<N>(w, ib, w.x[g], w.y[g], du, dv);
+        a.gradU[(size_t)(g * M + ib) * a.padC + c] = du;
+        a.gradV[(size_t)(g * M + ib) * a.padC + c] = dv;
+    }
+}
+
+// one thread per (cell, basis vertex)
+__global__ void __launch_bounds__(64) k_wach_gradients(InitArgs a)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     int c = t % a.nCells, ib = t / a.nCells;
@@ -230,34 +274,45 @@ __global__ void k_wach_gradients(InitArgs a)
         a.gradU[(size_t)(g * M + ib) * a.padC + c] = 0.0;
         a.gradV[(size_t)(g * M + ib) * a.padC + c] = 0.0;
     }
-    WachCell w;
-    wachSetup(w, a, c);
-    if (ib >= w.n) return;
-    int gs[3] = {ib, wrapIdx(ib - 1, w.n), wrapIdx(ib + 1, w.n)};
-    for (int q = 0; q < 3; q++) {
-        int g = gs[q];
-        double du, dv;
-        wachBasisDerivative(w, ib, w.x[g], w.y[g], du, dv);
-        a.gradU[(size_t)(g * M + ib) * a.padC + c] = du;
-        a.gradV[(size_t)(g * M + ib) * a.padC + c] = dv;
+    switch (a.nEdgesOnCell[c]) {
+    case 4: wachGradientsOf<4>(a, c, ib); break;
+    case 5: wachGradientsOf<5>(a, c, ib); break;
+    case 6: wachGradientsOf<6>(a, c, ib); break;
+    case 7: wachGradientsOf<7>(a, c, ib); break;
+    default: break;  // k_wach_gradients_any
     }
 }
 
-// integrate_wachspress / integrate_wachspress_polygon, wachspress.F:179-467:
-// one thread per (cell, velocity vertex j); accumulates the column (:, j) of the three integrals
-__global__ void k_wach_integrals(InitArgs a)
+// The same for the polygons the kernel above leaves out (triangles, octagons and beyond), with run-time loop bounds.
+// A kernel of its own, launched only on a mesh that has such cells: its arrays live in scratch memory, and a kernel
+// that declares scratch memory is given some whether or not a wave takes that path.
+__global__ void __launch_bounds__(64) k_wach_gradients_any(InitArgs a)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
-    int c = t % a.nCells, j = t / a.nCells;
-    if (j >= a.M) return;
+    int c = t % a.nCells, ib = t / a.nCells;
+    if (ib >= a.M) return;
+    const int n = a.nEdgesOnCell[c];
+    if (n >= 4 && n <= 7) return;
+    wachGradientsOf<0>(a, c, ib);
+}
+
+// integrate_wachspress / integrate_wachspress_polygon, wachspress.F:179-467, for velocity vertex j of cell c:
+// accumulates the column (:, j) of the three integrals
+template <int N>
+__device__ __forceinline__ void wachIntegralsOf(const InitArgs &a, int c, int j)
+{
+    constexpr int NA = N ? N : SIH_MAXE;
     const int M = a.M;
-    double SU[SIH_MAXE], SV[SIH_MAXE], SM[SIH_MAXE];
-    for (int s = 0; s < SIH_MAXE; s++) SU[s] = SV[s] = SM[s] = 0.0;
+    double SU[NA], SV[NA], SM[NA];
+#pragma unroll
+    for (int s = 0; s < NA; s++) SU[s] = SV[s] = SM[s] = 0.0;
     WachCell w;
-    wachSetup(w, a, c);
-    if (j < w.n) {
-        for (int tri = 0; tri < w.n; tri++) {
-            int i1 = tri, i2 = wrapIdx(tri + 1, w.n);
+    wachSetup<N>(w, a, c);
+    const int n = WACH_N(w);
+    if (j < n) {
+#pragma unroll
+        for (int tri = 0; tri < n; tri++) {
+            int i1 = tri, i2 = wrapIdx(tri + 1, n);
             // get_triangle_mapping (:485-517) from the unit triangle (1,0),(0,1)
             double x1 = 1.0, y1 = 0.0, x2 = 0.0, y2 = 1.0;
             double u1 = w.x[i1], v1 = w.y[i1], u2 = w.x[i2], v2 = w.y[i2];
@@ -266,39 +321,78 @@ __global__ void k_wach_integrals(InitArgs a)
             double m21 = (v2 * y1 - v1 * y2) / (x2 * y1 - x1 * y2);
             double m22 = (v1 * x2 - v2 * x1) / (y1 * x2 - y2 * x1);
             double jac = m11 * m22 - m12 * m21;
-            double sU[SIH_MAXE], sV[SIH_MAXE], sM[SIH_MAXE];
-            for (int s = 0; s < SIH_MAXE; s++) sU[s] = sV[s] = sM[s] = 0.0;
+            double sU[NA], sV[NA], sM[NA];
+#pragma unroll
+            for (int s = 0; s < NA; s++) sU[s] = sV[s] = sM[s] = 0.0;
             for (int p = 0; p < a.nQ; p++) {
                 double px = m11 * a.qU[p] + m12 * a.qV[p];
                 double py = m21 * a.qU[p] + m22 * a.qV[p];
-                double num[SIH_MAXE], den = 0.0;
-                for (int s = 0; s < w.n; s++) {
-                    num[s] = wachNumerator(w, s, px, py);
+                double num[NA], den = 0.0, numj = 0.0;
+#pragma unroll
+                for (int s = 0; s < n; s++) {
+                    num[s] = wachNumerator<N>(w, s, px, py);
                     den = den + num[s];
+                    numj = s == j ? num[s] : numj;
                 }
                 double dNu, dNv;
-                wachBasisDerivative(w, j, px, py, dNu, dNv);
-                double Nj = num[j] / den;
-                for (int s = 0; s < w.n; s++) {
+                wachBasisDerivative<N>(w, j, px, py, dNu, dNv);
+                double Nj = numj / den;
+#pragma unroll
+                for (int s = 0; s < n; s++) {
                     double tmp = jac * a.qW[p] * (num[s] / den);
                     sU[s] = sU[s] + tmp * dNu;
                     sV[s] = sV[s] + tmp * dNv;
                     sM[s] = sM[s] + tmp * Nj;
                 }
             }
-            for (int s = 0; s < w.n; s++) {
+#pragma unroll
+            for (int s = 0; s < n; s++) {
                 SU[s] = SU[s] + sU[s] / a.qNorm;
                 SV[s] = SV[s] + sV[s] / a.qNorm;
                 SM[s] = SM[s] + sM[s] / a.qNorm;
             }
         }
     }
-    for (int s = 0; s < M; s++) {  // host index (iStress s, iVelocity j) -> lead j*M + s
+    // host index (iStress s, iVelocity j) -> lead j*M + s
+#pragma unroll
+    for (int s = 0; s < NA; s++)
+        if (s < M) {
+            size_t k = (size_t)(j * M + s) * a.padC + c;
+            a.SU[k] = SU[s];
+            a.SV[k] = SV[s];
+            a.SM[k] = SM[s];
+        }
+    for (int s = NA; s < M; s++) {
         size_t k = (size_t)(j * M + s) * a.padC + c;
-        a.SU[k] = (s < SIH_MAXE) ? SU[s] : 0.0;
-        a.SV[k] = (s < SIH_MAXE) ? SV[s] : 0.0;
-        a.SM[k] = (s < SIH_MAXE) ? SM[s] : 0.0;
+        a.SU[k] = 0.0;
+        a.SV[k] = 0.0;
+        a.SM[k] = 0.0;
     }
+}
+
+// one thread per (cell, velocity vertex j)
+__global__ void __launch_bounds__(64) k_wach_integrals(InitArgs a)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int c = t % a.nCells, j = t / a.nCells;
+    if (j >= a.M) return;
+    switch (a.nEdgesOnCell[c]) {
+    case 4: wachIntegralsOf<4>(a, c, j); break;
+    case 5: wachIntegralsOf<5>(a, c, j); break;
+    case 6: wachIntegralsOf<6>(a, c, j); break;
+    case 7: wachIntegralsOf<7>(a, c, j); break;
+    default: break;  // k_wach_integrals_any
+    }
+}
+
+__global__ void __launch_bounds__(64) k_wach_integrals_any(InitArgs a)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int c = t % a.nCells, j = t / a.nCells;
+    if (j >= a.M) return;
+    const int n = a.nEdgesOnCell[c];
+    if (n >= 4 && n <= 7) return;
+    wachIntegralsOf<0>(a, c, j);
 }
 
 // ---- piecewise-linear basis (mpas_seaice_velocity_solver_pwl.F:44-373) ----------------------------
@@ -380,7 +474,7 @@ __global__ void k_pwl_basis(InitArgs a)
         a.SM[(size_t)k * pc + c] = 0.0;
     }
     WachCell w;  // only its local coordinates are used (seaice_calc_local_coords)
-    wachSetup(w, a, c);
+    wachSetup<0>(w, a, c);
     const int n = w.n;
     if (n < 3) return;
     const double alpha = 1.0 / (double)n;

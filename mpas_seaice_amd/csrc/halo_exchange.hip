@@ -23,6 +23,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -59,6 +60,47 @@ struct CommTable {  // one field group
     int nPlanesC = 0, nPlanesV = 0;
     bool isInt = false;
 };
+
+// Receive buffers are uncached (or fine-grained) device memory, and such memory is never given back to the runtime
+// while the process lives: ordinary allocations that came to lie on a freed uncached buffer were seen to hand later
+// kernels the words of earlier exchanges (fields of contexts created afterwards held halo payloads; with ordinary
+// memory for the buffer, or with the buffer kept, never).  A freed context's buffer waits here for the next
+// sih_comm_create on the same device; the buffers are a few megabytes.
+struct CommBufferSlot {
+    char *p;
+    size_t bytes;
+    int device;
+    bool inUse;
+};
+static std::vector<CommBufferSlot> g_commBuffers;
+static std::mutex g_commBuffersMutex;
+
+static char *takeCommBuffer(int device, size_t bytes)
+{
+    std::lock_guard<std::mutex> lock(g_commBuffersMutex);
+    for (CommBufferSlot &b : g_commBuffers)
+        if (!b.inUse && b.device == device && b.bytes >= bytes) {
+            b.inUse = true;
+            return b.p;
+        }
+    return nullptr;
+}
+static void keepCommBuffer(char *p, size_t bytes, int device)
+{
+    std::lock_guard<std::mutex> lock(g_commBuffersMutex);
+    g_commBuffers.push_back({p, bytes, device, true});
+}
+// true if the buffer is one of the kept ones (then it is marked free for reuse and must not be hipFree'd)
+static bool releaseCommBuffer(char *p)
+{
+    std::lock_guard<std::mutex> lock(g_commBuffersMutex);
+    for (CommBufferSlot &b : g_commBuffers)
+        if (b.p == p) {
+            b.inUse = false;
+            return true;
+        }
+    return false;
+}
 
 struct sih_comm_state {
     int rank = 0, nRanks = 0;
@@ -258,7 +300,7 @@ void sih_comm_free(sih_ctx *c)
         if (q) (void)hipFree(q);
     for (auto &kv : s->tables)
         if (kv.second.d_planes) (void)hipFree(kv.second.d_planes);
-    if (s->base) (void)hipFree(s->base);
+    if (s->base && !releaseCommBuffer(s->base)) (void)hipFree(s->base);
     if (s->evFork) (void)hipEventDestroy(s->evFork);
     if (s->evJoin) (void)hipEventDestroy(s->evJoin);
     if (s->commStream) (void)hipStreamDestroy(s->commStream);
@@ -342,15 +384,19 @@ extern "C" int sih_comm_create(sih_ctx *c, int rank, int nRanks, int maxCellPlan
     s->generation = ++generations;
     // uncached device memory where the runtime has it (remote stores and local polls then never meet a stale
     // cache line); fine-grained or ordinary memory otherwise -- every access is a system-scope atomic anyway
-    void *p = nullptr;
-    hipError_t e = hipExtMallocWithFlags(&p, s->allocBytes, hipDeviceMallocUncached);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        e = hipExtMallocWithFlags(&p, s->allocBytes, hipDeviceMallocFinegrained);
-    }
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        HIPCHK(hipMalloc(&p, s->allocBytes));
+    void *p = takeCommBuffer(c->device, s->allocBytes);
+    if (!p) {
+        hipError_t e = hipExtMallocWithFlags(&p, s->allocBytes, hipDeviceMallocUncached);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            e = hipExtMallocWithFlags(&p, s->allocBytes, hipDeviceMallocFinegrained);
+        }
+        if (e == hipSuccess) {
+            keepCommBuffer((char *)p, s->allocBytes, c->device);
+        } else {
+            (void)hipGetLastError();
+            HIPCHK(hipMalloc(&p, s->allocBytes));
+        }
     }
     s->base = (char *)p;
     HIPCHK(hipMemset(s->base, 0, s->allocBytes));
