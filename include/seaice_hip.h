@@ -470,6 +470,9 @@ size_t sih_comm_handle_size(void);
 int sih_comm_create(sih_ctx *ctx, int rank, int nRanks, int maxCellPlanes, int maxVertexPlanes);
 int sih_comm_get_handle(sih_ctx *ctx, void *handle);
 int sih_comm_connect(sih_ctx *ctx, const void *allHandles);
+/* releases the tables of the transport.  The receive buffer itself (uncached device memory, a few megabytes) is not
+ * given back to the runtime but kept for the next sih_comm_create on the same device: memory that ordinary allocations
+ * took over from a freed uncached buffer was seen to show kernels the payload of earlier exchanges. */
 int sih_comm_destroy(sih_ctx *ctx);
 /* One halo update of the named fields (cell and vertex fields may be mixed; all float64 or all int32),
  * asynchronous on the context's stream.  _start sends only, _finish waits for the neighbours and fills the halo:
