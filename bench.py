@@ -468,6 +468,10 @@ def main():
                      # the same kernel time against the bytes this layout really has to move (compact gradients)
                      # and, when the counters are current, against the bytes they counted
                      "layout_bytes_per_launch": layout_bytes,
+                     # what the layout leaves out of the algorithmic bytes: the compact gradients always; one side of the
+                     # mirrored metric integrals and the corner's own gradient unless switched off in the environment
+                     "layout": {"compact_gradients": True, "symmetric_metric_integrals": bool(sym_metric),
+                                "derived_corner_gradient": bool(derived_grad)},
                      "frac_layout": (layout_bytes / (cell_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if cell_ms > 0 else 0.0,
                      "frac_counter": (traffic / (cell_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and cell_ms > 0 else None,
                      "traffic_source": traffic_note},
