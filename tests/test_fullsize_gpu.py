@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from mpas_seaice_amd import advection as adv, cases, parallel, velocity_solver as vs
+from mpas_seaice_amd import advection as adv, cases, column, parallel, pools, time_integration, velocity_solver as vs
 from util import compare_domains, get_mesh
 
 pytestmark = pytest.mark.gpu
@@ -85,6 +85,52 @@ def test_qu60_advection_invariants(qu60, device_qu60):
     assert tp["iceVolumeCategory"].min() >= 0.0 and tp["snowVolumeCategory"].min() >= 0.0
     for n in TRACERS:
         assert np.isfinite(tp[n]).all(), n
+
+
+def test_qu60_dynamics_step_with_ridging_and_aggregation_properties(qu60):
+    """Two dynamics subcycles (velocity solver -> incremental remap -> ridging -> aggregation) with everything on the
+    device, at the benchmark's size, where the oracle would take minutes: what must hold whatever the size.  The ridging
+    closes the area sum, ice volume only moves between cells (advection) and categories (ridging), and the aggregate
+    fields are the sums over the categories of what the step left."""
+    cfg = {"config_use_column_package": True, "config_dynamics_subcycle_number": 2,
+           "config_elastic_subcycle_number": 60}
+    dom = cases.make_domain(qu60, "QU60", configs=cfg, open_water_band=(-0.2, 0.3))
+    b = dom.blocklist[0]
+    pools.allocate_ridging_pools(b)
+    nC = qu60.nCells
+    tr = b.structs["tracers"]
+    b.structs["icestate"]["openWaterArea"][:nC] = 1.0 - tr["iceAreaCategory"][0, :, :nC].sum(axis=0)
+    tr["snowEnthalpy"][..., :nC] -= 0.25e8   # snow well below the melting point (the clean-up sends warm snow to the ocean)
+    area = np.asarray(b.structs["mesh"]["areaCell"][:nC])
+    vol0 = float((tr["iceVolumeCategory"][0, :, :nC].sum(axis=0) * area).sum())
+    vs.seaice_mesh_pool_create(dom)
+    try:
+        vs.seaice_init_velocity_solver(dom)
+        adv.seaice_init_advection(dom)
+        time_integration.seaice_timestep_dynamics(dom, column_dynamics="device")
+    finally:
+        vs.seaice_mesh_pool_destroy(dom)
+    a = tr["iceAreaCategory"][0, :, :nC]
+    v = tr["iceVolumeCategory"][0, :, :nC]
+    for n in TRACERS:
+        assert np.isfinite(tr[n][..., :nC]).all(), n
+    assert a.min() >= 0.0 and v.min() >= 0.0 and tr["snowVolumeCategory"][0, :, :nC].min() >= 0.0
+    water = b.structs["icestate"]["openWaterArea"][:nC]
+    assert water.min() >= 0.0
+    assert np.abs(a.sum(axis=0) + water - 1.0).max() <= 1e-12      # ridge_ice ends with the area sum closed
+    rg = b.structs["ridging"]
+    assert rg["ridgeConvergence"][:nC].max() > 0.0 and np.isfinite(rg["areaLossRidge"][:nC]).all()
+    assert rg["areaLossRidge"][:nC].max() > 0.0                    # converging ice did ridge somewhere
+    vol1 = float((v.sum(axis=0) * area).sum())
+    assert abs(vol1 - vol0) <= 1e-9 * vol0, (vol0, vol1)           # (the clean-up may send areas below 1e-11 to the ocean)
+    ag = b.structs["tracers_aggregate"]
+    assert np.abs(ag["iceAreaCell"][:nC] - a.sum(axis=0)).max() <= 4e-16 * 5
+    assert np.abs(ag["iceVolumeCell"][:nC] - v.sum(axis=0)).max() <= 1e-15 * v.sum(axis=0).max()
+    tend = b.structs["diagnostics"]["iceVolumeTendencyTransport"][:nC]
+    assert np.isfinite(tend).all() and np.abs(tend).max() > 0.0
+    # volume that the transport of the last subcycle took from some cells arrived in others
+    dt = float(b.structs["velocity_solver"]["dynamicsTimeStep"][0])
+    assert abs(float((tend * area).sum()) * dt) <= 1e-9 * vol0
 
 
 def test_qu60_two_blocks_with_deep_halos_and_overlap_equal_one_block(qu60, device_qu60):
