@@ -746,7 +746,39 @@ __global__ void k_store_derived_gradients(InitArgs a)
     }
 }
 
-static int packStatic(sih_ctx *c, const InitArgs &a)
+// basisIntegralsU(s, j) = integral of N_s dN_j/dx (wachspress.F:436-441; plane j * M + s here): the basis functions sum to
+// one, so for every stress corner s the entries of the velocity corners j sum to zero up to rounding.  In a cell where
+// that holds for U and V and every s, the row of the first velocity corner is replaced by minus the sum of the other
+// rows, added in ascending j -- the value changes in its last places at most -- and the cell is marked (bit 9 of
+// nEdgesDerive).  The split cell kernel then forms that row on the chip from what the cell's other corners fetch,
+// with the same additions, and every other kernel computes with the same bits from the stored row.  (Cell by cell,
+// from the cell's own numbers: the same in every block that holds the cell.)
+__global__ void k_derive_integral_rows(InitArgs a)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.nCells) return;
+    const int M = a.M, E = a.nEdgesOnCell[c];
+    if (E < 3) return;
+    bool ok = true;
+    for (int uv = 0; uv < 2; uv++) {
+        const double *S = uv ? a.SV : a.SU;
+        for (int s = 0; s < E; s++) {
+            double acc = S[(size_t)(1 * M + s) * a.padC + c], big = fabs(acc);
+            for (int j = 2; j < E; j++) {
+                const double x = S[(size_t)(j * M + s) * a.padC + c];
+                acc = acc + x;
+                big = fmax(big, fabs(x));
+            }
+            const double own = S[(size_t)s * a.padC + c];
+            big = fmax(big, fabs(own));
+            if (!(fabs(-acc - own) <= 1.0e-13 * big)) ok = false;
+        }
+    }
+    if (!ok) return;
+    a.nEdgesDerive[c] |= 512;
+}
+
+static int packStatic(sih_ctx *c, const InitArgs &a, bool ownArrays)
 {
     hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(64), 0, c->stream, c->d_flag, 16);
     hipLaunchKernelGGL(k_pack_gradients, dim3((c->nCells + 255) / 256), dim3(256), 0, c->stream, a);
@@ -764,6 +796,17 @@ static int packStatic(sih_ctx *c, const InitArgs &a)
     }
     if (c->deriveGrad) {
         hipLaunchKernelGGL(k_store_derived_gradients, dim3((c->nCells + 255) / 256), dim3(256), 0, c->stream, a);
+        HIPCHK(hipGetLastError());
+    }
+    {
+        // Only arrays the set-up has just computed itself are touched (not what a host has put since).
+        // SIH_BASIS_INTEGRALS=as_computed: every row of basisIntegralsU / V stays as the reference's arithmetic gives it
+        const char *e = getenv("SIH_BASIS_INTEGRALS");
+        c->deriveRow = ownArrays && c->cfg.strainScheme == 0 && c->cfg.variationalBasis != 0 &&
+                       !(e && strcmp(e, "as_computed") == 0);
+    }
+    if (c->deriveRow) {
+        hipLaunchKernelGGL(k_derive_integral_rows, dim3((c->nCells + 255) / 256), dim3(256), 0, c->stream, a);
         HIPCHK(hipGetLastError());
     }
     return SIH_OK;
@@ -933,7 +976,7 @@ extern "C" int sih_evp_init(sih_ctx *c, const sih_evp_config *cfg)
             hipLaunchKernelGGL(k_mirror_metric, dim3((c->nCells + 255) / 256), block, 0, c->stream, a);
     }
     HIPCHK(hipGetLastError());
-    int rc = packStatic(c, a);
+    int rc = packStatic(c, a, true);
     if (rc) return rc;
     if (cfg->strainScheme == 1 && (rc = sih_weak_init(c))) return rc;
     // time steps and EVP constants: velocity_solver.F:155-157, constitutive_relation.F:125, 158-159
@@ -970,7 +1013,7 @@ extern "C" int sih_evp_static_changed(sih_ctx *c)
     }
     HIPCHK(hipSetDevice(c->device));
     InitArgs a = makeInitArgs(c);
-    int rc = packStatic(c, a);
+    int rc = packStatic(c, a, false);
     sih_drop_graphs(c);  // whatever was captured holds launches of the previous kernel variants
     if (rc) return rc;
     return sih_persist_setup(c);

@@ -102,6 +102,7 @@ struct PersistXchg {
 // vector registers are left for the state a thread keeps
 struct PersistDev {
     int nCells, nVerticesSolve, padC, padV, relation, useOcean, quadratic, haloVertices, symMetric;
+    int deriveRow;  // the arithmetic of k_sub_cells_split with derived integral rows; nEdgesOnCell then carries the marks
     double dtE, dampT, brlx, dtDyn;
     const int *nEdgesOnCell, *voc, *gidx, *vActive, *solveStress, *solveVelocity;
     const double *tanLat, *varDenom, *gradU3, *gradV3, *SU, *SV, *SM, *icePressure;
@@ -116,8 +117,9 @@ static PersistDev makePersistDev(const SihDev &d)
     q.nCells = d.nCells; q.nVerticesSolve = d.nVerticesSolve; q.padC = d.padC; q.padV = d.padV;
     q.relation = d.relation; q.useOcean = d.useOcean; q.quadratic = d.quadratic; q.haloVertices = d.haloVertices;
     q.symMetric = d.symMetric;
+    q.deriveRow = d.deriveRow;
     q.dtE = d.dtE; q.dampT = d.dampT; q.brlx = d.brlx; q.dtDyn = d.dtDyn;
-    q.nEdgesOnCell = d.nEdgesOnCell; q.voc = d.voc; q.gidx = d.gidx; q.vActive = d.vActive;
+    q.nEdgesOnCell = d.deriveRow ? d.nEdgesDerive : d.nEdgesOnCell; q.voc = d.voc; q.gidx = d.gidx; q.vActive = d.vActive;
     q.solveStress = d.solveStress; q.solveVelocity = d.solveVelocity;
     q.tanLat = d.tanLat; q.varDenom = d.varDenom; q.gradU3 = d.gradU3; q.gradV3 = d.gradV3;
     q.SU = d.SU; q.SV = d.SV; q.SM = d.SM; q.icePressure = d.icePressure;
@@ -227,8 +229,11 @@ __global__ void __launch_bounds__(TC * M, 4) k_sub_persistent(PersistDev d, Pers
     if (!inRange) c = 0;
     const size_t k = (size_t)g * P + c;
     const bool solve = inRange && d.solveStress[c] == 1;
-    const int E = inRange ? d.nEdgesOnCell[c] : 0;
+    const int Ev = inRange ? d.nEdgesOnCell[c] : 0;  // (with the set-up's marks above bit 7 when deriveRow is set)
+    const int E = Ev & 255;
     const bool corner = solve && g < E;
+    // corner 0 of this cell takes its sums from the other corners' (k_sub_cells_split has the reasons)
+    const bool cellDerives = solve && d.deriveRow && (Ev & 512);
     const int slot = corner ? p.cornerSlot[k] : 0;
     double tg = 0.0, P_ice = 0.0, o11 = 0.0, o22 = 0.0, o12 = 0.0;
     double gu3[3] = {0.0, 0.0, 0.0}, gv3[3] = {0.0, 0.0, 0.0};
@@ -426,8 +431,8 @@ __global__ void __launch_bounds__(TC * M, 4) k_sub_persistent(PersistDev d, Pers
         s22[g][lane] = a22;
         s12[g][lane] = a12;
         __syncthreads();
-        if (corner) {
-            double cu = 0.0, cv = 0.0;
+        double cu = 0.0, cv = 0.0;
+        if (corner && !d.deriveRow) {
 #pragma unroll
             for (int s = 0; s < M; s++) {
                 if (s < E) {
@@ -437,6 +442,45 @@ __global__ void __launch_bounds__(TC * M, 4) k_sub_persistent(PersistDev d, Pers
                     cv = cv - x22 * bv - x12 * bu + x11 * bm * tg;
                 }
             }
+        }
+        if (d.deriveRow) {  // (the same for every thread of the launch)
+            // k_sub_cells_split's arithmetic with derived rows: the terms with basisIntegralsU / V and the metric terms
+            // added up separately; corner 0 of a marked cell takes minus the sum of the other corners' former
+            double nu = 0.0, nv = 0.0, mu = 0.0, mv = 0.0;
+            if (corner) {
+#pragma unroll
+                for (int s = 0; s < M; s++) {
+                    if (s < E) {
+                        const double x11 = s11[s][lane], x22 = s22[s][lane], x12 = s12[s][lane];
+                        const double bu = sInt[s][tid], bv = sInt[M + s][tid], bm = STREAM ? bmS[s] : sInt[2 * M + s][tid];
+                        mu = mu - x12 * bm * tg;
+                        mv = mv + x11 * bm * tg;
+                        nu = nu - x11 * bu - x12 * bv;
+                        nv = nv - x22 * bv - x12 * bu;
+                    }
+                }
+                cu = nu + mu;
+                cv = nv + mv;
+                if (cellDerives && g > 0) {  // (su / sv: the velocities in them were taken before the barrier above)
+                    su[g][lane] = nu;
+                    sv[g][lane] = nv;
+                }
+            }
+            __syncthreads();
+            if (corner && cellDerives && g == 0) {
+                double du = su[1][lane], dv = sv[1][lane];
+#pragma unroll
+                for (int j = 2; j < M; j++) {
+                    if (j < E) {
+                        du = du + su[j][lane];
+                        dv = dv + sv[j][lane];
+                    }
+                }
+                cu = mu - du;
+                cv = mv - dv;
+            }
+        }
+        if (corner) {
             // the markers of the next buffer (stored one iteration ago) are in memory before these sums can be seen
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stAgent(&pU[k], bitsOf(cu));
@@ -691,7 +735,9 @@ __global__ void __launch_bounds__(64 * M, SIH_FUSED_MIN_WAVES) k_sub_fused(Persi
 {
     __shared__ double su[M][64], sv[M][64], s11[M][64], s22[M][64], s12[M][64];
     __shared__ double uT[64 * M], vT[64 * M], tT[64 * M];
+    __shared__ int arrived;  // waves of the tile that have left their part of corner 0's sums (deriveRow)
     const int lane = threadIdx.x, g = threadIdx.y, tid = g * 64 + lane;
+    if (CELLS && tid == 0) arrived = 0;  // (two barriers before anyone counts)
     int tile;  // consecutive tiles on one XCD, as in the persistent kernel
     {
         const int b = blockIdx.x, q = nT / 8, r = nT % 8, x = b % 8;
@@ -780,7 +826,7 @@ __global__ void __launch_bounds__(64 * M, SIH_FUSED_MIN_WAVES) k_sub_fused(Persi
     double bu[M], bv[M], bm[M];
     {
         solveFlag = d.solveStress[c];
-        E = d.nEdgesOnCell[c];
+        E = d.nEdgesOnCell[c];  // (with the set-up's marks above bit 7 when deriveRow is set; taken off below)
         slot = f.cornerSlot[k];
         P_ice = d.icePressure[c];
         o11 = d.stress11[k];
@@ -794,8 +840,13 @@ __global__ void __launch_bounds__(64 * M, SIH_FUSED_MIN_WAVES) k_sub_fused(Persi
 #pragma unroll
         for (int s = 0; s < M; s++) {
             const size_t kb = (size_t)(g * M + s) * P + c;
-            bu[s] = d.SU[kb];
-            bv[s] = d.SV[kb];
+            // (with deriveRow the corners 0 wait for the cell's mark below before they ask for their rows, if at all)
+            bu[s] = 0.0;
+            bv[s] = 0.0;
+            if (!(d.deriveRow && g == 0)) {
+                bu[s] = d.SU[kb];
+                bv[s] = d.SV[kb];
+            }
             // (a symmetric metric matrix is read from one side of its diagonal only, as in k_sub_cells_split)
             bm[s] = d.SM[d.symMetric ? (size_t)((g > s ? g : s) * M + (g > s ? s : g)) * P + c : kb];
         }
@@ -805,7 +856,19 @@ __global__ void __launch_bounds__(64 * M, SIH_FUSED_MIN_WAVES) k_sub_fused(Persi
     tT[tid] = tl;
     __syncthreads();
     // ---- cells: strain, stress, partial sums of the divergence (k_sub_cells_split)
+    const bool rowCell = d.deriveRow && (E & 512);
+    E &= 255;
     const bool corner = inRange && solveFlag == 1 && g < E;
+    const bool cellDerives = inRange && solveFlag == 1 && rowCell;
+    if (d.deriveRow && g == 0 && corner && !rowCell) {  // a cell without the mark: corner 0 computes from its own rows
+#pragma unroll
+        for (int s = 0; s < M; s++) {
+            if (s < E) {
+                bu[s] = d.SU[(size_t)s * P + c];
+                bv[s] = d.SV[(size_t)s * P + c];
+            }
+        }
+    }
     const double ug = uT[slot], vg = vT[slot], tg = tT[slot];
     su[g][lane] = corner ? ug : 0.0;
     sv[g][lane] = corner ? vg : 0.0;
@@ -873,18 +936,61 @@ __global__ void __launch_bounds__(64 * M, SIH_FUSED_MIN_WAVES) k_sub_fused(Persi
     s22[g][lane] = a22;
     s12[g][lane] = a12;
     __syncthreads();
+    if (!d.deriveRow) {  // (the same for every thread of the launch)
+        if (corner) {
+            double cu = 0.0, cv = 0.0;
+#pragma unroll
+            for (int s = 0; s < M; s++) {
+                if (s < E) {
+                    const double x11 = s11[s][lane], x22 = s22[s][lane], x12 = s12[s][lane];
+                    cu = cu - x11 * bu[s] - x12 * bv[s] - x12 * bm[s] * tg;
+                    cv = cv - x22 * bv[s] - x12 * bu[s] + x11 * bm[s] * tg;
+                }
+            }
+            f.sumsOut[k] = cu;
+            f.sumsOut[(size_t)M * P + k] = cv;
+        }
+        return;
+    }
+    // k_sub_cells_split's arithmetic with derived rows: the terms with basisIntegralsU / V and the metric terms added
+    // up separately; corner 0 of a marked cell takes minus the sum of the other corners' former, which the wave that
+    // comes last adds up for the tile's 64 cells
+    double nu = 0.0, nv = 0.0, mu = 0.0, mv = 0.0;
     if (corner) {
-        double cu = 0.0, cv = 0.0;
 #pragma unroll
         for (int s = 0; s < M; s++) {
             if (s < E) {
                 const double x11 = s11[s][lane], x22 = s22[s][lane], x12 = s12[s][lane];
-                cu = cu - x11 * bu[s] - x12 * bv[s] - x12 * bm[s] * tg;
-                cv = cv - x22 * bv[s] - x12 * bu[s] + x11 * bm[s] * tg;
+                mu = mu - x12 * bm[s] * tg;
+                mv = mv + x11 * bm[s] * tg;
+                nu = nu - x11 * bu[s] - x12 * bv[s];
+                nv = nv - x22 * bv[s] - x12 * bu[s];
             }
         }
-        f.sumsOut[k] = cu;
-        f.sumsOut[(size_t)M * P + k] = cv;
+        if (cellDerives) {  // (su / sv: the velocities in them were taken before the barrier above)
+            su[g][lane] = g == 0 ? mu : nu;
+            sv[g][lane] = g == 0 ? mv : nv;
+        }
+    }
+    int lastWave = 0;
+    if (lane == 0)
+        lastWave = __hip_atomic_fetch_add(&arrived, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == M - 1 ? 1 : 0;
+    lastWave = __builtin_amdgcn_readfirstlane(lastWave);
+    if (corner && !(cellDerives && g == 0)) {
+        f.sumsOut[k] = nu + mu;
+        f.sumsOut[(size_t)M * P + k] = nv + mv;
+    }
+    if (lastWave && cellDerives) {
+        double du = su[1][lane], dv = sv[1][lane];
+#pragma unroll
+        for (int j = 2; j < M; j++) {
+            if (j < E) {
+                du = du + su[j][lane];
+                dv = dv + sv[j][lane];
+            }
+        }
+        f.sumsOut[c] = su[0][lane] - du;
+        f.sumsOut[(size_t)M * P + c] = sv[0][lane] - dv;
     }
 }
 

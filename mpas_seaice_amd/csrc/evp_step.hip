@@ -142,6 +142,7 @@ void sih_bind_dev(sih_ctx *c)
     d.haloVertices = c->cfg.computeHaloVertices ? 1 : 0;
     d.symMetric = c->symMetric ? 1 : 0;
     d.deriveGrad = c->deriveGrad ? 1 : 0;
+    d.deriveRow = c->deriveRow ? 1 : 0;
 }
 
 __device__ inline double sign1(double x) { return copysign(1.0, x); }
@@ -600,22 +601,61 @@ __global__ void __launch_bounds__(256) k_sub_cells(SihDev d, const int *__restri
     }
     if (MODE == 1) return;
     // per-corner partial sums of the stress divergence
+    if (!d.deriveRow) {
 #pragma unroll
-    for (int j = 0; j < M; j++) {
+        for (int j = 0; j < M; j++) {
+            if (j < E) {
+                double cu = 0.0, cv = 0.0;
+                const double tj = t[j];
+#pragma unroll
+                for (int s = 0; s < M; s++) {
+                    if (s < E) {
+                        const size_t kb = (size_t)(j * M + s) * P + c;
+                        const double bu = d.SU[kb], bv = d.SV[kb], bm = d.SM[kb];
+                        cu = cu - s11[s] * bu - s12[s] * bv - s12[s] * bm * tj;
+                        cv = cv - s22[s] * bv - s12[s] * bu + s11[s] * bm * tj;
+                    }
+                }
+                d.partU[(size_t)j * P + c] = cu;
+                d.partV[(size_t)j * P + c] = cv;
+            }
+        }
+        return;
+    }
+    // the arithmetic of k_sub_cells_split with deriveRow: the terms with basisIntegralsU / V (nu, nv) and the metric
+    // terms (mu, mv) are added up separately, and in a marked cell corner 0 takes minus the other corners' nu, nv
+    const bool rowCell = (d.nEdgesDerive[c] & 512) != 0;
+    double du = 0.0, dv = 0.0;
+#pragma unroll
+    for (int jj = 1; jj <= M; jj++) {
+        const int j = jj == M ? 0 : jj;  // corner 0 last
         if (j < E) {
-            double cu = 0.0, cv = 0.0;
+            double nu = 0.0, nv = 0.0, mu = 0.0, mv = 0.0;
             const double tj = t[j];
 #pragma unroll
             for (int s = 0; s < M; s++) {
                 if (s < E) {
                     const size_t kb = (size_t)(j * M + s) * P + c;
-                    const double bu = d.SU[kb], bv = d.SV[kb], bm = d.SM[kb];
-                    cu = cu - s11[s] * bu - s12[s] * bv - s12[s] * bm * tj;
-                    cv = cv - s22[s] * bv - s12[s] * bu + s11[s] * bm * tj;
+                    const double bm = d.SM[kb];
+                    mu = mu - s12[s] * bm * tj;
+                    mv = mv + s11[s] * bm * tj;
+                    if (!(rowCell && j == 0)) {
+                        const double bu = d.SU[kb], bv = d.SV[kb];
+                        nu = nu - s11[s] * bu - s12[s] * bv;
+                        nv = nv - s22[s] * bv - s12[s] * bu;
+                    }
                 }
             }
-            d.partU[(size_t)j * P + c] = cu;
-            d.partV[(size_t)j * P + c] = cv;
+            if (rowCell && j == 0) {
+                d.partU[c] = mu - du;
+                d.partV[c] = mv - dv;
+            } else {
+                d.partU[(size_t)j * P + c] = nu + mu;
+                d.partV[(size_t)j * P + c] = nv + mv;
+                // (in the order the last wave of the split kernel adds them: corner 1 first)
+                du = j == 1 ? nu : du + nu;
+                dv = j == 1 ? nv : dv + nv;
+            }
         }
     }
 }
@@ -629,6 +669,7 @@ template <int M, bool SPARSE, bool LAST>
 __global__ void __launch_bounds__(64 * M) k_sub_cells_split(SihDev d, const int *__restrict__ list, int nList)
 {
     __shared__ double su[M][64], sv[M][64], s11[M][64], s22[M][64], s12[M][64];
+    __shared__ int arrived;  // waves of the block that have left their part of corner 0's sums (deriveRow)
     const int lane = threadIdx.x, g = threadIdx.y;
     int c = blockIdx.x * 64 + lane;
     bool inRange;
@@ -641,9 +682,12 @@ __global__ void __launch_bounds__(64 * M) k_sub_cells_split(SihDev d, const int 
     }
     const int P = d.padC;
     const bool solve = inRange && d.solveStress[c] == 1;
-    // (with derived gradients: the number of edges with the cell's mark in bit 8, from the set-up)
-    const int Ev = inRange ? (SPARSE && d.deriveGrad ? d.nEdgesDerive[c] : d.nEdgesOnCell[c]) : 0;
+    // (with derived gradients or integral rows: the number of edges with the cell's marks in bits 8 and 9, from the
+    // set-up)
+    const int Ev = inRange ? ((SPARSE && d.deriveGrad) || d.deriveRow ? d.nEdgesDerive[c] : d.nEdgesOnCell[c]) : 0;
     const int E = Ev & 255;
+    // this cell's first row of basisIntegralsU / V is minus the sum of its other rows, bit for bit
+    const bool rowCell = d.deriveRow && (Ev & 512);
     const bool corner = solve && g < E;
     const size_t k = (size_t)g * P + c;
     double ug = 0.0, vg = 0.0, tg = 0.0;
@@ -655,6 +699,7 @@ __global__ void __launch_bounds__(64 * M) k_sub_cells_split(SihDev d, const int 
     }
     su[g][lane] = ug;
     sv[g][lane] = vg;
+    if (g == 0 && lane == 0) arrived = 0;
     __syncthreads();
     double a11 = 0.0, a22 = 0.0, a12 = 0.0;
     if (corner) {
@@ -679,7 +724,7 @@ __global__ void __launch_bounds__(64 * M) k_sub_cells_split(SihDev d, const int 
             const double xv[3] = {sv[i0][lane], sv[i1][lane], sv[i2][lane]};
             // the corner's own gradient (slot `own`) is minus the sum of the other two in the cells where the set-up found
             // the partition of unity to hold to rounding: 32 instead of 48 bytes of gradients per corner from memory
-            const int own = (Ev & 256) ? (g == 0 ? 0 : (g == E - 1 ? 2 : 1)) : -1;
+            const int own = (d.deriveGrad && (Ev & 256)) ? (g == 0 ? 0 : (g == E - 1 ? 2 : 1)) : -1;
             double gu3[3], gv3[3];
 #pragma unroll
             for (int q = 0; q < 3; q++) {
@@ -764,24 +809,96 @@ __global__ void __launch_bounds__(64 * M) k_sub_cells_split(SihDev d, const int 
     s22[g][lane] = a22;
     s12[g][lane] = a12;
     __syncthreads();
+    // Partial sums of the stress divergence for corner j = g.
+    if (!d.deriveRow) {  // (the same for every thread of the launch)
+        if (corner) {
+            double cu = 0.0, cv = 0.0;
+#pragma unroll
+            for (int s = 0; s < M; s++) {
+                if (s < E) {
+                    const size_t kb = (size_t)(g * M + s) * P + c;
+                    // a symmetric metric matrix is read from one side of its diagonal only: 21 planes of HBM traffic
+                    // instead of 36 for M = 6 (the corners of a cell sit in different waves of this block)
+                    const size_t km = d.symMetric ? (size_t)((g > s ? g : s) * M + (g > s ? s : g)) * P + c : kb;
+                    const double bu = d.SU[kb], bv = d.SV[kb], bm = d.SM[km];
+                    const double x11 = s11[s][lane], x22 = s22[s][lane], x12 = s12[s][lane];
+                    cu = cu - x11 * bu - x12 * bv - x12 * bm * tg;
+                    cv = cv - x22 * bv - x12 * bu + x11 * bm * tg;
+                }
+            }
+            d.partU[k] = cu;
+            d.partV[k] = cv;
+        }
+        return;
+    }
+    // The basis functions sum to one, so summed over the velocity corners of a cell the terms with basisIntegralsU / V
+    // cancel.  Every corner adds up those terms (nu, nv) and the metric terms (mu, mv) separately; in a marked cell
+    // (bit 9, set at set-up where the integrals obey the cancellation to rounding) corner 0 does not fetch its rows of
+    // U and V: its sums are its metric terms minus the other corners' nu, nv, added in ascending corner order.  The
+    // corners of a cell sit in the block's M waves: each leaves its part in LDS and counts itself in, and the wave that
+    // comes last finishes corner 0 for the block's 64 cells -- no wave waits for another.
+    const bool cellDerives = solve && rowCell;
+    double nu = 0.0, nv = 0.0, mu = 0.0, mv = 0.0;
     if (corner) {
-        // partial sums of the stress divergence for corner j = g
-        double cu = 0.0, cv = 0.0;
+        const bool skipsRows = cellDerives && g == 0;
+        // (all loads first, the skipped rows in one predicated region: requested inside the loop below, every pass
+        // waited for its own loads)
+        double bu[M], bv[M], bm[M];
+#pragma unroll
+        for (int s = 0; s < M; s++) {
+            bu[s] = 0.0;
+            bv[s] = 0.0;
+            bm[s] = 0.0;
+            if (s < E) {
+                const size_t kb = (size_t)(g * M + s) * P + c;
+                bm[s] = d.SM[d.symMetric ? (size_t)((g > s ? g : s) * M + (g > s ? s : g)) * P + c : kb];
+            }
+        }
+        if (!skipsRows) {
+#pragma unroll
+            for (int s = 0; s < M; s++) {
+                if (s < E) {
+                    const size_t kb = (size_t)(g * M + s) * P + c;
+                    bu[s] = d.SU[kb];
+                    bv[s] = d.SV[kb];
+                }
+            }
+        }
 #pragma unroll
         for (int s = 0; s < M; s++) {
             if (s < E) {
-                const size_t kb = (size_t)(g * M + s) * P + c;
-                // a symmetric metric matrix is read from one side of its diagonal only: 21 planes of HBM traffic
-                // instead of 36 for M = 6 (the corners of a cell sit in different waves of this block)
-                const size_t km = d.symMetric ? (size_t)((g > s ? g : s) * M + (g > s ? s : g)) * P + c : kb;
-                const double bu = d.SU[kb], bv = d.SV[kb], bm = d.SM[km];
                 const double x11 = s11[s][lane], x22 = s22[s][lane], x12 = s12[s][lane];
-                cu = cu - x11 * bu - x12 * bv - x12 * bm * tg;
-                cv = cv - x22 * bv - x12 * bu + x11 * bm * tg;
+                mu = mu - x12 * bm[s] * tg;
+                mv = mv + x11 * bm[s] * tg;
+                nu = nu - x11 * bu[s] - x12 * bv[s];
+                nv = nv - x22 * bv[s] - x12 * bu[s];
             }
         }
-        d.partU[k] = cu;
-        d.partV[k] = cv;
+        if (cellDerives) {  // (su / sv: every corner has taken its velocities from them before the second barrier)
+            su[g][lane] = g == 0 ? mu : nu;
+            sv[g][lane] = g == 0 ? mv : nv;
+        }
+    }
+    int lastWave = 0;
+    if (lane == 0)
+        lastWave = __hip_atomic_fetch_add(&arrived, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == M - 1 ? 1 : 0;
+    lastWave = __builtin_amdgcn_readfirstlane(lastWave);
+    // (stores to memory after the count: a release waits for the stores before it)
+    if (corner && !(cellDerives && g == 0)) {
+        d.partU[k] = nu + mu;
+        d.partV[k] = nv + mv;
+    }
+    if (lastWave && cellDerives) {
+        double du = su[1][lane], dv = sv[1][lane];
+#pragma unroll
+        for (int j = 2; j < M; j++) {
+            if (j < E) {
+                du = du + su[j][lane];
+                dv = dv + sv[j][lane];
+            }
+        }
+        d.partU[c] = su[0][lane] - du;
+        d.partV[c] = sv[0][lane] - dv;
     }
 }
 
@@ -1158,16 +1275,18 @@ static void launchCells(sih_ctx *c, bool last, const int *list, int nList, int m
     if (mode == 0 && c->splitCells) {
         const int n = list ? nList : c->nCells;
         dim3 bs(64, M), gs((unsigned)((n + 63) / 64));
+        // the rows of basisIntegralsU / V that the corners of a cell pass to its first corner (pairs of doubles)
+        const size_t lds = 0;
         if (c->sparseGrad) {
             if (last)
-                hipLaunchKernelGGL((k_sub_cells_split<M, true, true>), gs, bs, 0, c->stream, d, list, nList);
+                hipLaunchKernelGGL((k_sub_cells_split<M, true, true>), gs, bs, lds, c->stream, d, list, nList);
             else
-                hipLaunchKernelGGL((k_sub_cells_split<M, true, false>), gs, bs, 0, c->stream, d, list, nList);
+                hipLaunchKernelGGL((k_sub_cells_split<M, true, false>), gs, bs, lds, c->stream, d, list, nList);
         } else {
             if (last)
-                hipLaunchKernelGGL((k_sub_cells_split<M, false, true>), gs, bs, 0, c->stream, d, list, nList);
+                hipLaunchKernelGGL((k_sub_cells_split<M, false, true>), gs, bs, lds, c->stream, d, list, nList);
             else
-                hipLaunchKernelGGL((k_sub_cells_split<M, false, false>), gs, bs, 0, c->stream, d, list, nList);
+                hipLaunchKernelGGL((k_sub_cells_split<M, false, false>), gs, bs, lds, c->stream, d, list, nList);
         }
         return;
     }

@@ -1089,7 +1089,7 @@ extern "C" int sih_field_get_noalloc(sih_ctx *c, const char *name, void *host, s
 static void notePut(sih_ctx *c, const char *name)
 {
     if (c->inited && (!strncmp(name, "basisGradient", 13) || !strncmp(name, "basisIntegrals", 14)) &&
-        (c->sparseGrad || c->symMetric || c->deriveGrad)) {
+        (c->sparseGrad || c->symMetric || c->deriveGrad || c->deriveRow)) {
         // the compact gradients are stale until sih_evp_static_changed(), and the metric integrals may no longer be
         // symmetric; the dense kernel variant reads what the host has just put.  Captured graphs hold launches of the
         // compact variant: they go too.
@@ -1098,6 +1098,8 @@ static void notePut(sih_ctx *c, const char *name)
         c->dev.symMetric = 0;
         c->deriveGrad = false;
         c->dev.deriveGrad = 0;
+        c->deriveRow = false;
+        c->dev.deriveRow = 0;
         sih_drop_graphs(c);
     }
 }
@@ -1468,6 +1470,7 @@ extern "C" int sih_get_info(sih_ctx *c, const char *key, double *value)
     if (k == "sparseGradient") *value = c->sparseGrad ? 1.0 : 0.0;
     else if (k == "symmetricMetric") *value = c->symMetric ? 1.0 : 0.0;
     else if (k == "derivedGradient") *value = c->deriveGrad ? 1.0 : 0.0;
+    else if (k == "derivedIntegralRow") *value = c->deriveRow ? 1.0 : 0.0;
     else if (k == "dampingTimescale") *value = c->dev.dampT;
     else if (k == "elasticTimeStep") *value = c->dev.dtE;
     else if (k == "dynamicsTimeStep") *value = c->dev.dtDyn;

@@ -69,7 +69,9 @@ struct SihDev {
     int relation, useOcean, quadratic, useAir, tiltMode, useColumn, haloVertices;
     int symMetric;  // basisIntegralsMetric(s, j) == (j, s) bit for bit: the cell kernels read one of each pair
     int deriveGrad; // where the three gradients met at a corner sum to zero to rounding the corner's own is not fetched
-    const int *nEdgesDerive;  // nEdgesOnCell | 256 for the cells where that holds at every corner
+    int deriveRow;  // basisIntegralsU / V: the first velocity corner's row of a marked cell (bit 9 of nEdgesDerive) is minus the
+                    // sum of the other rows, bit for bit, and the split cell kernel forms it on the chip instead of fetching it
+    const int *nEdgesDerive;  // nEdgesOnCell | 256 for the cells where that holds at every corner | 512 (see deriveRow)
     int columnStrength, kstrength, krdgPartic, krdgRedist;  // colpkg_ice_strength in place of Hibler's formula
     double muRdg, Cf;
 };
@@ -103,6 +105,7 @@ struct sih_ctx {
     bool inited = false, sparseGrad = false;
     bool symMetric = false;  // the metric integrals are bitwise symmetric (checked on the device at set-up)
     bool deriveGrad = false; // compact gradients obey the partition of unity to rounding (checked likewise)
+    bool deriveRow = false;  // rows of basisIntegralsU / V of marked cells stored as minus the sum of the other rows
     bool counted = false;  // in the per-device count of live contexts
     int persistMode = -1;  // sih_evp_set_persistent: -1 environment, 0 two-kernel form, 1 persistent kernel, 2 with the exchange inside
     bool splitCells = false;  // cell kernel with one thread per (cell, corner) instead of one per cell
