@@ -43,15 +43,16 @@ def b_alg_cell_kernel(M):
     return 16 * M * M + 24 * M * M + 48 * M + 8 * M + (4 * M + 8) + 8 + 24 * 2
 
 
-def b_layout_cell_kernel(M, symmetric_metric=True, derived_gradient=True):
+def b_layout_cell_kernel(M, symmetric_metric=True, derived_gradient=True, derived_row=True):
     """Bytes per cell this library's layout makes the cell kernel move: like b_alg_cell_kernel, but the basis
     gradients are stored compactly (three non-zeros per column: 48 M instead of 16 M^2 bytes), the per-corner
     partial sums of the stress divergence are written (16 M), and of the metric integrals, mirrored at set-up to be
     symmetric bit for bit, one side of the diagonal is fetched (4 M (M + 1) instead of 8 M^2 bytes); of the three
-    gradients of a corner two are fetched."""
+    gradients of a corner two are fetched; of the M rows of basisIntegralsU / V all but the first corner's."""
     metric = 4 * M * (M + 1) if symmetric_metric else 8 * M * M
     gradients = 32 * M if derived_gradient else 48 * M   # the corner's own gradient is minus the sum of the other two
-    return gradients + 16 * M * M + metric + 48 * M + 16 * M + (4 * M + 8) + 8 + 24 * 2
+    integrals = 16 * M * (M - 1) if derived_row else 16 * M * M   # corner 0's sums are minus the other corners'
+    return gradients + integrals + metric + 48 * M + 16 * M + (4 * M + 8) + 8 + 24 * 2
 
 
 def kernel_source_hash(files=("evp_step.hip", "sih_internal.h")):
@@ -338,6 +339,7 @@ def main():
 
     sym_metric = os.environ.get("SIH_METRIC_INTEGRALS") != "as_computed"
     derived_grad = os.environ.get("SIH_BASIS_GRADIENTS") != "as_computed"
+    derived_row = os.environ.get("SIH_BASIS_INTEGRALS") != "as_computed"
     if world == 1:
         dom = cases.make_domain(mesh, args.mesh, configs={"config_elastic_subcycle_number": nsub})
         vs.seaice_mesh_pool_create(dom, device=local_rank, renumber=not args.no_renumber)
@@ -360,6 +362,7 @@ def main():
         single_form = int(ctx.info("iterationForm"))
         sym_metric = bool(ctx.info("symmetricMetric"))
         derived_grad = bool(ctx.info("derivedGradient"))
+        derived_row = bool(ctx.info("derivedIntegralRow"))
         cell_ms, vert_ms, nsamp = 0.0, 0.0, 0
         if single_form != 0:
             for _ in range(args.warmup):
@@ -440,7 +443,7 @@ def main():
                               "from": tj.get("kernel_stats_file")}
         else:
             traffic_note = "profiles/traffic_latest.json was taken with other kernel sources: not reported"
-    layout_bytes = b_layout_cell_kernel(M, sym_metric, derived_grad) * cells_per_launch
+    layout_bytes = b_layout_cell_kernel(M, sym_metric, derived_grad, derived_row) * cells_per_launch
     # a mesh with cells of several degrees: the same accounting with every cell's own number of corners in place of
     # maxEdges (the planes are maxEdges deep, but a corner a cell does not have is never read)
     degree_note = None
@@ -469,9 +472,16 @@ def main():
                      # and, when the counters are current, against the bytes they counted
                      "layout_bytes_per_launch": layout_bytes,
                      # what the layout leaves out of the algorithmic bytes: the compact gradients always; one side of the
-                     # mirrored metric integrals and the corner's own gradient unless switched off in the environment
+                     # mirrored metric integrals, the corner's own gradient and the first corner's rows of
+                     # basisIntegralsU / V unless switched off in the environment.  The algorithmic count is that of
+                     # the dense formulation: with these reductions the kernel moves fewer bytes than it names, so
+                     # `frac` can pass 1 while frac_layout and frac_counter cannot
                      "layout": {"compact_gradients": True, "symmetric_metric_integrals": bool(sym_metric),
-                                "derived_corner_gradient": bool(derived_grad)},
+                                "derived_corner_gradient": bool(derived_grad),
+                                "derived_first_corner_sums": bool(derived_row)},
+                     "frac_note": "achieved / frac price the kernel's time with the algorithmic bytes of the dense "
+                                  "formulation; this layout moves fewer (layout_bytes_per_launch), so frac can pass 1: "
+                                  "frac_layout and frac_counter are the fractions of peak by bytes really moved",
                      "frac_layout": (layout_bytes / (cell_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if cell_ms > 0 else 0.0,
                      "frac_counter": (traffic / (cell_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and cell_ms > 0 else None,
                      "traffic_source": traffic_note},

@@ -166,7 +166,13 @@ int sih_evp_set_edge_mesh(sih_ctx *ctx, const struct sih_ir_desc *edges);
  * A second one inside the subcycle kernel only: in cells where the three non-zero basis gradients of every corner sum
  * to zero to 1e-13 of the largest (the basis functions sum to one), the corner's own gradient is formed as minus the
  * sum of the other two instead of being fetched; basisGradientU / V are untouched.  SIH_BASIS_GRADIENTS=as_computed
- * switches that off.  Both keep the velocities within 1e-10 of the reference arithmetic. */
+ * switches that off.
+ * A third, also inside the subcycle kernels only (all their forms alike): the inner sums of the stress divergence
+ * (variational.F:1151-1170) add the terms with basisIntegralsU / V and the metric terms separately, and in cells where
+ * basisIntegralsU / V summed over the velocity corners vanish to 1e-13 of the largest entry for every stress corner
+ * (again the basis functions summing to one) the first corner's sum is its metric terms minus the other corners' sums,
+ * so that its rows of basisIntegralsU / V are not fetched; the arrays are untouched.  SIH_BASIS_INTEGRALS=as_computed
+ * keeps the reference's statement.  All three keep the velocities within 1e-10 of the reference arithmetic. */
 int sih_evp_init(sih_ctx *ctx, const sih_evp_config *cfg);
 /* re-pack the static basis after the host replaced basisGradient* / basisIntegrals* with its own
  * (e.g. the piecewise-linear basis computed by the host model) */

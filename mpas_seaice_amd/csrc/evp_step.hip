@@ -812,18 +812,30 @@ __global__ void __launch_bounds__(64 * M) k_sub_cells_split(SihDev d, const int 
     // Partial sums of the stress divergence for corner j = g.
     if (!d.deriveRow) {  // (the same for every thread of the launch)
         if (corner) {
-            double cu = 0.0, cv = 0.0;
+            // (all loads first: requested inside the loop of the sums, every pass waited for its own three)
+            double bu[M], bv[M], bm[M];
 #pragma unroll
             for (int s = 0; s < M; s++) {
+                bu[s] = 0.0;
+                bv[s] = 0.0;
+                bm[s] = 0.0;
                 if (s < E) {
                     const size_t kb = (size_t)(g * M + s) * P + c;
                     // a symmetric metric matrix is read from one side of its diagonal only: 21 planes of HBM traffic
                     // instead of 36 for M = 6 (the corners of a cell sit in different waves of this block)
                     const size_t km = d.symMetric ? (size_t)((g > s ? g : s) * M + (g > s ? s : g)) * P + c : kb;
-                    const double bu = d.SU[kb], bv = d.SV[kb], bm = d.SM[km];
+                    bu[s] = d.SU[kb];
+                    bv[s] = d.SV[kb];
+                    bm[s] = d.SM[km];
+                }
+            }
+            double cu = 0.0, cv = 0.0;
+#pragma unroll
+            for (int s = 0; s < M; s++) {
+                if (s < E) {
                     const double x11 = s11[s][lane], x22 = s22[s][lane], x12 = s12[s][lane];
-                    cu = cu - x11 * bu - x12 * bv - x12 * bm * tg;
-                    cv = cv - x22 * bv - x12 * bu + x11 * bm * tg;
+                    cu = cu - x11 * bu[s] - x12 * bv[s] - x12 * bm[s] * tg;
+                    cv = cv - x22 * bv[s] - x12 * bu[s] + x11 * bm[s] * tg;
                 }
             }
             d.partU[k] = cu;

@@ -549,3 +549,51 @@ def test_corner_gradient_from_the_partition_of_unity(oracle, monkeypatch):
             assert flag == (1.0 if mode == "derived" else 0.0), (name, mode)
             compare_domains(dev, ref, STATIC_OUTPUTS, 1e-13)
             compare_domains(dev, ref, STATE, 1e-10)
+
+
+def test_first_corner_sums_from_the_partition_of_unity(oracle, monkeypatch):
+    """Summed over the velocity corners of a cell the terms of the stress divergence with basisIntegralsU / V cancel
+    (the basis functions sum to one), so corner 0 takes minus the other corners' sums of those terms plus its own metric
+    terms and does not fetch its rows; SIH_BASIS_INTEGRALS=as_computed keeps the reference's statement order.  Velocities
+    within 1e-10 of the oracle either way, on hexagons with pentagons, on the mesh with heptagons and on a plane; the
+    basis integrals themselves are untouched (STATIC_OUTPUTS at 1e-13).  On the plane (no metric terms) the sums of a
+    cell's corners then cancel to the last place: what the ice inside a cell does to itself moves nothing."""
+    for name in ("QU480", "var12", "hex_24_20"):
+        mesh = get_mesh(name)
+        cfg = {"config_elastic_subcycle_number": 30}
+        if name == "hex_24_20":
+            cfg["config_dt"] = 600.0
+        kw = {"open_water_band": (-0.2, 0.3)} if name == "var12" else {}
+        label = name if name == "QU480" else None
+        ref = cases.make_domain(mesh, label, configs=cfg, **kw)
+        oracle.seaice_init_velocity_solver(ref)
+        oracle.seaice_run_velocity_solver(ref)
+        for mode in ("derived", "as_computed"):
+            if mode == "as_computed":
+                monkeypatch.setenv("SIH_BASIS_INTEGRALS", "as_computed")
+            else:
+                monkeypatch.delenv("SIH_BASIS_INTEGRALS", raising=False)
+            dev = cases.make_domain(mesh, label, configs=cfg, **kw)
+            vs.seaice_mesh_pool_create(dev)
+            try:
+                vs.seaice_init_velocity_solver(dev)
+                ctx = dev.blocklist[0].ctx
+                flag = ctx.info("derivedIntegralRow")
+                vs.seaice_run_velocity_solver(dev)
+                n, _ = ctx.field_count("_partU")
+                part = np.zeros(n)
+                ctx.get("_partU", part)
+            finally:
+                vs.seaice_mesh_pool_destroy(dev)
+            assert flag == (1.0 if mode == "derived" else 0.0), (name, mode)
+            compare_domains(dev, ref, STATIC_OUTPUTS, 1e-13)
+            compare_domains(dev, ref, STATE, 1e-10)
+            if name == "hex_24_20":
+                M = mesh.maxEdges
+                part = part.reshape((-1, M))[:mesh.nCells]   # (cell, corner), the sums of the last subcycle
+                assert np.abs(part).max() > 0.0
+                total = np.abs(part.sum(axis=1)).max()
+                if mode == "derived":
+                    assert total <= 4e-16 * np.abs(part).max(), total
+                else:
+                    assert total <= 1e-12 * np.abs(part).max(), total
