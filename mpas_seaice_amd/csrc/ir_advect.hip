@@ -666,22 +666,39 @@ __global__ void __launch_bounds__(256) k_ir_reconstruct(IrDev d, const IrTabEntr
     unsigned plus = 0, valid = 0;  // per edge slot: the cell is the edge's first cell; the slot has a neighbour cell
     double t11 = 0, t12 = 0, t13 = 0, t21 = 0, t22 = 0, t23 = 0;
     if (ice) {
+        // (in passes: everything that depends on the cell alone is requested in the first, what hangs on an edge number
+        // in the second -- in one pass over the edge slots every slot waited for its own chain of loads)
+        int eds[M];
 #pragma unroll
         for (int ie = 0; ie < M; ie++) {
             nb[ie] = d.nCells;
+            eds[ie] = 0;
             rdc[ie] = 1.0;
             cf0[ie] = cf1[ie] = cf2[ie] = xv[ie] = yv[ie] = 0.0;
             if (ie < n) {
                 nb[ie] = d.coc[(size_t)ie * pc + c];
-                if (nb[ie] < d.nCells) valid |= 1u << ie;
-                int e = d.eoc[(size_t)ie * pc + c];
-                rdc[ie] = d.dcEdge[e];
-                if (c == d.coe[e]) plus |= 1u << ie;
+                eds[ie] = d.eoc[(size_t)ie * pc + c];
                 cf0[ie] = d.coeffs[(size_t)(ie * 3 + 0) * pc + c];
                 cf1[ie] = d.coeffs[(size_t)(ie * 3 + 1) * pc + c];
                 cf2[ie] = d.coeffs[(size_t)(ie * 3 + 2) * pc + c];
                 xv[ie] = d.xVOC[(size_t)ie * pc + c];
                 yv[ie] = d.yVOC[(size_t)ie * pc + c];
+            }
+        }
+        int first[M];
+#pragma unroll
+        for (int ie = 0; ie < M; ie++) {
+            first[ie] = -1;
+            if (ie < n) {
+                rdc[ie] = d.dcEdge[eds[ie]];
+                first[ie] = d.coe[eds[ie]];
+            }
+        }
+#pragma unroll
+        for (int ie = 0; ie < M; ie++) {
+            if (ie < n) {
+                if (nb[ie] < d.nCells) valid |= 1u << ie;
+                if (c == first[ie]) plus |= 1u << ie;
             }
         }
         if (d.onSphere) {
@@ -1492,15 +1509,27 @@ __global__ void __launch_bounds__(IR_UPD_BLOCK) k_ir_update(IrDev d, const IrTab
 #pragma unroll
     for (int ie = 0; ie < M; ie++) {
         ed[ie] = d.nEdges;
-        rel[ie] = -1;
-        if (ie < n) {
-            ed[ie] = d.eoc[(size_t)ie * pc + c];
-            rel[ie] = ed[ie] - eLo;
-            if (rel[ie] >= IR_UPD_WIN) rel[ie] = -1;
-            if (c == d.coe[ed[ie]]) plus |= 1u << ie;
-        }
+        if (ie < n) ed[ie] = d.eoc[(size_t)ie * pc + c];
     }
     const double area = d.areaCell[c];
+    {
+        // (the edges' first cells in a pass of their own: asked for slot by slot, each waited for its edge number)
+        int first[M];
+#pragma unroll
+        for (int ie = 0; ie < M; ie++) {
+            first[ie] = -1;
+            if (ie < n) first[ie] = d.coe[ed[ie]];
+        }
+#pragma unroll
+        for (int ie = 0; ie < M; ie++) {
+            rel[ie] = -1;
+            if (ie < n) {
+                rel[ie] = ed[ie] - eLo;
+                if (rel[ie] >= IR_UPD_WIN) rel[ie] = -1;
+                if (c == first[ie]) plus |= 1u << ie;
+            }
+        }
+    }
     bool negMass = false;
     // what a thread copies of a window: IR_UPD_PER entries, 256 apart
     int wi[IR_UPD_PER];
@@ -1544,15 +1573,20 @@ __global__ void __launch_bounds__(IR_UPD_BLOCK) k_ir_update(IrDev d, const IrTab
             const double prodOld = prodNext;
             if (more1) prodNext = tab[ti1].prod[(size_t)(cat * tab[ti1].L + ly1) * pc + c];
             const IrG *fp = T.flux + (size_t)l * pe;
+            // (requested before the gathers below, not after them where it is used)
+            const double pp = hasParent ? P->prod[(size_t)(P->L == 1 ? cat : l) * pc + c] : 1.0;
+            // (the six fluxes first, then their sum: with the gather and the addition in one pass of the loop, every
+            // pass with a lane outside the window waited for its own load)
+            double fe[M];
+#pragma unroll
+            for (int ie = 0; ie < M; ie++) fe[ie] = win[buf * IR_UPD_WIN + (rel[ie] >= 0 ? rel[ie] : 0)];
+#pragma unroll
+            for (int ie = 0; ie < M; ie++)
+                if (ie < n && rel[ie] < 0) fe[ie] = fp[ed[ie]];
             double flux = 0.0;
 #pragma unroll
             for (int ie = 0; ie < M; ie++)
-                if (ie < n) {
-                    double fe = win[buf * IR_UPD_WIN + (rel[ie] >= 0 ? rel[ie] : 0)];
-                    if (rel[ie] < 0) fe = fp[ed[ie]];
-                    flux = flux + fe * ((plus >> ie) & 1u ? 1.0 : -1.0);
-                }
-            const double pp = hasParent ? P->prod[(size_t)(P->L == 1 ? cat : l) * pc + c] : 1.0;
+                if (ie < n) flux = flux + fe[ie] * ((plus >> ie) & 1u ? 1.0 : -1.0);
             double nv;
             if (pp > 0.0)
                 nv = (prodOld - (flux / area)) / pp;
