@@ -38,6 +38,7 @@ struct InitArgs {
     double *gradU, *gradV, *SU, *SV, *SM, *gradU3, *gradV3;
     int *flag;
     int *nEdgesDerive;  // nEdgesOnCell | 256 where every corner's own gradient is minus the sum of the other two
+    int unmarkEvery;    // tests only (SIH_TEST_UNMARK_EVERY = n > 0): cells whose local index is a multiple of n get no mark
 };
 
 // mesh.F:2350-2381
@@ -618,6 +619,7 @@ __global__ void k_pack_gradients(InitArgs a)
             }
         }
     }
+    if (a.unmarkEvery > 0 && c % a.unmarkEvery == 0) noUnity = true;
     a.nEdgesDerive[c] = E | ((!dense && !noUnity) ? 256 : 0);
     if (dense) atomicOr(a.flag, 1);
 }
@@ -695,6 +697,7 @@ static InitArgs makeInitArgs(sih_ctx *c)
     a.gradU3 = fd("_gradU3");
     a.gradV3 = fd("_gradV3");
     a.flag = c->d_flag;
+    if (const char *e = getenv("SIH_TEST_UNMARK_EVERY")) a.unmarkEvery = atoi(e);
     return a;
 }
 
@@ -758,7 +761,7 @@ __global__ void k_derive_integral_rows(InitArgs a)
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.nCells) return;
     const int M = a.M, E = a.nEdgesOnCell[c];
-    if (E < 3) return;
+    if (E < 3 || (a.unmarkEvery > 0 && c % a.unmarkEvery == 0)) return;
     bool ok = true;
     for (int uv = 0; uv < 2; uv++) {
         const double *S = uv ? a.SV : a.SU;

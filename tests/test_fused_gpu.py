@@ -108,3 +108,60 @@ def test_a_block_with_an_option_outside_the_fused_kernel_is_refused():
             b.ctx.subcycle_fused(3)
     finally:
         vs.seaice_mesh_pool_destroy(dom)
+
+
+def test_cells_without_the_marks_of_the_set_up_in_every_kernel_form(oracle, monkeypatch):
+    """The subcycle kernels leave out a corner's own gradient and the first corner's rows of basisIntegralsU / V only in
+    cells the set-up has marked (where the partition of unity holds to rounding); no mesh of these tests has an
+    unmarked cell, so SIH_TEST_UNMARK_EVERY withholds the marks from every third cell: marked and unmarked cells then
+    sit side by side in every wave.  The four kernel forms must still give the same bits, and the oracle's velocities
+    to 1e-10."""
+    monkeypatch.setenv("SIH_TEST_UNMARK_EVERY", "3")
+    mesh = get_mesh("QU240")
+    res = {}
+    for form in ("split", "cell", "fused", "persistent"):
+        if form == "cell":
+            monkeypatch.setenv("SIH_CELL_KERNEL", "fused")   # one thread per cell
+        else:
+            monkeypatch.delenv("SIH_CELL_KERNEL", raising=False)
+        dom, b = _prepared(mesh, "QU240")
+        try:
+            assert b.ctx.info("derivedGradient") == 1.0 and b.ctx.info("derivedIntegralRow") == 1.0
+            n_marks, _ = b.ctx.field_count("_nEdgesDerive")
+            marks = np.zeros(n_marks, dtype=np.int32)
+            b.ctx.get("_nEdgesDerive", marks)
+            marks = marks[:mesh.nCells] & 768
+            assert (marks == 0).sum() == (mesh.nCells + 2) // 3 and (marks == 768).sum() == mesh.nCells - (mesh.nCells + 2) // 3
+            for n in (7, 1, 12):
+                if form == "fused":
+                    b.ctx.subcycle_fused(n)
+                elif form == "persistent":
+                    b.ctx.subcycle_persistent(n)
+                else:
+                    b.ctx.subcycle(n, last=False)
+                b.ctx.subcycle(2, last=False)
+            b.ctx.sync()
+            res[form] = _state(b)
+        finally:
+            vs.seaice_mesh_pool_destroy(dom)
+    assert np.abs(res["split"]["uVelocity"]).max() > 1e-4
+    for form in ("cell", "fused", "persistent"):
+        for k in res["split"]:
+            assert np.array_equal(res["split"][k], res[form][k]), (form, k)
+    monkeypatch.delenv("SIH_CELL_KERNEL", raising=False)
+    small = get_mesh("QU480")
+    cfg = {"config_elastic_subcycle_number": 30}
+    ref = cases.make_domain(small, "QU480", configs=cfg)
+    oracle.seaice_init_velocity_solver(ref)
+    oracle.seaice_run_velocity_solver(ref)
+    dev = cases.make_domain(small, "QU480", configs=cfg)
+    vs.seaice_mesh_pool_create(dev)
+    try:
+        vs.seaice_init_velocity_solver(dev)
+        vs.seaice_run_velocity_solver(dev)
+    finally:
+        vs.seaice_mesh_pool_destroy(dev)
+    for k in ("uVelocity", "vVelocity"):
+        a = dev.blocklist[0].structs["velocity_solver"][k]
+        r = ref.blocklist[0].structs["velocity_solver"][k]
+        assert np.abs(a - r).max() <= 1e-10 * np.abs(r).max(), k
