@@ -598,7 +598,8 @@ int sih_upwind_run(sih_ctx *ctx, double dt, int checks);
  * nCategories values each */
 int sih_upwind_get_sums(sih_ctx *ctx, const char *tracer, double *initSums, double *finalSums);
 
-/* introspection for tests and reports.  Keys: sparseGradient, splitCellKernel, persistentKernel (and persistentPerCU,
+/* introspection for tests and reports.  Keys: sparseGradient, symmetricMetric, derivedGradient, derivedIntegralRow (1 when
+ * the set-up found the layout reduction of that name to apply, see sih_evp_init), splitCellKernel, persistentKernel (and persistentPerCU,
  * persistentTiles, persistentReason, persistentArrived, persistentLaunches, persistentExchangeLaunches,
  * persistentExchangeReady (see sih_evp_set_persistent), fusedKernel and fusedLaunches (sih_evp_subcycle_fused), persistentTileCells, iterationForm (what the last loop of iterations ran as: 0 two
  * kernels an iteration, 1 the persistent kernel, 2 the fused kernel): workgroups of
