@@ -296,7 +296,12 @@ def main():
     ap.add_argument("--partition-file", default=None, help="METIS graph.info.part.N for --gpus N (default: "
                     "cut along a space-filling curve)")
     ap.add_argument("--subcycles", type=int, default=120)
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("SIH_BENCH_GRAPH", "0")))
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("SIH_BENCH_GRAPH", "2")),
+                    help="how one GPU queues the subcycles of a step: 2 (default) the first iteration as two launches "
+                         "between HIP events (the roofline's kernel times, inside the timed region), the others replayed "
+                         "from a HIP graph as the library's own step (sih_evp_run) does; 1 all of them from the graph "
+                         "(kernel times sampled after the timed region); 0 all as separate launches, every "
+                         "--sample-every-th between events")
     ap.add_argument("--sample-every", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-renumber", action="store_true")
@@ -374,17 +379,27 @@ def main():
             ctx.sync()
             wall = time.perf_counter() - t0
         else:
+            def one_step(sample_every):
+                if args.graph == 2:
+                    # the first iteration as two launches between HIP events, the other nsub - 1 replayed from a graph
+                    _, tc, tv = ctx.subcycle_timed(1, use_graph=False, sample_every=1 if sample_every else 0)
+                    ctx.subcycle_graph(nsub - 1)
+                    return tc, tv
+                _, tc, tv = ctx.subcycle_timed(nsub, use_graph=args.graph, sample_every=sample_every)
+                return tc, tv
             for _ in range(args.warmup):
-                ctx.subcycle_timed(nsub, use_graph=args.graph, sample_every=0)
+                one_step(0)
             torch.cuda.synchronize()
+            ctx.sync()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                _, tc, tv = ctx.subcycle_timed(nsub, use_graph=args.graph, sample_every=args.sample_every)
+                tc, tv = one_step(args.sample_every)
                 if tc > 0:
                     cell_ms += tc
                     vert_ms += tv
                     nsamp += 1
             torch.cuda.synchronize()
+            ctx.sync()
             wall = time.perf_counter() - t0
         t0 = time.perf_counter()
         ctx.subcycle(1, last=True)
@@ -460,7 +475,10 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{mesh_label} full-sphere mesh ({n_cells_total} cells, maxEdges {M}), "
                                f"{nsub} EVP subcycles per step, variational Wachspress operators, idealised forcing",
-                   "parallelism": parallelism, "hip_graph": bool(args.graph)},
+                   "parallelism": parallelism, "hip_graph": bool(args.graph),
+                   "launches": ({2: "per step: one iteration as two launches between HIP events, the others replayed from a HIP graph",
+                                 1: "per step: all iterations replayed from a HIP graph",
+                                 0: "two launches per iteration"}.get(int(args.graph)) if world == 1 else None)},
         "roofline": {"bound": "hbm", "kernel": "k_sub_cells_split (fused strain + EVP stress + stress-divergence partial sums, one thread per cell corner)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_launch": roof_bytes,
