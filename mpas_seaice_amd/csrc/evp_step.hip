@@ -144,11 +144,13 @@ void sih_bind_dev(sih_ctx *c)
     d.deriveGrad = c->deriveGrad ? 1 : 0;
     d.deriveRow = c->deriveRow ? 1 : 0;
     {
-        // Blocks from about 120 000 cells on move more per iteration than the caches hold (measured: 164 k cells 0.2 %
-        // faster with the marks, 655 k cells 6 %; 88 k cells 2.5 % slower, 47 k cells 3 % slower); SIH_STREAM_HINTS = 0 / 1
-        // overrides.
+        // Blocks from about 120 000 cells on move more per iteration than the caches hold: level 1 marks the stresses
+        // and the partial sums (measured: 164 k cells 0.2 % faster, 655 k cells 6 %; 88 k cells 2.5 % slower, 47 k cells
+        // 3 % slower).  Where even the basis arrays cannot survive from one iteration to the next, level 2 marks them
+        // too (655 k cells: 12 % faster than without marks; at 164 k cells, where they do survive, 12 % slower).
+        // SIH_STREAM_HINTS = 0 / 1 / 2 overrides.
         const char *e = getenv("SIH_STREAM_HINTS");
-        d.streamHints = e ? (atoi(e) != 0) : (c->nCells >= 120000);
+        d.streamHints = e ? atoi(e) : (c->nCells >= 400000 ? 2 : (c->nCells >= 120000 ? 1 : 0));
     }
 }
 
@@ -692,7 +694,7 @@ __device__ __forceinline__ void stStreamT(double *p, double v)
 // entries of one plane.  Corner velocities and the new corner stresses are exchanged through LDS.  Each
 // thread issues 1/M of the loads of the one-thread-per-cell kernel, which shortens the dependent chain
 // that dominates on small blocks (many-GPU runs), at the price of two block barriers.
-template <int M, bool SPARSE, bool LAST, bool NT>
+template <int M, bool SPARSE, bool LAST, int NT>
 __global__ void __launch_bounds__(64 * M) k_sub_cells_split(SihDev d, const int *__restrict__ list, int nList)
 {
     __shared__ double su[M][64], sv[M][64], s11[M][64], s22[M][64], s12[M][64];
@@ -708,7 +710,7 @@ __global__ void __launch_bounds__(64 * M) k_sub_cells_split(SihDev d, const int 
         if (!inRange) c = 0;
     }
     const int P = d.padC;
-    constexpr bool nt = NT;  // (a template parameter: behind a run-time condition the compiler merges the two loads into a plain one)
+    constexpr bool nt = NT >= 1, ntAll = NT >= 2;  // (a template parameter: behind a run-time condition the compiler merges the two loads into a plain one)
     const bool solve = inRange && d.solveStress[c] == 1;
     // (with derived gradients or integral rows: the number of edges with the cell's marks in bits 8 and 9, from the
     // set-up)
@@ -759,8 +761,8 @@ __global__ void __launch_bounds__(64 * M) k_sub_cells_split(SihDev d, const int 
                 gu3[q] = 0.0;
                 gv3[q] = 0.0;
                 if (q != own) {
-                    gu3[q] = d.gradU3[(size_t)(q * M + g) * P + c];
-                    gv3[q] = d.gradV3[(size_t)(q * M + g) * P + c];
+                    gu3[q] = ldStream(&d.gradU3[(size_t)(q * M + g) * P + c], ntAll);
+                    gv3[q] = ldStream(&d.gradV3[(size_t)(q * M + g) * P + c], ntAll);
                 }
             }
             if (own >= 0) {
@@ -893,7 +895,7 @@ __global__ void __launch_bounds__(64 * M) k_sub_cells_split(SihDev d, const int 
             bm[s] = 0.0;
             if (s < E) {
                 const size_t kb = (size_t)(g * M + s) * P + c;
-                bm[s] = d.SM[d.symMetric ? (size_t)((g > s ? g : s) * M + (g > s ? s : g)) * P + c : kb];
+                bm[s] = ldStream(&d.SM[d.symMetric ? (size_t)((g > s ? g : s) * M + (g > s ? s : g)) * P + c : kb], ntAll);
             }
         }
         if (!skipsRows) {
@@ -901,8 +903,8 @@ __global__ void __launch_bounds__(64 * M) k_sub_cells_split(SihDev d, const int 
             for (int s = 0; s < M; s++) {
                 if (s < E) {
                     const size_t kb = (size_t)(g * M + s) * P + c;
-                    bu[s] = d.SU[kb];
-                    bv[s] = d.SV[kb];
+                    bu[s] = ldStream(&d.SU[kb], ntAll);
+                    bv[s] = ldStream(&d.SV[kb], ntAll);
                 }
             }
         }
@@ -1320,10 +1322,12 @@ static void launchCells(sih_ctx *c, bool last, const int *list, int nList, int m
         const bool nt = d.streamHints != 0;
 #define SIH_LAUNCH_SPLIT(SP, LA)                                                                                        \
     do {                                                                                                                \
-        if (nt)                                                                                                         \
-            hipLaunchKernelGGL((k_sub_cells_split<M, SP, LA, true>), gs, bs, 0, c->stream, d, list, nList);             \
+        if (d.streamHints >= 2)                                                                                         \
+            hipLaunchKernelGGL((k_sub_cells_split<M, SP, LA, 2>), gs, bs, 0, c->stream, d, list, nList);                \
+        else if (nt)                                                                                                    \
+            hipLaunchKernelGGL((k_sub_cells_split<M, SP, LA, 1>), gs, bs, 0, c->stream, d, list, nList);                \
         else                                                                                                            \
-            hipLaunchKernelGGL((k_sub_cells_split<M, SP, LA, false>), gs, bs, 0, c->stream, d, list, nList);            \
+            hipLaunchKernelGGL((k_sub_cells_split<M, SP, LA, 0>), gs, bs, 0, c->stream, d, list, nList);                \
     } while (0)
         if (c->sparseGrad) {
             if (last)
