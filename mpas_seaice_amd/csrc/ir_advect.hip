@@ -727,12 +727,19 @@ __global__ void __launch_bounds__(256) k_ir_reconstruct(IrDev d, const IrTabEntr
             ybS = P->yB[(size_t)cat * pc + c];
         }
         if (ice && sharedMask) {
+            // (the parent's values at the cell and its neighbours: all seven requested before the first is looked at;
+            // with look-up and test in one pass per neighbour every pass waited for its own gather.  A slot without a
+            // neighbour reads the cell itself and is left out by its `valid` bit.)
             const size_t lp1 = (size_t)cat * pc;
-            mcS = P->val[lp1 + c] > EPS11;
+            const double pvc = P->val[lp1 + c];
+            double pvn[M];
+#pragma unroll
+            for (int ie = 0; ie < M; ie++) pvn[ie] = P->val[lp1 + (((valid >> ie) & 1u) ? nb[ie] : c)];
+            mcS = pvc > EPS11;
             mnbS = 0;
 #pragma unroll
             for (int ie = 0; ie < M; ie++)
-                if (ie < n && nb[ie] < d.nCells && P->val[lp1 + nb[ie]] > EPS11) mnbS |= 1u << ie;
+                if (((valid >> ie) & 1u) && pvn[ie] > EPS11) mnbS |= 1u << ie;
         }
         // the values of a layer (the cell's and its neighbours') are requested one layer ahead, so that their way
         // through memory overlaps the arithmetic of the layer before (2 waves a SIMD hide nothing of it: 0.70 ->
