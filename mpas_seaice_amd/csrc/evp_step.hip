@@ -669,6 +669,15 @@ __global__ void __launch_bounds__(256) k_sub_cells(SihDev d, const int *__restri
     }
 }
 
+// Workgroups are dealt round-robin over the eight XCDs, each with an L2 of its own: with this permutation of the block
+// index an XCD works on one contiguous eighth of the range, so that neighbouring blocks, which gather from the same
+// cache lines along their common border, mostly share an L2.
+__device__ __forceinline__ int xcdChunkedBlock()
+{
+    const int b = blockIdx.x, nb = gridDim.x, q = nb / 8, r = nb % 8, x = b % 8;
+    return x * q + (x < r ? x : r) + b / 8;
+}
+
 // Loads and stores of data that passes through once an iteration (stresses, partial sums), non-temporal on request:
 // on a block whose working set does not fit the caches that leaves more of them (the 256 MB Infinity Cache above all)
 // to the arrays the next iteration reads again.  On a block that does fit, the same marks cost time.
@@ -700,7 +709,7 @@ __global__ void __launch_bounds__(64 * M) k_sub_cells_split(SihDev d, const int 
     __shared__ double su[M][64], sv[M][64], s11[M][64], s22[M][64], s12[M][64];
     __shared__ int arrived;  // waves of the block that have left their part of corner 0's sums (deriveRow)
     const int lane = threadIdx.x, g = threadIdx.y;
-    int c = blockIdx.x * 64 + lane;
+    int c = xcdChunkedBlock() * 64 + lane;
     bool inRange;
     if (list) {
         inRange = c < nList;
@@ -1030,7 +1039,7 @@ __global__ void k_sb_masks(SihDev d, const int *__restrict__ maskV, const int *_
 template <bool LAST, bool PREDIV>
 __global__ void __launch_bounds__(256) k_sub_vertices(SihDev d, const int *__restrict__ list, int nList)
 {
-    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    int v = xcdChunkedBlock() * blockDim.x + threadIdx.x;
     if (list) {
         if (v >= nList) return;
         v = list[v];
