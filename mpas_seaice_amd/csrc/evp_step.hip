@@ -151,6 +151,10 @@ void sih_bind_dev(sih_ctx *c)
         // SIH_STREAM_HINTS = 0 / 1 / 2 overrides.
         const char *e = getenv("SIH_STREAM_HINTS");
         d.streamHints = e ? atoi(e) : (c->nCells >= 400000 ? 2 : (c->nCells >= 120000 ? 1 : 0));
+        // the cell kernel's blocks in contiguous eighths per XCD (xcdChunkedBlock): 164 k cells 5 % faster, 655 k cells
+        // 4 % slower (the vertex kernel gains at every size and always has it); SIH_XCD_CHUNKS = 0 / 1 overrides
+        const char *x = getenv("SIH_XCD_CHUNKS");
+        d.chunkCells = x ? (atoi(x) != 0) : (c->nCells < 400000);
     }
 }
 
@@ -709,7 +713,7 @@ __global__ void __launch_bounds__(64 * M) k_sub_cells_split(SihDev d, const int 
     __shared__ double su[M][64], sv[M][64], s11[M][64], s22[M][64], s12[M][64];
     __shared__ int arrived;  // waves of the block that have left their part of corner 0's sums (deriveRow)
     const int lane = threadIdx.x, g = threadIdx.y;
-    int c = xcdChunkedBlock() * 64 + lane;
+    int c = (d.chunkCells ? xcdChunkedBlock() : (int)blockIdx.x) * 64 + lane;
     bool inRange;
     if (list) {
         inRange = c < nList;

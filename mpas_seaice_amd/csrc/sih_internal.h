@@ -69,6 +69,7 @@ struct SihDev {
     int relation, useOcean, quadratic, useAir, tiltMode, useColumn, haloVertices;
     int symMetric;  // basisIntegralsMetric(s, j) == (j, s) bit for bit: the cell kernels read one of each pair
     int deriveGrad; // where the three gradients met at a corner sum to zero to rounding the corner's own is not fetched
+    int chunkCells;   // the split cell kernel maps its blocks to contiguous eighths of the cells per XCD
     int streamHints;  // the cell kernel's non-temporal marks: 1 stresses and partial sums (large blocks), 2 the basis arrays too (huge ones)
     int deriveRow;  // basisIntegralsU / V: the first velocity corner's row of a marked cell (bit 9 of nEdgesDerive) is minus the
                     // sum of the other rows, bit for bit, and the split cell kernel forms it on the chip instead of fetching it
