@@ -201,7 +201,7 @@ int sih_persist_launch(sih_ctx *c, int n);
 int sih_persist_status(sih_ctx *c);
 double sih_persist_info(sih_ctx *c, int what);
 // the same tiles as one launch per iteration, for blocks that cannot stay resident (evp_persist.hip)
-#define SIH_FUSED_MAX_CELLS_DEFAULT 100000
+#define SIH_FUSED_MAX_CELLS_DEFAULT 70000  // (88 k cells: two kernels 28.1 us an iteration, fused 28.9; 47 k cells: 18.2 / 17.7)
 bool sih_fused_usable(sih_ctx *c);
 int sih_fused_launch(sih_ctx *c, int m);
 int sih_comm_push(sih_ctx *c, int nFields, const char *const *names, hipStream_t stream);
