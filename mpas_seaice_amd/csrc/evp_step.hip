@@ -1050,16 +1050,25 @@ __global__ void __launch_bounds__(256) k_sub_vertices(SihDev d, const int *__res
     } else if (v >= d.nVertices) {
         return;
     }
+    // (the places of the vertex's partial sums are requested with the flags that decide whether it is solved -- the
+    // planes are padded, every address is valid --: the sums themselves then travel together with everything else the
+    // solve reads, two memory round trips a thread instead of three)
+    const int PV = d.padV;
+    int g3[3] = {0, 0, 0};
+    if (!PREDIV && d.D == 3) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) g3[k] = d.gidx[k * PV + v];
+    }
+    const int solvedFlag = d.solveVelocity[v];
     if (d.haloVertices) {  // halo vertices with all three cells in the block are updated redundantly
         if (!d.vActive[v]) return;
     } else if (v >= d.nVerticesSolve) {
         return;
     }
-    if (d.solveVelocity[v] != 1) {
+    if (solvedFlag != 1) {
         if (LAST && !d.useOcean) d.ocnCoeff[v] = 0.0;
         return;
     }
-    const int PV = d.padV;
     double dU = 0.0, dV = 0.0;
     if (PREDIV) {
         dU = d.divU[v];
@@ -1070,9 +1079,8 @@ __global__ void __launch_bounds__(256) k_sub_vertices(SihDev d, const int *__res
         if (d.D == 3) {
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                int g = d.gidx[k * PV + v];
-                dU = dU + d.partU[g];
-                dV = dV + d.partV[g];
+                dU = dU + d.partU[g3[k]];
+                dV = dV + d.partV[g3[k]];
             }
         } else {
             for (int k = 0; k < d.D; k++) {
