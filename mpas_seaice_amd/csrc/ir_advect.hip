@@ -1392,12 +1392,16 @@ __global__ void __launch_bounds__(256, 4) k_ir_flux_walk(IrDev d, const IrTabEnt
     const int cat = (int)ucat;
     const size_t pe = d.padE, pc = d.padC;
     for (int sl = 0; sl < nSlots; sl++) fl[sl * 256 + tid] = 0.0;
+    const int eSafe = e < d.nEdges ? e : 0;
     const int cnt = e < d.nEdges ? d.triCount[e] : 0;
     // area and source cell of a triangle are requested one triangle ahead, and the first record of the next
     // triangle with the last step of this one: a triangle then starts with one memory round trip in front of it
     // (its vertices) instead of two in a row (its source cell, then that cell's first record)
-    double areaN = cnt > 0 ? d.triArea[e] : 0.0;
-    int cellN = cnt > 0 ? d.triCell[e] : 0;
+    // (the first triangle's area and cell are requested together with the count, not after it)
+    const double area0 = d.triArea[eSafe];
+    const int cell0 = d.triCell[eSafe];
+    double areaN = cnt > 0 ? area0 : 0.0;
+    int cellN = cnt > 0 ? cell0 : 0;
     double cur[3] = {0.0, 0.0, 0.0};
     bool curReady = false;  // `cur` holds the first record of the triangle at hand
     const IrTabEntry T0 = tab[steps[0].ti];
